@@ -1,0 +1,64 @@
+// emu_backend.cpp -- host emulation of the device backend (TEST INFRASTRUCTURE ONLY).
+// Runs the very same kernel functors (orz_amd/csrc/orz_kernels.h) and orchestration
+// (orz_pipeline.h) in host loops, so the CPU-only test tier can check the encoder's logic
+// byte-for-byte against the oracle without a GPU.  Never linked into the product library.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "../../orz_amd/csrc/orz_pipeline.h"
+
+namespace {
+struct EmuBackend {
+    template <class T> T* alloc(size_t n) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
+    void free(void* p) { std::free(p); }
+    void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
+    void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
+    void sync() {}
+    double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    template <class F> void launch(size_t n, const F& f) {
+        for (size_t i = 0; i < n; i++) f(i);
+    }
+    const uint64_t* sort_u64(uint64_t* a, uint64_t*, size_t n, int bits) {
+        uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+        std::sort(a, a + n, [mask](uint64_t x, uint64_t y) { return (x & mask) < (y & mask); });
+        return a;
+    }
+    void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
+        uint32_t run = 0;
+        for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = run; run += v; }
+    }
+    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
+        for (uint32_t c = 0; c < 512; c++) {
+            uint16_t value[orz::kSyms], index[orz::kSyms];
+            orz::symrank_run(value, index, srstate + (size_t)c * orz::kSrWords, gsym, grank, rstart[c], rstart[c + 1]);
+        }
+    }
+};
+}  // namespace
+
+extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, unsigned seg, unsigned win,
+                          uint8_t** dst, size_t* dst_len, unsigned long long* stats5) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, seg, win ? win : 0xffffffffu);
+        std::vector<uint8_t> out;
+        orz::encode_stream(enc, be, src, n, false, out);
+        *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        if (stats5) {
+            stats5[0] = enc.stats.blocks; stats5[1] = enc.stats.sweeps; stats5[2] = enc.stats.seg_evals;
+            stats5[3] = enc.stats.items; stats5[4] = enc.stats.chunks;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_encode: %s\n", e.what());
+        return -1;
+    }
+}
+extern "C" void emu_free(void* p) { std::free(p); }
