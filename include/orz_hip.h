@@ -1,0 +1,99 @@
+/*
+ * orz_hip.h -- C ABI of the MI355X-native orz encoder (liborz_hip.so).
+ *
+ * This is the drop-in boundary of the repo: plain C, pointers and sizes only.  The reference
+ * (richox/orz v1.6.1, Rust) exports no C symbols (its `// pub mod ffi;` at src/lib.rs:10 is dead),
+ * so each entry point below replaces the Rust call surface that `orz::encode` / `orz::decode`
+ * use; the file:line of the interface it stands in for is cited per function.  INTEGRATION.md
+ * shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Error convention: 0 = ok, negative = failure (ORZ_E*); nothing throws across the boundary.
+ * orz_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef ORZ_HIP_H
+#define ORZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORZ_OK 0
+#define ORZ_EINVAL (-22)  /* bad argument / InvalidData (io::ErrorKind::InvalidData, src/lz.rs:413-415) */
+#define ORZ_ENOMEM (-12)  /* output buffer too small / allocation failure */
+#define ORZ_EIO (-5)      /* read/write callback failed (io::Error from Read/Write, src/lib.rs:58-63) */
+#define ORZ_ENODEV (-19)  /* no usable HIP device, or a HIP runtime error */
+
+/* src/lib.rs:31-34,54-55 -- window geometry the object-level API inherits */
+#define ORZ_LZ_BLOCK_SIZE ((1u << 25) - 1)
+#define ORZ_SBVEC_SENTINEL_LEN 480u
+#define ORZ_SBVEC_PREMATCH_LEN (ORZ_LZ_BLOCK_SIZE / 2)
+
+/* mirrors #[repr(C)] LZCfg, src/lz.rs:32-37 (three usize) */
+typedef struct {
+    size_t match_depth, lazy_match_depth1, lazy_match_depth2;
+} orz_lzcfg;
+
+/* level -> LZCfg, src/main.rs:97-102.  Returns ORZ_EINVAL for levels other than 0,1,2. */
+int orz_lzcfg_from_level(int level, orz_lzcfg* out);
+
+/* ---- object level: LZEncoder (src/lz.rs:69-346) --------------------------------------------- */
+typedef struct orz_lz_encoder orz_lz_encoder;
+
+/* LZEncoder::new, src/lz.rs:75-80.  `device` = HIP device ordinal.  NULL on failure. */
+orz_lz_encoder* orz_lz_encoder_new(int device);
+void orz_lz_encoder_free(orz_lz_encoder*);
+
+/* LZEncoder::encode(&mut self, &LZCfg, sbuf, tbuf, spos) -> (spos, tpos), src/lz.rs:89-95,346.
+ * Preconditions inherited from src/lib.rs:67-69: sbuf points ORZ_SBVEC_SENTINEL_LEN bytes inside
+ * an allocation and sbuf[-480 .. sbuf_len+480) is readable (bytes past sbuf_len influence tail
+ * decisions exactly as in the reference); spos >= ORZ_SBVEC_PREMATCH_LEN on the first call of a
+ * block.  Produces ONE chunk (at most 2^20 items) per call like the reference.  The device parses
+ * the whole block on the first call of a block and hands the remaining chunks out on the following
+ * calls, which must continue at the returned *spos_out with the same sbuf contents. */
+int orz_lz_encoder_encode(orz_lz_encoder*, const orz_lzcfg*, const uint8_t* sbuf, size_t sbuf_len, uint8_t* tbuf,
+                          size_t tbuf_cap, size_t spos, size_t* spos_out, size_t* tlen_out);
+/* LZEncoder::forward, src/lz.rs:82-87 (forward_len must be 2^24 = LZ_BLOCK_SIZE - PREMATCH, the
+ * only value the reference ever passes, src/lib.rs:84). */
+int orz_lz_encoder_forward(orz_lz_encoder*, size_t forward_len);
+
+/* ---- stream level: orz::encode (src/lib.rs:58-92) ------------------------------------------- */
+typedef ssize_t (*orz_read_fn)(void* ctx, uint8_t* buf, size_t cap); /* 0 = EOF, <0 = error */
+typedef int (*orz_write_fn)(void* ctx, const uint8_t* buf, size_t len);
+/* ProgressLogger, src/progress.rs:9-13 */
+typedef void (*orz_progress_fn)(void* ctx, int is_finish, size_t in_bytes, size_t out_bytes);
+
+int orz_encode(orz_read_fn, void* rctx, orz_write_fn, void* wctx, const orz_lzcfg*, orz_progress_fn, void* pctx,
+               int device);
+
+/* ---- reusable stream encoder on caller memory (what bench.py and the Python mirror drive) ---- */
+typedef struct {
+    uint64_t blocks, sweeps, seg_evals, items, chunks, in_bytes, out_bytes;
+    double t_prep_s, t_parse_s, t_post_s; /* host clock around device syncs */
+    double parse_kernel_ms;               /* HIP-event time of the parse kernel launches (sum) */
+    uint64_t parse_launches;
+    double total_ms;                      /* HIP-event time of the whole encode on the stream */
+} orz_encode_stats;
+
+typedef struct orz_stream orz_stream;
+orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg);
+void orz_stream_free(orz_stream*);
+/* tuning: bytes per speculative segment and segments per sweep window (0 = keep) */
+int orz_stream_set_tuning(orz_stream*, unsigned seg_bytes, unsigned window_segs);
+/* Encode `n` bytes at `src` (host memory, or device memory when src_on_device != 0) into a
+ * malloc()ed orz stream (*dst, free with orz_free).  Same bytes as `orz encode` would write. */
+int orz_stream_encode(orz_stream*, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
+                      orz_encode_stats* stats);
+void orz_free(void* p);
+
+int orz_device_count(void);
+const char* orz_last_error(void);
+const char* orz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""ctypes binding of liborz_hip.so (C ABI in include/orz_hip.h).
+
+The library is the product; there is deliberately no Python or CPU fallback: if the shared object
+is missing or no HIP device is usable, constructing an encoder raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liborz_hip.so")
+
+
+class LZCfg(ctypes.Structure):
+    """#[repr(C)] LZCfg of the reference (src/lz.rs:32-37): three usize."""
+
+    _fields_ = [
+        ("match_depth", ctypes.c_size_t),
+        ("lazy_match_depth1", ctypes.c_size_t),
+        ("lazy_match_depth2", ctypes.c_size_t),
+    ]
+
+
+class EncodeStats(ctypes.Structure):
+    _fields_ = [
+        ("blocks", ctypes.c_uint64),
+        ("sweeps", ctypes.c_uint64),
+        ("seg_evals", ctypes.c_uint64),
+        ("items", ctypes.c_uint64),
+        ("chunks", ctypes.c_uint64),
+        ("in_bytes", ctypes.c_uint64),
+        ("out_bytes", ctypes.c_uint64),
+        ("t_prep_s", ctypes.c_double),
+        ("t_parse_s", ctypes.c_double),
+        ("t_post_s", ctypes.c_double),
+        ("parse_kernel_ms", ctypes.c_double),
+        ("parse_launches", ctypes.c_uint64),
+        ("total_ms", ctypes.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+READ_FN = ctypes.CFUNCTYPE(ctypes.c_ssize_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+WRITE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t)
+
+# every symbol include/orz_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("orz_lzcfg_from_level", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LZCfg)]),
+    ("orz_lz_encoder_new", ctypes.c_void_p, [ctypes.c_int]),
+    ("orz_lz_encoder_free", None, [ctypes.c_void_p]),
+    (
+        "orz_lz_encoder_encode",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(LZCfg), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+         ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
+    ),
+    ("orz_lz_encoder_forward", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    (
+        "orz_encode",
+        ctypes.c_int,
+        [READ_FN, ctypes.c_void_p, WRITE_FN, ctypes.c_void_p, ctypes.POINTER(LZCfg), PROGRESS_FN, ctypes.c_void_p,
+         ctypes.c_int],
+    ),
+    ("orz_stream_new", ctypes.c_void_p, [ctypes.c_int, ctypes.POINTER(LZCfg)]),
+    ("orz_stream_free", None, [ctypes.c_void_p]),
+    ("orz_stream_set_tuning", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    (
+        "orz_stream_encode",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(EncodeStats)],
+    ),
+    ("orz_free", None, [ctypes.c_void_p]),
+    ("orz_device_count", ctypes.c_int, []),
+    ("orz_last_error", ctypes.c_char_p, []),
+    ("orz_version", ctypes.c_char_p, []),
+]
+
+_lib = None
+
+
+def load():
+    """Load liborz_hip.so and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "liborz_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().orz_last_error().decode("utf-8", "replace")

@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference's encoder interface, driving liborz_hip.so.
+
+  cfg_for_level   src/main.rs:97-102
+  LZEncoder       src/lz.rs:69-95   (new / encode / forward, one chunk per encode() call)
+  encode          src/lib.rs:58-92  (Read -> Write stream encode)
+  StreamEncoder / encode_bytes : reusable whole-buffer encoder (what bench.py times)
+"""
+import ctypes
+
+from . import _native
+from ._native import EncodeStats, LZCfg
+
+
+class OrzError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise OrzError("%s failed (%d): %s" % (what, rc, _native.last_error()))
+
+
+def cfg_for_level(level):
+    """level -> LZCfg exactly as `orz encode -l` maps it (src/main.rs:97-102); other levels raise."""
+    cfg = LZCfg()
+    rc = _native.load().orz_lzcfg_from_level(int(level), ctypes.byref(cfg))
+    if rc != 0:
+        raise ValueError("invalid level")
+    return cfg
+
+
+class StreamEncoder:
+    """One orz stream encoder bound to one GPU; reusable across inputs."""
+
+    def __init__(self, device=0, level=1, cfg=None):
+        self._lib = _native.load()
+        self.cfg = cfg if cfg is not None else cfg_for_level(level)
+        self._h = self._lib.orz_stream_new(int(device), ctypes.byref(self.cfg))
+        if not self._h:
+            raise OrzError("orz_stream_new failed: " + _native.last_error())
+
+    def set_tuning(self, seg_bytes=0, window_segs=0):
+        _check(self._lib.orz_stream_set_tuning(self._h, seg_bytes, window_segs), "orz_stream_set_tuning")
+
+    def _encode(self, ptr, n, on_device, want_stats):
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        dlen = ctypes.c_size_t()
+        st = EncodeStats()
+        rc = self._lib.orz_stream_encode(
+            self._h, ptr, n, 1 if on_device else 0, ctypes.byref(dst), ctypes.byref(dlen),
+            ctypes.byref(st) if want_stats else None,
+        )
+        _check(rc, "orz_stream_encode")
+        try:
+            out = ctypes.string_at(dst, dlen.value)
+        finally:
+            self._lib.orz_free(dst)
+        return out, (st.as_dict() if want_stats else None)
+
+    def encode(self, data, stats=False):
+        """bytes -> orz stream (same bytes `orz encode` writes)."""
+        data = bytes(data)
+        buf = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
+        out, st = self._encode(ctypes.cast(buf, ctypes.c_void_p), len(data), False, stats)
+        return (out, st) if stats else out
+
+    def encode_device(self, dev_ptr, nbytes, stats=False):
+        """Encode `nbytes` already resident in this GPU's HBM at address `dev_ptr`."""
+        out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats)
+        return (out, st) if stats else out
+
+    def close(self):
+        if self._h:
+            self._lib.orz_stream_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_bytes(data, level=1, device=0):
+    enc = StreamEncoder(device=device, level=level)
+    try:
+        return enc.encode(data)
+    finally:
+        enc.close()
+
+
+def encode(src, dst, cfg, progress=None, device=0):
+    """orz::encode (src/lib.rs:58-92): read everything from file-like `src`, write the stream to `dst`.
+
+    `progress(is_finish, in_bytes, out_bytes)` mirrors ProgressLogger (src/progress.rs:9-13).
+    Returns (bytes_read, bytes_written) like the reference's CountRead/CountWrite totals."""
+    lib = _native.load()
+    counts = [0, 0]
+
+    def _rd(_ctx, buf, cap):
+        try:
+            chunk = src.read(cap)
+        except Exception:
+            return -1
+        n = len(chunk)
+        if n:
+            ctypes.memmove(buf, chunk, n)
+            counts[0] += n
+        return n
+
+    def _wr(_ctx, buf, n):
+        try:
+            dst.write(ctypes.string_at(buf, n))
+        except Exception:
+            return -1
+        counts[1] += n
+        return 0
+
+    def _pg(_ctx, fin, a, b):
+        if progress:
+            progress(bool(fin), a, b)
+
+    rd, wr, pg = _native.READ_FN(_rd), _native.WRITE_FN(_wr), _native.PROGRESS_FN(_pg)
+    _check(lib.orz_encode(rd, None, wr, None, ctypes.byref(cfg), pg, None, int(device)), "orz_encode")
+    return tuple(counts)
+
+
+class LZEncoder:
+    """Object-level mirror of the reference's LZEncoder (src/lz.rs:69-95).
+
+    `encode(cfg, window, sbuf_len, spos)` takes the caller's window allocation INCLUDING the two
+    480-byte sentinel pads (i.e. `window[480]` is sbuf[0], as `orz::encode` lays it out,
+    src/lib.rs:67-69) and returns (spos_out, chunk_bytes)."""
+
+    def __init__(self, device=0):
+        self._lib = _native.load()
+        self._h = self._lib.orz_lz_encoder_new(int(device))
+        if not self._h:
+            raise OrzError("orz_lz_encoder_new failed: " + _native.last_error())
+        self._tbuf = ctypes.create_string_buffer(3 * 16777215)
+
+    def encode(self, cfg, window, sbuf_len, spos):
+        base = ctypes.addressof(window) if not isinstance(window, int) else window
+        so, tl = ctypes.c_size_t(), ctypes.c_size_t()
+        rc = self._lib.orz_lz_encoder_encode(
+            self._h, ctypes.byref(cfg), ctypes.c_void_p(base + 480), sbuf_len, self._tbuf, len(self._tbuf), spos,
+            ctypes.byref(so), ctypes.byref(tl),
+        )
+        _check(rc, "orz_lz_encoder_encode")
+        return so.value, self._tbuf.raw[: tl.value]
+
+    def forward(self, forward_len):
+        _check(self._lib.orz_lz_encoder_forward(self._h, forward_len), "orz_lz_encoder_forward")
+
+    def close(self):
+        if self._h:
+            self._lib.orz_lz_encoder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,290 @@
+// orz_capi.hip -- C ABI of liborz_hip.so (declared in include/orz_hip.h).
+//
+// Host side of the MI355X encoder: mirrors the reference's LZEncoder / orz::encode call surface
+// (/root/reference/src/lz.rs:69-95, src/lib.rs:58-92) on top of StreamEncoder<HipBackend>.
+// There is no CPU fallback: if no HIP device is usable every constructor fails with ORZ_ENODEV.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/orz_hip.h"
+#include "backend_hip.h"
+#include "orz_stream.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+orz::Cfg to_cfg(const orz_lzcfg* c) {
+    return orz::Cfg{(int)c->match_depth, (int)c->lazy_match_depth1, (int)c->lazy_match_depth2};
+}
+bool cfg_ok(const orz_lzcfg* c) {
+    return c && c->match_depth >= 1 && c->match_depth <= 200 && c->lazy_match_depth1 <= 200 &&
+           c->lazy_match_depth2 <= 200;
+}
+
+constexpr unsigned kDefaultSeg = 64, kDefaultWin = 4096;
+
+unsigned env_u(const char* name, unsigned dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? (unsigned)std::strtoul(v, nullptr, 10) : dflt;
+}
+
+using Enc = orz::StreamEncoder<orz::HipBackend>;
+
+}  // namespace
+
+struct orz_stream {
+    std::unique_ptr<orz::HipBackend> be;
+    std::unique_ptr<Enc> enc;
+    orz_lzcfg cfg;
+    unsigned seg, win;
+    void rebuild() {
+        enc.reset();
+        enc.reset(new Enc(*be, to_cfg(&cfg), seg, win));
+    }
+};
+
+struct orz_lz_encoder {
+    std::unique_ptr<orz::HipBackend> be;
+    std::unique_ptr<Enc> enc;
+    orz_lzcfg cfg{0, 0, 0};
+    unsigned seg, win;
+    // chunks of the block parsed last, handed out one per encode() call
+    std::vector<uint8_t> framed;  // { LEB128(t) chunk[t] }*
+    size_t framed_pos = 0;
+    std::vector<size_t> chunk_end_spos;
+    size_t next_chunk = 0;
+    size_t expect_spos = 0;
+    bool first_block = true;
+};
+
+extern "C" {
+
+const char* orz_last_error(void) { return g_err.c_str(); }
+const char* orz_version(void) { return "orz_hip 0.1 (bitstream: richox/orz 1.6.1)"; }
+
+int orz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orz_lzcfg_from_level(int level, orz_lzcfg* out) {  // src/main.rs:97-102
+    if (!out) return fail(ORZ_EINVAL, "null cfg");
+    switch (level) {
+        case 0: *out = orz_lzcfg{5, 3, 2}; return ORZ_OK;
+        case 1: *out = orz_lzcfg{15, 9, 6}; return ORZ_OK;
+        case 2: *out = orz_lzcfg{45, 27, 18}; return ORZ_OK;
+        default: return fail(ORZ_EINVAL, "invalid level");
+    }
+}
+
+void orz_free(void* p) { std::free(p); }
+
+// ------------------------------------------------------------------------------ orz_stream
+orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
+    if (!cfg_ok(cfg)) { fail(ORZ_EINVAL, "bad LZCfg"); return nullptr; }
+    try {
+        if (device < 0 || device >= orz_device_count()) { fail(ORZ_ENODEV, "no such HIP device"); return nullptr; }
+        std::unique_ptr<orz_stream> s(new orz_stream);
+        s->be.reset(new orz::HipBackend(device));
+        s->cfg = *cfg;
+        s->seg = env_u("ORZ_SEG", kDefaultSeg);
+        s->win = env_u("ORZ_WIN", kDefaultWin);
+        s->rebuild();
+        return s.release();
+    } catch (const std::exception& e) {
+        fail(ORZ_ENODEV, e.what());
+        return nullptr;
+    }
+}
+void orz_stream_free(orz_stream* s) {
+    if (!s) return;
+    s->enc.reset();
+    s->be.reset();
+    delete s;
+}
+int orz_stream_set_tuning(orz_stream* s, unsigned seg_bytes, unsigned window_segs) {
+    if (!s) return fail(ORZ_EINVAL, "null stream");
+    try {
+        if (seg_bytes) s->seg = seg_bytes;
+        if (window_segs) s->win = window_segs;
+        s->rebuild();
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
+}
+int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
+                      orz_encode_stats* stats) {
+    if (!s || !dst || !dst_len || (!src && n)) return fail(ORZ_EINVAL, "null argument");
+    try {
+        std::vector<uint8_t> out;
+        out.reserve(n / 3 + 4096);
+        orz::HipBackend& be = *s->be;
+        be.set_timing(stats != nullptr);
+        hipEvent_t e0, e1;
+        ORZ_HIP_CHECK(hipEventCreate(&e0));
+        ORZ_HIP_CHECK(hipEventCreate(&e1));
+        ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
+        orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out);
+        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
+        be.sync();
+        float total = 0;
+        ORZ_HIP_CHECK(hipEventElapsedTime(&total, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (stats) {
+            const orz::EncodeStats& st = s->enc->stats;
+            stats->blocks = st.blocks; stats->sweeps = st.sweeps; stats->seg_evals = st.seg_evals;
+            stats->items = st.items; stats->chunks = st.chunks; stats->in_bytes = st.in_bytes;
+            stats->out_bytes = out.size();
+            stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
+            stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches);
+            stats->total_ms = total;
+        }
+        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+        std::memcpy(p, out.data(), out.size());
+        *dst = p;
+        *dst_len = out.size();
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_ENODEV, e.what());
+    }
+}
+
+// ------------------------------------------------------------------------------ orz_lz_encoder
+orz_lz_encoder* orz_lz_encoder_new(int device) {
+    try {
+        if (device < 0 || device >= orz_device_count()) { fail(ORZ_ENODEV, "no such HIP device"); return nullptr; }
+        std::unique_ptr<orz_lz_encoder> e(new orz_lz_encoder);
+        e->be.reset(new orz::HipBackend(device));
+        e->seg = env_u("ORZ_SEG", kDefaultSeg);
+        e->win = env_u("ORZ_WIN", kDefaultWin);
+        return e.release();
+    } catch (const std::exception& ex) {
+        fail(ORZ_ENODEV, ex.what());
+        return nullptr;
+    }
+}
+void orz_lz_encoder_free(orz_lz_encoder* e) {
+    if (!e) return;
+    e->enc.reset();
+    e->be.reset();
+    delete e;
+}
+
+int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t* sbuf, size_t sbuf_len, uint8_t* tbuf,
+                          size_t tbuf_cap, size_t spos, size_t* spos_out, size_t* tlen_out) {
+    if (!e || !sbuf || !tbuf || !spos_out || !tlen_out || !cfg_ok(cfg)) return fail(ORZ_EINVAL, "bad argument");
+    if (sbuf_len > orz::kBlock || spos > sbuf_len || spos < orz::kPre) return fail(ORZ_EINVAL, "bad window geometry");
+    try {
+        const bool same_cfg = e->enc && std::memcmp(&e->cfg, cfg, sizeof *cfg) == 0;
+        if (!e->enc) {
+            e->cfg = *cfg;
+            e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, e->win));
+        } else if (!same_cfg) {
+            return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
+        }
+        const bool continuing = e->next_chunk < e->chunk_end_spos.size() && spos == e->expect_spos;
+        if (!continuing) {
+            if (spos != orz::kPre) return fail(ORZ_EINVAL, "a block must start at SBVEC_PREMATCH_LEN");
+            // upload the caller's window exactly as it is, sentinel pads included (src/lib.rs:67-69)
+            e->be->h2d(e->enc->dwinbuf(), sbuf - orz::kSent, (size_t)sbuf_len + 2 * orz::kSent);
+            e->framed.clear();
+            e->chunk_end_spos.clear();
+            e->enc->encode_block((uint32_t)(sbuf_len - orz::kPre), e->framed, &e->chunk_end_spos);
+            e->framed_pos = 0;
+            e->next_chunk = 0;
+        }
+        // un-frame the next chunk: LEB128(t) chunk[t]
+        size_t t = 0, shift = 0, at = e->framed_pos;
+        for (;;) {
+            uint8_t b = e->framed[at++];
+            t |= (size_t)(b & 0x7f) << shift;
+            shift += 7;
+            if (!(b & 0x80)) break;
+        }
+        if (t > tbuf_cap) return fail(ORZ_ENOMEM, "tbuf too small");
+        std::memcpy(tbuf, e->framed.data() + at, t);
+        e->framed_pos = at + t;
+        *tlen_out = t;
+        *spos_out = e->chunk_end_spos[e->next_chunk++];
+        e->expect_spos = *spos_out;
+        return ORZ_OK;
+    } catch (const std::exception& ex) {
+        return fail(ORZ_ENODEV, ex.what());
+    }
+}
+
+int orz_lz_encoder_forward(orz_lz_encoder* e, size_t forward_len) {
+    if (!e || !e->enc) return fail(ORZ_EINVAL, "forward before encode");
+    if (forward_len != orz::kNewMax) return fail(ORZ_EINVAL, "forward_len must be 2^24");
+    try {
+        e->enc->slide(false);  // the caller re-supplies the slid window on the next encode()
+        e->chunk_end_spos.clear();
+        e->next_chunk = 0;
+        return ORZ_OK;
+    } catch (const std::exception& ex) {
+        return fail(ORZ_ENODEV, ex.what());
+    }
+}
+
+// ------------------------------------------------------------------------------ orz::encode
+int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const orz_lzcfg* cfg, orz_progress_fn prog,
+               void* pctx, int device) {
+    if (!rd || !wr || !cfg_ok(cfg)) return fail(ORZ_EINVAL, "bad argument");
+    orz_stream* s = orz_stream_new(device, cfg);
+    if (!s) return ORZ_ENODEV;
+    int rc = ORZ_OK;
+    try {
+        Enc& enc = *s->enc;
+        orz::HipBackend& be = *s->be;
+        enc.reset();
+        std::vector<uint8_t> in(orz::kNewMax), out;
+        size_t in_total = 0, out_total = 0;
+        bool first = true;
+        for (;;) {
+            // read_repeatedly, src/lib.rs:42-52: fill the block or hit EOF
+            size_t got = 0;
+            while (got < in.size()) {
+                ssize_t r = rd(rctx, in.data() + got, in.size() - got);
+                if (r < 0) { rc = fail(ORZ_EIO, "read failed"); break; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            if (rc != ORZ_OK || got == 0) break;
+            if (!first) enc.slide();
+            first = false;
+            be.h2d(enc.dwin() + orz::kPre, in.data(), got);
+            out.clear();
+            enc.encode_block((uint32_t)got, out);
+            if (wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }
+            in_total += got;
+            out_total += out.size();
+            if (prog) prog(pctx, 0, in_total, out_total);
+            if (got < in.size()) break;
+        }
+        if (rc == ORZ_OK) {
+            const uint8_t eof = 0;  // write_len(0), src/lib.rs:89
+            if (wr(wctx, &eof, 1) != 0) rc = fail(ORZ_EIO, "write failed");
+            out_total += 1;
+            if (prog) prog(pctx, 1, in_total, out_total);
+        }
+    } catch (const std::exception& ex) {
+        rc = fail(ORZ_ENODEV, ex.what());
+    }
+    orz_stream_free(s);
+    return rc;
+}
+
+}  // extern "C"

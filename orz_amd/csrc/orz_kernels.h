@@ -4,10 +4,7 @@
 // __global__ grid on gfx950, the emulation backend (tests only) runs it in a host loop.
 //
 // What replaces what (reference = /root/reference, Rust):
-//   ParseSeg      LZEncoder::encode parse loop src/lz.rs:131-235 + BucketMatcher::find_match /
-//                 has_lazy_match src/matcher.rs:135-228 + Bucket/BucketMatcher::update :62-80,115-121,
-//                 re-stated as a speculative segment-parallel fixed-point iteration
-//   Rank*         ring ordinals = what Bucket.head / node_size_bounded_sub encode, src/matcher.rs:62-91
+//   (the parse itself -- find_match / has_lazy_match / ring updates -- lives in orz_parse.h)
 //   LenMin*       Bucket::update's match_len_min rule, src/matcher.rs:65-71
 //   ItemSyms      symbol construction src/lz.rs:148,173-189,216-230
 //   SymRank       SymRankCoder src/symrank.rs:38-97 driven by src/lz.rs:274-305
@@ -37,313 +34,7 @@ template <class T, class U> inline T orz_fetch_or(T* p, U v) { T o = *p; *p = (T
 namespace orz {
 
 // ---------------------------------------------------------------------------------------------
-// K0: per-position keys.  Builds the two sort inputs of a block:
-//   ent[j]  = bucket_key(x) << 25 | x   for history item starts x in [1,P) and all x in [P,len)
-//   kent[j] = hash2(u-1)    << 25 | u   for u in [P-1,len)       (word-predictor chain)
-struct BuildEntries {
-    const uint8_t* win;     // window base, win[-480 .. kBlock+480) readable
-    const uint32_t* hpos;   // compacted history item starts (ascending), nhist entries
-    uint32_t nhist, n;      // n new bytes
-    uint64_t* ent;          // nhist + n
-    uint64_t* kent;         // n + 1
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid < nhist) {
-            uint32_t x = hpos[tid];
-            ent[tid] = ((uint64_t)bucket_key(win, x) << kPosBits) | x;
-        } else if (tid < (size_t)nhist + n) {
-            uint32_t x = kPre + (uint32_t)(tid - nhist);
-            ent[tid] = ((uint64_t)bucket_key(win, x) << kPosBits) | x;
-        }
-        if (tid < (size_t)n + 1) {
-            uint32_t u = kPre - 1 + (uint32_t)tid;
-            kent[tid] = ((uint64_t)hash2(win, u - 1) << kPosBits) | u;
-        }
-    }
-};
-
-// after sorting: idx[x] = slot of in-block position x in ent; kidx[u] likewise for kent
-struct ScatterIndex {
-    const uint64_t* ent;
-    uint32_t nent;
-    uint32_t* idx;  // indexed by window offset
-    uint32_t lo;    // only positions >= lo are scattered
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid >= nent) return;
-        uint32_t x = (uint32_t)(ent[tid] & kPosMask);
-        if (x >= lo) idx[x] = (uint32_t)tid;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// Parse state of one stream on the device (window offsets index every per-position array).
-struct ParseState {
-    const uint8_t* win;
-    uint32_t len;        // kPre + n
-    uint32_t seg_size;   // bytes per segment (>= 256, multiple of 8)
-    uint32_t nseg;
-    const uint64_t* ent;
-    const uint32_t* idx;
-    const uint64_t* kent;
-    const uint32_t* kidx;
-    const uint8_t* wsnap;  // words table at block start, [32768][2]
-    // double-buffered speculative state (old = previous sweep, new = this sweep)
-    const uint8_t* S_old;
-    const uint8_t* E_old;
-    const uint8_t* ML_old;
-    const uint32_t* ORD_old;
-    uint8_t* S_new;
-    uint8_t* E_new;
-    uint8_t* ML_new;
-    uint32_t* ORD_new;
-    const uint32_t* first_old;
-    const uint8_t* lt_old;
-    uint32_t* first_new;
-    uint8_t* lt_new;
-    // single-buffered per-item outputs
-    uint16_t* LR;    // rank of the item among same-ctx items of its segment
-    uint32_t* SRC;   // match source position
-    uint8_t* W0;     // words[hash2(p-1)][0] at the item start (symrank_unlikely)
-    uint8_t* TY;     // type | after_literal << 2
-    const uint32_t* base;  // [nseg+1][256] items of ctx c before segment sg (stream ordinals)
-    uint32_t* first_changed;
-    uint8_t lt0;     // last item type before the block (after_literal carry)
-    Cfg cfg;
-};
-
-// One lane re-parses one segment with the reference's exact decision rules, reading the previous
-// sweep's state for everything outside its own segment.  See DESIGN.md section 3 for why the
-// fixed point of this iteration is the reference's serial parse.
-struct ParseSeg {
-    ParseState s;
-    uint32_t seg0, seg1;  // evaluate segments [seg0, seg1)
-    uint16_t* lcnt;       // [256][seg1-seg0] lane-private per-ctx counters
-
-    struct Cand {
-        uint32_t q, ord, valid;
-    };
-
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t sg = seg0 + (uint32_t)tid;
-        if (sg >= seg1) return;
-        const uint8_t* b = s.win;
-        const uint32_t seg_start = kPre + sg * s.seg_size;
-        const uint32_t seg_end = (seg_start + s.seg_size < s.len) ? seg_start + s.seg_size : s.len;
-        // per-ctx count of this lane's own items so far (lane-private column of a global scratch)
-        const size_t nl = seg1 - seg0;
-        uint16_t* lc = lcnt + tid;
-        for (uint32_t c = 0; c < 256; c++) lc[c * nl] = 0;
-        for (uint32_t x = seg_start; x < seg_end; x++) { s.S_new[x] = 0; s.E_new[x] = 0; s.ML_new[x] = 0; }
-        uint32_t p = sg == 0 ? kPre : s.first_old[sg];
-        uint32_t lt = sg == 0 ? s.lt0 : s.lt_old[sg];
-        if (sg > 0 && p < seg_end) s.E_new[p] = (lt != kTyWord);
-
-        while (p < seg_end) {
-            const uint32_t c = hash1(b, p - 1);
-            // ---- word predictor lookup: latest in-block update of key hash2(p-1), else snapshot
-            uint32_t kk = hash2(b, p - 1);
-            uint8_t w0 = s.wsnap[kk * 2], w1 = s.wsnap[kk * 2 + 1];
-            {
-                uint32_t j = s.kidx[p];
-                while (j > 0) {
-                    j--;
-                    uint64_t e = s.kent[j];
-                    if ((uint32_t)(e >> kPosBits) != kk) break;
-                    uint32_t u = (uint32_t)(e & kPosMask);
-                    if (u + 2 > p) continue;
-                    uint32_t en = u + 2;
-                    uint8_t eb = en >= seg_start ? s.E_new[en] : s.E_old[en];
-                    if (eb) { w0 = b[u]; w1 = b[u + 1]; break; }
-                }
-            }
-            const uint32_t lwm = (b[p] == w0 && b[p + 1] == w1);
-            // ---- find_match (src/matcher.rs:135-192)
-            const uint32_t hcnt = s.base[(size_t)sg * 256 + c] + lc[c * nl];
-            uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0;
-            uint32_t mld = ld32(b + p + max_len - 3);
-            {
-                const uint32_t key = bucket_key(b, p);
-                uint32_t j = s.idx[p];
-                int cnt = 0;
-                while (j > 0 && cnt < s.cfg.depth) {
-                    j--;
-                    uint64_t e = s.ent[j];
-                    if ((uint32_t)(e >> kPosBits) != key) break;
-                    uint32_t q = (uint32_t)(e & kPosMask);
-                    uint8_t sv = q >= seg_start ? s.S_new[q] : s.S_old[q];
-                    if (!sv) continue;
-                    uint32_t oq = q >= seg_start ? s.ORD_new[q] : s.ORD_old[q];
-                    if (hcnt - 1 - oq > kRing - 1) break;  // fell out of the 4094-entry ring
-                    cnt++;
-                    if (ld32(b + q + max_len - 3) == mld) {
-                        uint32_t l = lcp240(b, q, p);
-                        if (l > max_len) {
-                            mlexp = q >= seg_start ? s.ML_new[q] : s.ML_old[q];
-                            max_len = l;
-                            bestq = q;
-                            besto = oq;
-                            mld = ld32(b + p + max_len - 3);
-                        }
-                        if (l == kMaxLen) break;
-                        if (mlexp > 0 && l > mlexp) break;
-                    }
-                }
-            }
-            const bool is_match = max_len >= kMinLen && p + max_len < s.len;
-            uint32_t lazy = 0;
-            if (is_match && max_len < kMaxLen / 2) {  // src/lz.rs:151-170
-                const uint32_t ro = hcnt - 1 - besto;
-                const uint32_t l1 = max_len + 1 + (roid_bitlen(ro) < 8), l2 = l1 - lwm;
-                if (has_lazy(seg_start, sg, p, p + 1, l1, s.cfg.lazy1, lc, nl)) lazy = 1;
-                else if (has_lazy(seg_start, sg, p, p + 2, l2, s.cfg.lazy2, lc, nl)) lazy = 2;
-            }
-            // ---- commit the item (src/lz.rs:172-234)
-            s.S_new[p] = 1;
-            s.ORD_new[p] = hcnt;
-            s.LR[p] = lc[c * nl];
-            lc[c * nl]++;
-            s.W0[p] = w0;
-            const uint8_t al = (lt == kTyLit) ? 4 : 0;
-            if (is_match && !lazy) {
-                s.ML_new[p] = (uint8_t)max_len;
-                s.SRC[p] = bestq;
-                s.TY[p] = kTyMatch | al;
-                p += max_len;
-                lt = kTyMatch;
-            } else if (p + 1 < s.len && lazy != 1 && lwm) {
-                s.TY[p] = kTyWord | al;
-                p += 2;
-                lt = kTyWord;
-            } else {
-                s.TY[p] = kTyLit | al;
-                p += 1;
-                lt = kTyLit;
-            }
-            if (p < seg_end) s.E_new[p] = (lt != kTyWord);
-        }
-        s.first_new[sg + 1] = p;
-        s.lt_new[sg + 1] = (uint8_t)lt;
-        // ---- change detection against the previous sweep
-        bool ch = s.first_new[sg + 1] != s.first_old[sg + 1] || s.lt_new[sg + 1] != s.lt_old[sg + 1];
-        for (uint32_t x = seg_start; x < seg_end && !ch; x++)
-            ch = s.S_new[x] != s.S_old[x] || s.ML_new[x] != s.ML_old[x] || s.E_new[x] != s.E_old[x];
-        if (ch) ORZ_ATOMIC_MIN(s.first_changed, sg);
-    }
-
-    // has_lazy_match (src/matcher.rs:194-228) for the probe position x in {p+1, p+2}: candidates
-    // are the items inserted before p, i.e. positions < p.
-    ORZ_HD bool has_lazy(uint32_t seg_start, uint32_t sg, uint32_t p, uint32_t x, uint32_t min_len,
-                         int depth, const uint16_t* lc, size_t nl) const {
-        const uint8_t* b = s.win;
-        const uint32_t cx = hash1(b, x - 1);
-        const uint32_t hx = s.base[(size_t)sg * 256 + cx] + lc[cx * nl];
-        const uint32_t key = bucket_key(b, x);
-        uint32_t j = s.idx[x];
-        int cnt = 0;
-        while (j > 0 && cnt < depth) {
-            j--;
-            uint64_t e = s.ent[j];
-            if ((uint32_t)(e >> kPosBits) != key) break;
-            uint32_t q = (uint32_t)(e & kPosMask);
-            if (q >= p) continue;
-            uint8_t sv = q >= seg_start ? s.S_new[q] : s.S_old[q];
-            if (!sv) continue;
-            uint32_t oq = q >= seg_start ? s.ORD_new[q] : s.ORD_old[q];
-            if (hx - 1 - oq > kRing - 1) break;
-            cnt++;
-            if (lcp240(b, q, x) >= min_len) return true;  // == mem_fast_equal over min_len bytes
-        }
-        return false;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// Rank kernels: per-segment per-ctx item histograms -> base table -> stream ordinals.
-struct RankHist {
-    const uint8_t* win;
-    const uint8_t* S;
-    uint32_t x0, x1, seg_size;
-    uint32_t* hist;  // [nseg][256]
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t x = x0 + (uint32_t)tid;
-        if (x >= x1 || !S[x]) return;
-        uint32_t sg = (x - kPre) / seg_size;
-        ORZ_ATOMIC_ADD(&hist[(size_t)sg * 256 + hash1(win, x - 1)], 1u);
-    }
-};
-// two-level scan over segments for each of the 256 contexts
-struct RankChunkSum {  // thread = (chunk, c)
-    const uint32_t* hist;
-    uint32_t seg0, seg1, chunk;  // chunk = segments per chunk
-    uint32_t* csum;              // [nchunks][256]
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t c = (uint32_t)(tid & 255), ch = (uint32_t)(tid >> 8);
-        uint32_t a = seg0 + ch * chunk;
-        if (a >= seg1) return;
-        uint32_t e = a + chunk < seg1 ? a + chunk : seg1;
-        uint32_t sum = 0;
-        for (uint32_t sg = a; sg < e; sg++) sum += hist[(size_t)sg * 256 + c];
-        csum[(size_t)ch * 256 + c] = sum;
-    }
-};
-struct RankChunkScan {  // thread = c ; exclusive scan of chunk sums, seeded by base[seg0][c]
-    uint32_t* csum;
-    const uint32_t* base;
-    uint32_t seg0, nchunks;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid >= 256) return;
-        uint32_t run = base[(size_t)seg0 * 256 + tid];
-        for (uint32_t ch = 0; ch < nchunks; ch++) {
-            uint32_t v = csum[(size_t)ch * 256 + tid];
-            csum[(size_t)ch * 256 + tid] = run;
-            run += v;
-        }
-    }
-};
-struct RankApply {  // thread = (chunk, c): base[sg+1] = base[sg] + hist[sg]
-    const uint32_t* hist;
-    const uint32_t* csum;
-    uint32_t seg0, seg1, chunk;
-    uint32_t* base;
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t c = (uint32_t)(tid & 255), ch = (uint32_t)(tid >> 8);
-        uint32_t a = seg0 + ch * chunk;
-        if (a >= seg1) return;
-        uint32_t e = a + chunk < seg1 ? a + chunk : seg1;
-        uint32_t run = csum[(size_t)ch * 256 + c];
-        for (uint32_t sg = a; sg < e; sg++) {
-            run += hist[(size_t)sg * 256 + c];
-            base[(size_t)(sg + 1) * 256 + c] = run;
-        }
-    }
-};
-struct RankOrd {  // ORD[x] = base[seg(x)][ctx(x)] + LR[x]
-    const uint8_t* win;
-    const uint8_t* S;
-    const uint16_t* LR;
-    const uint32_t* base;
-    uint32_t x0, x1, seg_size;
-    uint32_t* ORD;
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t x = x0 + (uint32_t)tid;
-        if (x >= x1 || !S[x]) return;
-        uint32_t sg = (x - kPre) / seg_size;
-        ORD[x] = base[(size_t)sg * 256 + hash1(win, x - 1)] + LR[x];
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
 // Post-parse: items
-struct ItemPos {  // scatter item start positions by their exclusive-scan index
-    const uint8_t* S;
-    const uint32_t* scan;  // exclusive scan of S over [kPre, len), indexed from 0
-    uint32_t n;
-    uint32_t* ipos;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid >= n) return;
-        if (S[kPre + tid]) ipos[scan[tid]] = kPre + (uint32_t)tid;
-    }
-};
-
 // match_len_min of the source at the time of each reference (src/matcher.rs:65-71): the ring
 // node's value is min(127, 1 + max len of earlier references), 0 if none.
 struct LenMinKeys {  // key = src << 25 | pos for match items, ~0 for the others
@@ -882,33 +573,4 @@ struct SlideArray {
         dst[tid] = tid == 0 ? (T)0 : src[tid + kNewMax];
     }
 };
-struct FillFirst {  // segment-start guesses for a fresh block
-    uint32_t* a;
-    uint32_t* b2;
-    uint8_t* la;
-    uint8_t* lb;
-    uint32_t nseg, seg_size;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid > nseg) return;
-        uint32_t v = kPre + (uint32_t)tid * seg_size;
-        a[tid] = v; b2[tid] = v; la[tid] = kTyLit; lb[tid] = kTyLit;
-    }
-};
-struct IotaFlags {  // history compaction input: flag[x] = S[x] for x in [1,P)
-    const uint8_t* S;
-    uint8_t* flag;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid < kPre) flag[tid] = tid >= 1 && S[tid];
-    }
-};
-struct CompactPos {
-    const uint8_t* flag;
-    const uint32_t* scan;
-    uint32_t n, off;
-    uint32_t* out;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid < n && flag[tid]) out[scan[tid]] = off + (uint32_t)tid;
-    }
-};
-
 }  // namespace orz

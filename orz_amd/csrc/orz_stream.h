@@ -1,0 +1,516 @@
+// orz_stream.h -- host-side orchestration of one orz stream on one device.
+//
+// StreamEncoder<BE> is the device-side LZEncoder (reference: /root/reference/src/lz.rs:69-346):
+// it owns the window, the ring / symrank / word-predictor model state and produces, block by
+// block, the framed chunks `orz::encode` (src/lib.rs:58-92) would write.  BE is a backend:
+//   HipBackend  (backend_hip.h)  -- the product: HIP kernels on gfx950
+//   EmuBackend  (tests/emu)      -- host emulation of the same kernel bodies, tests only
+//
+// Per block:  prep   (candidate lists: radix sort by (ctx, hash) / by hash2, slot state)
+//             parse  (speculative sweeps of ParseWave + RankScan + RankApply until the front
+//                     reaches the end of the block; the sweep loop is enqueued in batches, the
+//                     front lives on the device)
+//             post   (items -> len_min -> symbols -> symrank -> histograms -> Huffman -> bit pack)
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "orz_kernels.h"
+#include "orz_parse.h"
+
+namespace orz {
+
+struct EncodeStats {
+    uint64_t blocks = 0, sweeps = 0, seg_evals = 0, items = 0, chunks = 0, in_bytes = 0, out_bytes = 0;
+    double t_prep = 0, t_parse = 0, t_post = 0;  // seconds (host clock around device syncs)
+};
+
+// ---- prep kernels (thread per element) -------------------------------------------------------
+struct HistFlags32 {
+    const uint8_t* S;
+    uint32_t* f;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid < kPre) f[tid] = (tid >= 1 && S[tid]) ? 1u : 0u;
+    }
+};
+struct Flags32 {
+    const uint8_t* S;
+    uint32_t n;
+    uint32_t* f;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid < n) f[tid] = S[kPre + tid];
+    }
+};
+struct CompactPos32 {
+    const uint32_t* flag;
+    const uint32_t* scan;
+    uint32_t n, off;
+    uint32_t* out;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid < n && flag[tid]) out[scan[tid]] = off + (uint32_t)tid;
+    }
+};
+// sort inputs: (bucket_key(x), x) for history item starts and every new position;
+//              (hash2(u-1), u) for u in [P-1, len)
+struct BuildKeys {
+    const uint8_t* win;
+    const uint32_t* hpos;
+    uint32_t nhist, n;
+    uint32_t *keys, *vals, *kkeys, *kvals;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid < (size_t)nhist + n) {
+            uint32_t x = tid < nhist ? hpos[tid] : kPre + (uint32_t)(tid - nhist);
+            keys[tid] = bucket_key(win, x);
+            vals[tid] = x;
+        }
+        if (tid < (size_t)n + 1) {
+            uint32_t u = kPre - 1 + (uint32_t)tid;
+            kkeys[tid] = hash2(win, u - 1);
+            kvals[tid] = u;
+        }
+    }
+};
+struct ScatterSlots {  // idx[pos[j]] = j ; run starts
+    const uint32_t* keys;
+    const uint32_t* pos;
+    uint32_t n;
+    uint32_t* idx;
+    uint32_t* runstart;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid >= n) return;
+        idx[pos[tid]] = (uint32_t)tid;
+        if (tid == 0 || keys[tid] != keys[tid - 1]) runstart[keys[tid]] = (uint32_t)tid;
+    }
+};
+struct SlotInit {  // history slots carry their final item state, new slots start empty
+    const uint32_t* epos;
+    uint32_t n;
+    const uint8_t* ML;
+    const uint32_t* ORD;
+    uint8_t* sml;
+    uint32_t* sord;
+    uint64_t* vbits;  // zeroed
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid >= n) return;
+        uint32_t x = epos[tid];
+        if (x < kPre) {
+            sml[tid] = ML[x];
+            sord[tid] = ORD[x];
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicOr((unsigned long long*)&vbits[tid >> 6], 1ull << (tid & 63));
+#else
+            vbits[tid >> 6] |= 1ull << (tid & 63);
+#endif
+        } else {
+            sml[tid] = 255;
+            sord[tid] = 0;
+        }
+    }
+};
+struct FillExit {
+    uint32_t* exitst;
+    uint32_t nseg, seg;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid <= nseg) exitst[tid] = ((kPre + (uint32_t)tid * seg) << 2) | kTyLit;
+    }
+};
+struct ParseCtlInit {
+    ParseCtl* ctl;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid) return;
+        ctl->front[0] = 0; ctl->front[1] = 0;
+        ctl->fchg[0] = kNoChange; ctl->fchg[1] = kNoChange;
+        ctl->evals = 0;
+    }
+};
+struct FinalizeBlock {  // slot state -> per-position arrays of the new region
+    const uint32_t* idx;
+    const uint32_t* kidx;
+    const uint8_t* sml;
+    const uint32_t* sord;
+    const uint64_t* kbits;
+    uint32_t len;
+    uint8_t *S, *ML, *E;
+    uint32_t* ORD;
+    ORZ_HD void operator()(size_t tid) const {
+        uint32_t x = kPre + (uint32_t)tid;
+        if (x >= len) return;
+        uint32_t j = idx[x];
+        uint32_t m = sml[j];
+        S[x] = m != 255;
+        ML[x] = m == 255 ? 0 : (uint8_t)m;
+        ORD[x] = sord[j];
+        uint32_t e = 0;
+        if (x >= kPre + 1) {
+            uint32_t ks = kidx[x - 2];
+            e = (uint32_t)((kbits[ks >> 6] >> (ks & 63)) & 1);
+        }
+        E[x] = (uint8_t)e;
+    }
+};
+struct ChunkTotals {  // total payload bits of each chunk = header + items
+    const uint32_t* bscan;
+    const uint32_t* blen;
+    const uint32_t* hdrbits;
+    uint32_t nitems, nchunks;
+    uint32_t* tot;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid >= nchunks) return;
+        uint32_t i0 = (uint32_t)tid << 20;
+        uint32_t i1 = i0 + kChunkItems < nitems ? i0 + kChunkItems : nitems;
+        tot[tid] = hdrbits[tid] + (bscan[i1 - 1] + blen[i1 - 1] - bscan[i0]);
+    }
+};
+
+template <class BE>
+class StreamEncoder {
+   public:
+    static constexpr size_t kChunkCapWords = (size_t)kChunkItems * 40 / 32 + 8192;  // payload words per chunk
+    static constexpr uint32_t kMaxChunks = 17;
+    static constexpr uint32_t kNumKeys = 256 * kHash;
+
+    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 64, uint32_t win_segs = 4096)
+        : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs) {
+        if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 64]");
+        if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
+        dmax_ = (uint32_t)std::max(cfg.depth, std::max(cfg.lazy1, cfg.lazy2));
+        if (cfg.depth < 1 || dmax_ > 200) throw std::runtime_error("LZCfg depth out of range");
+        nseg_max_ = (kNewMax + seg_ - 1) / seg_;
+        if (wsegs_ > nseg_max_) wsegs_ = nseg_max_;
+        ring_ = wsegs_ + 8;
+        winbuf_ = be_.template alloc<uint8_t>((size_t)kBlock + 2 * kSent + 64);
+        S_ = be_.template alloc<uint8_t>(kWLen);
+        E_ = be_.template alloc<uint8_t>(kWLen);
+        ML_ = be_.template alloc<uint8_t>(kWLen);
+        ORD_ = be_.template alloc<uint32_t>(kWLen);
+        LR_ = be_.template alloc<uint8_t>(kWLen);
+        SRC_ = be_.template alloc<uint32_t>(kWLen);
+        W0_ = be_.template alloc<uint8_t>(kWLen);
+        TY_ = be_.template alloc<uint8_t>(kWLen);
+        LENMIN_ = be_.template alloc<uint8_t>(kWLen);
+        LMV_ = be_.template alloc<uint8_t>(kWLen);
+        idx_ = be_.template alloc<uint32_t>(kWLen);
+        kidx_ = be_.template alloc<uint32_t>(kWLen);
+        // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
+        entA_ = be_.template alloc<uint64_t>((size_t)kWLen);
+        entB_ = be_.template alloc<uint64_t>((size_t)kWLen);
+        epos_ = be_.template alloc<uint32_t>(kWLen);
+        kpos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 8);
+        runstart_ = be_.template alloc<uint32_t>(kNumKeys + 1);
+        krun_ = be_.template alloc<uint32_t>(32768 + 1);
+        vbits_ = be_.template alloc<uint64_t>(kWLen / 64 + 2);
+        kbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 2);
+        sml_ = be_.template alloc<uint8_t>(kWLen);
+        sord_ = be_.template alloc<uint32_t>(kWLen);
+        exitst_ = be_.template alloc<uint32_t>((size_t)nseg_max_ + 2);
+        hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
+        base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
+        ctl_ = be_.template alloc<ParseCtl>(1);
+        f32_ = be_.template alloc<uint32_t>(kWLen);
+        sc32_ = be_.template alloc<uint32_t>(kWLen);
+        hpos_ = be_.template alloc<uint32_t>(kPre + 1);
+        ctxcount_ = be_.template alloc<uint32_t>(256);
+        wsnap_ = be_.template alloc<uint8_t>(65536);
+        wlast_ = be_.template alloc<uint32_t>(32768);
+        // items
+        ipos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 1);
+        isym_ = be_.template alloc<uint16_t>(kNewMax);
+        ictx_ = be_.template alloc<uint16_t>(kNewMax);
+        irank_ = be_.template alloc<uint16_t>(kNewMax);
+        irob_ = be_.template alloc<uint16_t>(kNewMax);
+        grank_ = be_.template alloc<uint16_t>(kNewMax);
+        iunl_ = be_.template alloc<uint8_t>(kNewMax);
+        ienc_ = be_.template alloc<uint8_t>(kNewMax);
+        ial_ = be_.template alloc<uint8_t>(kNewMax);
+        gsym_ = be_.template alloc<uint32_t>(kNewMax);
+        blen_ = be_.template alloc<uint32_t>(kNewMax);
+        bscan_ = be_.template alloc<uint32_t>(kNewMax);
+        rstart_ = be_.template alloc<uint32_t>(520);
+        counts_ = be_.template alloc<uint32_t>(kSyms + 3);
+        order_ = be_.template alloc<uint16_t>(kSyms + 3);
+        ncounted_ = be_.template alloc<uint32_t>(4);
+        srstate_ = be_.template alloc<uint16_t>((size_t)512 * kSrWords);
+        hw_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * kHwStride);
+        hl_ = be_.template alloc<uint8_t>((size_t)kMaxChunks * kHwStride);
+        hc_ = be_.template alloc<uint16_t>((size_t)kMaxChunks * kHwStride);
+        hscr_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
+        hdrbits_ = be_.template alloc<uint32_t>(kMaxChunks);
+        tot_ = be_.template alloc<uint32_t>(kMaxChunks);
+        outoff_ = be_.template alloc<uint64_t>(kMaxChunks);
+        out_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
+        reset();
+    }
+    ~StreamEncoder() {
+        void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, epos_,
+                        kpos_, runstart_, krun_, vbits_, kbits_, sml_, sord_, exitst_, hist_, base_, ctl_, f32_, sc32_,
+                        hpos_, ctxcount_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
+                        gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
+                        hdrbits_, tot_, outoff_, out_};
+        for (void* p : ptrs) be_.free(p);
+    }
+    StreamEncoder(const StreamEncoder&) = delete;
+    StreamEncoder& operator=(const StreamEncoder&) = delete;
+
+    // LZEncoder::new (src/lz.rs:75-80): empty rings, zero word table, after_literal = true
+    void reset() {
+        be_.memset(winbuf_, 0, (size_t)kBlock + 2 * kSent + 64);
+        be_.memset(S_, 0, kWLen);
+        be_.memset(ML_, 0, kWLen);
+        be_.memset(ORD_, 0, (size_t)kWLen * 4);
+        be_.memset(LENMIN_, 0, kWLen);
+        be_.memset(ctxcount_, 0, 256 * 4);
+        be_.memset(wsnap_, 0, 65536);
+        lt_carry_ = kTyLit;
+        stream_start_ = true;
+        stats = EncodeStats();
+    }
+
+    uint8_t* dwin() { return winbuf_ + kSent; }  // device address of window offset 0
+    uint8_t* dwinbuf() { return winbuf_; }       // device address of the allocation (sentinel included)
+    uint32_t seg_size() const { return seg_; }
+    uint32_t window_segs() const { return wsegs_; }
+
+    // Encode the block whose n new bytes sit at dwin()[kPre, kPre+n).  Appends
+    // { LEB128(t) chunk[t] }* (src/lib.rs:76-82, src/ioutil.rs:79-88) to `out`; optionally reports
+    // each chunk's end position (the value LZEncoder::encode returns, src/lz.rs:268,346).
+    void encode_block(uint32_t n, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends = nullptr) {
+        if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
+        double t0 = be_.now();
+        const uint8_t* win = dwin();
+        const uint32_t len = kPre + n;
+        const uint32_t nseg = (n + seg_ - 1) / seg_;
+        // ---- history item starts -> hpos
+        uint32_t nhist = 0;
+        if (!stream_start_) {
+            be_.launch(kPre, HistFlags32{S_, f32_});
+            be_.exclusive_scan_u32(f32_, sc32_, kPre);
+            uint32_t a, b2;
+            be_.d2h(&a, sc32_ + (kPre - 1), 4);
+            be_.d2h(&b2, f32_ + (kPre - 1), 4);
+            nhist = a + b2;
+            be_.launch(kPre, CompactPos32{f32_, sc32_, kPre, 0, hpos_});
+        }
+        // ---- candidate lists: stable radix sort of positions by (ctx8, hash) and by hash2
+        const uint32_t nent = nhist + n;
+        uint32_t* keysA = (uint32_t*)entA_;
+        uint32_t* valsA = keysA + kWLen;
+        uint32_t* keysB = (uint32_t*)entB_;
+        uint32_t* kkeysA = f32_;
+        uint32_t* kvalsA = sc32_;
+        uint32_t* kkeysB = keysB + kWLen;
+        be_.launch(std::max<size_t>(nent, (size_t)n + 1), BuildKeys{win, hpos_, nhist, n, keysA, valsA, kkeysA, kvalsA});
+        be_.sort_pairs_u32(keysA, keysB, valsA, epos_, nent, 21);
+        be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_});
+        be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
+        be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_});
+        be_.memset(vbits_, 0, ((size_t)nent / 64 + 1) * 8);
+        be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
+        be_.launch(nent, SlotInit{epos_, nent, ML_, ORD_, sml_, sord_, vbits_});
+        be_.launch((size_t)nseg + 1, FillExit{exitst_, nseg, seg_});
+        be_.memset(hist_, 0, (size_t)ring_ * 256);
+        be_.d2d(base_, ctxcount_, 256 * 4);
+        be_.launch(1, ParseCtlInit{ctl_});
+        be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
+        be_.sync();
+        double t1 = be_.now();
+        stats.t_prep += t1 - t0;
+
+        // ---- speculative sweeps to the causal fixed point
+        ParseArgs pa;
+        pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
+        pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
+        pa.lt0 = lt_carry_; pa.par = 0;
+        pa.epos = epos_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
+        pa.wsnap = wsnap_; pa.vbits = vbits_; pa.sml = sml_; pa.sord = sord_; pa.kbits = kbits_; pa.exitst = exitst_;
+        pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.ctl = ctl_;
+        const size_t lds_bytes = ParseLds::make(dmax_).total;
+        const uint32_t grid = std::min(wsegs_, nseg);
+        uint32_t par = 0, front = 0, batch = 8;
+        uint64_t sweeps = 0;
+        while (front < nseg) {
+            for (uint32_t i = 0; i < batch; i++) {
+                pa.par = par;
+                be_.timed_begin();
+                be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
+                be_.timed_end();
+                be_.rank_scan(RankScanArgs{ctl_, hist_, base_, nseg, wsegs_, ring_, par});
+                be_.launch((size_t)grid * seg_,
+                           RankApply{win, ctl_, idx_, sml_, LR_, base_, sord_, nseg, seg_, wsegs_, ring_, len, par});
+                par ^= 1;
+                sweeps++;
+            }
+            ParseCtl h;
+            be_.d2h(&h, ctl_, sizeof h);
+            const uint32_t adv = h.front[par] > front ? h.front[par] - front : 1;
+            front = h.front[par];
+            stats.seg_evals = stats.seg_evals + 0;  // (evals are read once, below)
+            // size the next batch to what the front still has to cover, assuming this batch's speed
+            const uint64_t left = nseg > front ? nseg - front : 0;
+            const uint64_t per = std::max<uint64_t>(1, adv / batch);
+            batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(2, left / per + 1));
+            if (getenv("ORZ_TRACE_SWEEPS"))
+                fprintf(stderr, "sweeps=%llu front=%u/%u next batch=%u\n", (unsigned long long)sweeps, front, nseg, batch);
+        }
+        {
+            ParseCtl h;
+            be_.d2h(&h, ctl_, sizeof h);
+            stats.seg_evals += h.evals;
+        }
+        stats.sweeps += sweeps;
+        be_.launch(n, FinalizeBlock{idx_, kidx_, sml_, sord_, kbits_, len, S_, ML_, E_, ORD_});
+        be_.sync();
+        double t2 = be_.now();
+        stats.t_parse += t2 - t1;
+
+        // ---- items
+        be_.launch(n, Flags32{S_, n, f32_});
+        be_.exclusive_scan_u32(f32_, sc32_, n);
+        uint32_t a, b2;
+        be_.d2h(&a, sc32_ + (n - 1), 4);
+        be_.d2h(&b2, f32_ + (n - 1), 4);
+        const uint32_t nitems = a + b2;
+        be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, ipos_});
+        // len_min of each reference (keys reuse the sort buffers)
+        be_.launch(nitems, LenMinKeys{ipos_, TY_, SRC_, nitems, entA_});
+        const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
+        be_.launch(nitems, LenMinEval{lk, nitems, ML_, LENMIN_, LMV_});
+        be_.launch(nitems, LenMinCommit{lk, nitems, ML_, LMV_, LENMIN_});
+        be_.launch(nitems, ItemSyms{win, ipos_, nitems, TY_, ML_, W0_, LMV_, SRC_, ORD_, isym_, ictx_, iunl_, ienc_, irob_,
+                                    ial_});
+        const uint32_t nchunks = (nitems + kChunkItems - 1) / kChunkItems;
+        if (nchunks > kMaxChunks) throw std::runtime_error("too many chunks in a block");
+        if (stream_start_) {  // src/lz.rs:238-265
+            be_.memset(counts_, 0, (kSyms + 3) * 4);
+            be_.launch(std::min(nitems, kChunkItems), CensusCount{isym_, std::min(nitems, kChunkItems), counts_});
+            be_.launch(1, CensusInit{counts_, order_, ncounted_, srstate_});
+        }
+        // symbol ranking: 512 independent serial chains
+        be_.launch(nitems, SymKeys{ictx_, nitems, entA_});
+        const uint64_t* sk = be_.sort_u64(entA_, entB_, nitems, 33);
+        be_.launch(nitems, SymGather{sk, isym_, iunl_, nitems, gsym_});
+        be_.launch(513, SymRunStart{sk, nitems, rstart_});
+        be_.symrank(srstate_, gsym_, grank_, rstart_);
+        be_.launch(nitems, SymScatter{sk, grank_, nitems, irank_});
+        // static Huffman per chunk
+        be_.memset(hw_, 0, (size_t)nchunks * kHwStride * 4);
+        be_.launch(nitems, Hist{irank_, ial_, ienc_, nitems, hw_});
+        be_.launch((size_t)nchunks * 3, HuffBuild{hw_, nchunks, hl_, hc_, hscr_});
+        be_.launch(nitems, ItemBits{irank_, ial_, ienc_, irob_, hl_, nitems, blen_});
+        be_.exclusive_scan_u32(blen_, bscan_, nitems);
+        // bit packing
+        std::vector<uint64_t> off(nchunks);
+        for (uint32_t i = 0; i < nchunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
+        be_.h2d(outoff_, off.data(), nchunks * 8);
+        be_.memset(out_, 0, (size_t)nchunks * kChunkCapWords * 4);
+        be_.launch(nchunks, ChunkHeader{hl_, nchunks, nitems, len, ipos_, order_, ncounted_, stream_start_ ? 1 : 0, out_,
+                                        outoff_, hdrbits_});
+        be_.launch(nitems, Pack{irank_, ial_, ienc_, irob_, hl_, hc_, bscan_, hdrbits_, outoff_, nitems, out_});
+        be_.launch(nchunks, ChunkTotals{bscan_, blen_, hdrbits_, nitems, nchunks, tot_});
+        std::vector<uint32_t> tot(nchunks);
+        be_.d2h(tot.data(), tot_, nchunks * 4);
+        for (uint32_t i = 0; i < nchunks; i++) {
+            size_t t = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
+            if (t / 4 > kChunkCapWords) throw std::runtime_error("chunk payload overflow");
+            size_t v = t;  // write_len, src/ioutil.rs:79-88
+            while (v >= 128) { out.push_back((uint8_t)(128 + v % 128)); v /= 128; }
+            out.push_back((uint8_t)v);
+            size_t at = out.size();
+            out.resize(at + t);
+            be_.d2h(out.data() + at, out_ + off[i], t);
+            if (chunk_ends) {  // end_spos of the chunk, src/lz.rs:268
+                uint32_t i1 = (i + 1) << 20, e = len;
+                if (i1 < nitems) be_.d2h(&e, ipos_ + i1, 4);
+                chunk_ends->push_back(e);
+            }
+        }
+        // ---- model state carried to the next block
+        be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
+        uint32_t ex;
+        be_.d2h(&ex, exitst_ + nseg, 4);
+        const uint8_t ltf = (uint8_t)(ex & 3);
+        be_.memset(wlast_, 0, 32768 * 4);
+        be_.launch((size_t)n + 1, WordsLast{win, E_, len, wlast_});
+        be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
+        lt_carry_ = ltf;
+        stream_start_ = false;
+        be_.sync();
+        stats.t_post += be_.now() - t2;
+        stats.blocks++;
+        stats.items += nitems;
+        stats.chunks += nchunks;
+        stats.in_bytes += n;
+    }
+
+    // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
+    // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.
+    // `slide_window` false = the caller re-uploads the whole window itself (object-level API).
+    void slide(bool slide_window = true) {
+        if (slide_window) be_.d2d(dwin(), dwin() + kNewMax, kPre);
+        be_.launch(kPre, SlideArray<uint8_t>{S_, S_});
+        be_.launch(kPre, SlideArray<uint8_t>{ML_, ML_});
+        be_.launch(kPre, SlideArray<uint32_t>{ORD_, ORD_});
+        be_.launch(kPre, SlideArray<uint8_t>{LENMIN_, LENMIN_});
+        be_.sync();
+    }
+
+    EncodeStats stats;
+
+   private:
+    BE& be_;
+    Cfg cfg_;
+    uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
+    uint8_t lt_carry_ = kTyLit;
+    bool stream_start_ = true;
+    uint8_t* winbuf_;
+    uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
+    uint32_t *ORD_, *SRC_;
+    uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_;
+    uint64_t *entA_, *entB_, *vbits_, *kbits_;
+    uint8_t* sml_;
+    uint32_t* sord_;
+    uint32_t* exitst_;
+    uint8_t* hist_;
+    uint32_t* base_;
+    ParseCtl* ctl_;
+    uint32_t *f32_, *sc32_, *hpos_, *ctxcount_;
+    uint8_t* wsnap_;
+    uint32_t* wlast_;
+    uint32_t* ipos_;
+    uint16_t *isym_, *ictx_, *irank_, *irob_, *grank_;
+    uint8_t *iunl_, *ienc_, *ial_;
+    uint32_t *gsym_, *blen_, *bscan_, *rstart_, *counts_;
+    uint16_t* order_;
+    uint32_t* ncounted_;
+    uint16_t* srstate_;
+    uint32_t* hw_;
+    uint8_t* hl_;
+    uint16_t* hc_;
+    uint32_t *hscr_, *hdrbits_, *tot_;
+    uint64_t* outoff_;
+    uint32_t* out_;
+};
+
+// orz::encode (src/lib.rs:58-92) over a memory buffer that the backend can read with h2d():
+// fills the window block by block, frames chunks, slides, and appends the EOF chunk.
+template <class BE>
+void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n, bool src_on_device,
+                   std::vector<uint8_t>& out) {
+    enc.reset();
+    size_t off = 0;
+    while (off < n) {
+        uint32_t take = (uint32_t)std::min<size_t>(n - off, kNewMax);
+        if (src_on_device) be.d2d(enc.dwin() + kPre, src + off, take);
+        else be.h2d(enc.dwin() + kPre, src + off, take);
+        enc.encode_block(take, out);
+        off += take;
+        if (off < n) enc.slide();
+    }
+    out.push_back(0);  // EOF chunk, src/lib.rs:89
+    enc.stats.out_bytes = out.size();
+}
+
+}  // namespace orz

@@ -1,0 +1,85 @@
+"""ctypes access to the CPU parity oracle (oracle/liborz_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by orz_amd/."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liborz_oracle.so")
+CLI = os.path.join(ORACLE_DIR, "orz_oracle")
+
+LEVELS = {0: (5, 3, 2), 1: (15, 9, 6), 2: (45, 27, 18)}  # src/main.rs:97-102
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_size_t), ("b", ctypes.c_size_t), ("c", ctypes.c_size_t)]
+
+
+class Item(ctypes.Structure):
+    _fields_ = [
+        ("pos", ctypes.c_uint32), ("symbol", ctypes.c_uint16), ("rank", ctypes.c_uint16), ("ctx", ctypes.c_uint16),
+        ("reduced_offset", ctypes.c_uint16), ("unlikely", ctypes.c_uint8), ("match_len", ctypes.c_uint8),
+        ("enc_len", ctypes.c_uint8), ("after_literal", ctypes.c_uint8),
+    ]
+
+
+class Trace(ctypes.Structure):
+    _fields_ = [("items", ctypes.POINTER(Item)), ("cap", ctypes.c_size_t), ("n", ctypes.c_size_t)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.orc_encode_mem.restype = ctypes.c_int
+        _lib.orc_decode_mem.restype = ctypes.c_int
+        _lib.orc_huffman_lengths.restype = ctypes.c_int
+        _lib.orc_coder_selftest.restype = ctypes.c_long
+        _lib.orc_hash_entry.restype = ctypes.c_uint32
+    return _lib
+
+
+def encode(data, level=1, cfg=None, trace_cap=0):
+    """bytes -> orz stream with the oracle's restatement of orz::encode (src/lib.rs:58-92)."""
+    L = lib()
+    c = Cfg(*(cfg if cfg is not None else LEVELS[level]))
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    tr = None
+    if trace_cap:
+        buf = (Item * trace_cap)()
+        tr = Trace(buf, trace_cap, 0)
+    data = bytes(data)
+    rc = L.orc_encode_mem(data, ctypes.c_size_t(len(data)), ctypes.byref(c), ctypes.byref(dst), ctypes.byref(n),
+                          ctypes.byref(tr) if tr is not None else None)
+    assert rc == 0
+    out = ctypes.string_at(dst, n.value)
+    L.orc_free(dst)
+    if trace_cap:
+        return out, [tr.items[i] for i in range(min(tr.n, trace_cap))]
+    return out
+
+
+def decode(stream):
+    """orz stream -> bytes (src/lib.rs:94-129).  Returns (data, consumed) ; raises on InvalidData."""
+    L = lib()
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    used = ctypes.c_size_t()
+    stream = bytes(stream)
+    rc = L.orc_decode_mem(stream, ctypes.c_size_t(len(stream)), ctypes.byref(dst), ctypes.byref(n), ctypes.byref(used))
+    if rc != 0:
+        raise ValueError("oracle decode: invalid data")
+    out = ctypes.string_at(dst, n.value)
+    L.orc_free(dst)
+    return out, used.value

@@ -1,16 +1,22 @@
 // emu_backend.cpp -- host emulation of the device backend (TEST INFRASTRUCTURE ONLY).
-// Runs the very same kernel functors (orz_amd/csrc/orz_kernels.h) and orchestration
-// (orz_pipeline.h) in host loops, so the CPU-only test tier can check the encoder's logic
-// byte-for-byte against the oracle without a GPU.  Never linked into the product library.
+// Runs the very same kernel bodies (orz_amd/csrc/orz_kernels.h, orz_parse.h) and orchestration
+// (orz_stream.h) on the CPU, so the CPU-only test tier can check the encoder's logic byte for
+// byte against the oracle without a GPU.  Thread kernels run as host loops; the wave-cooperative
+// parse kernel runs on the SIMT emulator of simt.h, with its blocks visited in ascending,
+// descending (= pure Jacobi speculation) or shuffled order.  Never linked into the product.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 
-#include "../../orz_amd/csrc/orz_pipeline.h"
+#include "../../orz_amd/csrc/orz_stream.h"
+#include "simt.h"
 
 namespace {
 struct EmuBackend {
+    int order = 1;  // simt::Order for wave kernels
+    uint64_t seed = 1;
     template <class T> T* alloc(size_t n) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
     void free(void* p) { std::free(p); }
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
@@ -18,14 +24,33 @@ struct EmuBackend {
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
+    void timed_begin() {}
+    void timed_end() {}
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     template <class F> void launch(size_t n, const F& f) {
         for (size_t i = 0; i < n; i++) f(i);
     }
+    template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
+        simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
+    }
+    void rank_scan(const orz::RankScanArgs& a) {
+        std::vector<uint32_t> partial(4 * 256);
+        for (uint32_t k = 0; k < 4; k++)
+            for (uint32_t c = 0; c < 256; c++) orz::rank_scan_pass1(a, k, c, partial.data());
+        for (uint32_t k = 4; k-- > 0;)  // (k,c) = (0,0) moves the front: run it last
+            for (uint32_t c = 256; c-- > 0;) orz::rank_scan_pass2(a, k, c, partial.data());
+    }
     const uint64_t* sort_u64(uint64_t* a, uint64_t*, size_t n, int bits) {
         uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-        std::sort(a, a + n, [mask](uint64_t x, uint64_t y) { return (x & mask) < (y & mask); });
+        std::stable_sort(a, a + n, [mask](uint64_t x, uint64_t y) { return (x & mask) < (y & mask); });
         return a;
+    }
+    void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits) {
+        uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1);
+        std::vector<uint32_t> perm(n);
+        std::iota(perm.begin(), perm.end(), 0u);
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return (kin[x] & mask) < (kin[y] & mask); });
+        for (size_t i = 0; i < n; i++) { kout[i] = kin[perm[i]]; vout[i] = vin[perm[i]]; }
     }
     void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
         uint32_t run = 0;
@@ -40,12 +65,14 @@ struct EmuBackend {
 };
 }  // namespace
 
+// order: 0 ascending, 1 descending, 2 shuffled block order inside a sweep
 extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, unsigned seg, unsigned win,
-                          uint8_t** dst, size_t* dst_len, unsigned long long* stats5) {
+                          int order, uint8_t** dst, size_t* dst_len, unsigned long long* stats5) {
     try {
         EmuBackend be;
+        be.order = order;
         orz::Cfg cfg{depth, lazy1, lazy2};
-        orz::StreamEncoder<EmuBackend> enc(be, cfg, seg, win ? win : 0xffffffffu);
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, seg, win ? win : 4096);
         std::vector<uint8_t> out;
         orz::encode_stream(enc, be, src, n, false, out);
         *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
