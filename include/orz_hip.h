@@ -89,6 +89,25 @@ int orz_stream_encode(orz_stream*, const void* src, size_t n, int src_on_device,
                       orz_encode_stats* stats);
 void orz_free(void* p);
 
+/* Per-item trace of the last orz_stream_encode call (diagnostics / stage-level parity tests):
+ * what the parse decided for each item, in stream order.  Mirrors the reference's MatchItem
+ * (src/lz.rs:100-116) after the symrank pass. */
+typedef struct {
+    uint32_t block;         /* 0-based block index */
+    uint32_t pos;           /* window offset of the item start (spos) */
+    uint16_t symbol;        /* raw symbol: literal, 256 + roid*6 + lenid, or 388 (WORD) */
+    uint16_t rank;          /* symbol after symrank */
+    uint16_t ctx;           /* symrank_context (9 bit) */
+    uint16_t robits;        /* robits | robitlen << 12 */
+    uint8_t unlikely;       /* symrank_unlikely */
+    uint8_t enc_len;        /* encoded_match_len */
+    uint8_t after_literal;  /* bit 0: after_literal, bit 1: item is a match */
+    uint8_t pad;
+} orz_item;
+int orz_stream_set_item_trace(orz_stream*, int on);
+/* copies up to cap items to out, returns the total number traced (or a negative error) */
+long orz_stream_get_item_trace(orz_stream*, orz_item* out, size_t cap);
+
 int orz_device_count(void);
 const char* orz_last_error(void);
 const char* orz_version(void);

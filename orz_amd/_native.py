@@ -41,6 +41,14 @@ class EncodeStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class Item(ctypes.Structure):
+    _fields_ = [
+        ("block", ctypes.c_uint32), ("pos", ctypes.c_uint32), ("symbol", ctypes.c_uint16), ("rank", ctypes.c_uint16),
+        ("ctx", ctypes.c_uint16), ("robits", ctypes.c_uint16), ("unlikely", ctypes.c_uint8), ("enc_len", ctypes.c_uint8),
+        ("after_literal", ctypes.c_uint8), ("pad", ctypes.c_uint8),
+    ]
+
+
 READ_FN = ctypes.CFUNCTYPE(ctypes.c_ssize_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 WRITE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t)
@@ -73,6 +81,8 @@ SYMBOLS = [
          ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(EncodeStats)],
     ),
     ("orz_free", None, [ctypes.c_void_p]),
+    ("orz_stream_set_item_trace", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("orz_stream_get_item_trace", ctypes.c_long, [ctypes.c_void_p, ctypes.POINTER(Item), ctypes.c_size_t]),
     ("orz_device_count", ctypes.c_int, []),
     ("orz_last_error", ctypes.c_char_p, []),
     ("orz_version", ctypes.c_char_p, []),

@@ -69,6 +69,20 @@ class StreamEncoder:
         out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats)
         return (out, st) if stats else out
 
+    def set_item_trace(self, on=True):
+        _check(self._lib.orz_stream_set_item_trace(self._h, 1 if on else 0), "orz_stream_set_item_trace")
+
+    def item_trace(self):
+        """numpy structured array of the items of the last encode() (needs set_item_trace(True))."""
+        import numpy as np
+
+        n = self._lib.orz_stream_get_item_trace(self._h, None, 0)
+        buf = (_native.Item * max(n, 1))()
+        self._lib.orz_stream_get_item_trace(self._h, buf, n)
+        dt = np.dtype([("block", "<u4"), ("pos", "<u4"), ("symbol", "<u2"), ("rank", "<u2"), ("ctx", "<u2"),
+                       ("robits", "<u2"), ("unlikely", "u1"), ("enc_len", "u1"), ("after_literal", "u1"), ("pad", "u1")])
+        return np.frombuffer(buf, dtype=dt, count=n).copy()
+
     def close(self):
         if self._h:
             self._lib.orz_stream_free(self._h)

@@ -46,9 +46,12 @@ struct orz_stream {
     std::unique_ptr<Enc> enc;
     orz_lzcfg cfg;
     unsigned seg, win;
+    orz::ItemTrace trace;
+    bool tracing = false;
     void rebuild() {
         enc.reset();
         enc.reset(new Enc(*be, to_cfg(&cfg), seg, win));
+        enc->trace = tracing ? &trace : nullptr;
     }
 };
 
@@ -135,6 +138,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
         ORZ_HIP_CHECK(hipEventCreate(&e0));
         ORZ_HIP_CHECK(hipEventCreate(&e1));
         ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
+        s->trace.clear();
         orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out);
         ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
         be.sync();
@@ -160,6 +164,26 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
     } catch (const std::exception& e) {
         return fail(ORZ_ENODEV, e.what());
     }
+}
+
+int orz_stream_set_item_trace(orz_stream* s, int on) {
+    if (!s) return fail(ORZ_EINVAL, "null stream");
+    s->tracing = on != 0;
+    s->enc->trace = s->tracing ? &s->trace : nullptr;
+    if (!on) s->trace.clear();
+    return ORZ_OK;
+}
+long orz_stream_get_item_trace(orz_stream* s, orz_item* out, size_t cap) {
+    if (!s) return fail(ORZ_EINVAL, "null stream");
+    const orz::ItemTrace& t = s->trace;
+    const size_t n = t.pos.size();
+    for (size_t i = 0; i < n && i < cap && out; i++) {
+        orz_item it;
+        it.block = t.block[i]; it.pos = t.pos[i]; it.symbol = t.sym[i]; it.rank = t.rank[i]; it.ctx = t.ctx[i];
+        it.robits = t.rob[i]; it.unlikely = t.unl[i]; it.enc_len = t.enc[i]; it.after_literal = t.al[i]; it.pad = 0;
+        out[i] = it;
+    }
+    return (long)n;
 }
 
 // ------------------------------------------------------------------------------ orz_lz_encoder

@@ -24,6 +24,14 @@
 
 namespace orz {
 
+// optional per-item trace of the encoder (parity tests compare it with the oracle's trace)
+struct ItemTrace {
+    std::vector<uint32_t> block, pos;
+    std::vector<uint16_t> sym, ctx, rank, rob;
+    std::vector<uint8_t> unl, enc, al;
+    void clear() { block.clear(); pos.clear(); sym.clear(); ctx.clear(); rank.clear(); rob.clear(); unl.clear(); enc.clear(); al.clear(); }
+};
+
 struct EncodeStats {
     uint64_t blocks = 0, sweeps = 0, seg_evals = 0, items = 0, chunks = 0, in_bytes = 0, out_bytes = 0;
     double t_prep = 0, t_parse = 0, t_post = 0;  // seconds (host clock around device syncs)
@@ -56,15 +64,27 @@ struct CompactPos32 {
 };
 // sort inputs: (bucket_key(x), x) for history item starts and every new position;
 //              (hash2(u-1), u) for u in [P-1, len)
+// The reference hashes an item's four bytes when it inserts it (src/matcher.rs:115-121); for the
+// last three positions of a block those bytes include the sentinel past the block end, which the
+// next block's data later replaces in the window.  Their keys are therefore taken before the slide.
+struct TailKeys {
+    const uint8_t* win;
+    uint32_t len;
+    uint32_t* tailkey;  // [3] keys of positions len-3, len-2, len-1
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid < 3) tailkey[tid] = bucket_key(win, len - 3 + (uint32_t)tid);
+    }
+};
 struct BuildKeys {
     const uint8_t* win;
     const uint32_t* hpos;
+    const uint32_t* tailkey;
     uint32_t nhist, n;
     uint32_t *keys, *vals, *kkeys, *kvals;
     ORZ_HD void operator()(size_t tid) const {
         if (tid < (size_t)nhist + n) {
             uint32_t x = tid < nhist ? hpos[tid] : kPre + (uint32_t)(tid - nhist);
-            keys[tid] = bucket_key(win, x);
+            keys[tid] = (x < kPre && x + 3 >= kPre) ? tailkey[x + 3 - kPre] : bucket_key(win, x);
             vals[tid] = x;
         }
         if (tid < (size_t)n + 1) {
@@ -214,6 +234,7 @@ class StreamEncoder {
         sc32_ = be_.template alloc<uint32_t>(kWLen);
         hpos_ = be_.template alloc<uint32_t>(kPre + 1);
         ctxcount_ = be_.template alloc<uint32_t>(256);
+        tailkey_ = be_.template alloc<uint32_t>(4);
         wsnap_ = be_.template alloc<uint8_t>(65536);
         wlast_ = be_.template alloc<uint32_t>(32768);
         // items
@@ -247,7 +268,7 @@ class StreamEncoder {
     ~StreamEncoder() {
         void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, epos_,
                         kpos_, runstart_, krun_, vbits_, kbits_, sml_, sord_, exitst_, hist_, base_, ctl_, f32_, sc32_,
-                        hpos_, ctxcount_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
+                        hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_};
         for (void* p : ptrs) be_.free(p);
@@ -302,7 +323,7 @@ class StreamEncoder {
         uint32_t* kkeysA = f32_;
         uint32_t* kvalsA = sc32_;
         uint32_t* kkeysB = keysB + kWLen;
-        be_.launch(std::max<size_t>(nent, (size_t)n + 1), BuildKeys{win, hpos_, nhist, n, keysA, valsA, kkeysA, kvalsA});
+        be_.launch(std::max<size_t>(nent, (size_t)n + 1), BuildKeys{win, hpos_, tailkey_, nhist, n, keysA, valsA, kkeysA, kvalsA});
         be_.sort_pairs_u32(keysA, keysB, valsA, epos_, nent, 21);
         be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_});
         be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
@@ -427,6 +448,21 @@ class StreamEncoder {
                 chunk_ends->push_back(e);
             }
         }
+        if (trace) {
+            const size_t at = trace->pos.size();
+            trace->block.resize(at + nitems, (uint32_t)stats.blocks);
+            trace->pos.resize(at + nitems); trace->sym.resize(at + nitems); trace->ctx.resize(at + nitems);
+            trace->rank.resize(at + nitems); trace->rob.resize(at + nitems); trace->unl.resize(at + nitems);
+            trace->enc.resize(at + nitems); trace->al.resize(at + nitems);
+            be_.d2h(trace->pos.data() + at, ipos_, (size_t)nitems * 4);
+            be_.d2h(trace->sym.data() + at, isym_, (size_t)nitems * 2);
+            be_.d2h(trace->ctx.data() + at, ictx_, (size_t)nitems * 2);
+            be_.d2h(trace->rank.data() + at, irank_, (size_t)nitems * 2);
+            be_.d2h(trace->rob.data() + at, irob_, (size_t)nitems * 2);
+            be_.d2h(trace->unl.data() + at, iunl_, nitems);
+            be_.d2h(trace->enc.data() + at, ienc_, nitems);
+            be_.d2h(trace->al.data() + at, ial_, nitems);
+        }
         // ---- model state carried to the next block
         be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
         uint32_t ex;
@@ -449,6 +485,7 @@ class StreamEncoder {
     // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.
     // `slide_window` false = the caller re-uploads the whole window itself (object-level API).
     void slide(bool slide_window = true) {
+        be_.launch(3, TailKeys{dwin(), kBlock, tailkey_});  // only full blocks are ever slid (src/lib.rs:72-84)
         if (slide_window) be_.d2d(dwin(), dwin() + kNewMax, kPre);
         be_.launch(kPre, SlideArray<uint8_t>{S_, S_});
         be_.launch(kPre, SlideArray<uint8_t>{ML_, ML_});
@@ -458,6 +495,7 @@ class StreamEncoder {
     }
 
     EncodeStats stats;
+    ItemTrace* trace = nullptr;  // when set, every block appends its items
 
    private:
     BE& be_;
@@ -476,7 +514,7 @@ class StreamEncoder {
     uint8_t* hist_;
     uint32_t* base_;
     ParseCtl* ctl_;
-    uint32_t *f32_, *sc32_, *hpos_, *ctxcount_;
+    uint32_t *f32_, *sc32_, *hpos_, *ctxcount_, *tailkey_;
     uint8_t* wsnap_;
     uint32_t* wlast_;
     uint32_t* ipos_;

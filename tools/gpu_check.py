@@ -13,6 +13,22 @@ import corpus  # noqa: E402
 import orz_amd  # noqa: E402
 
 
+def frames(stream):
+    """chunk payload lengths of an orz stream (src/lib.rs:108-110)"""
+    out, at = [], 0
+    while at < len(stream):
+        t, sh = 0, 0
+        while True:
+            b = stream[at]; at += 1
+            t |= (b & 0x7F) << sh; sh += 7
+            if not b & 0x80:
+                break
+        if t == 0:
+            break
+        out.append(t); at += t
+    return out
+
+
 def main():
     sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1000, 1 << 20, 4 << 20]
     segs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64]
@@ -40,6 +56,9 @@ def main():
                            launches=st["parse_launches"])
                 print(json.dumps(rec), flush=True)
                 if not ok:
+                    print("frames gpu:", frames(out)[:12], "ref:", frames(ref)[:12], flush=True)
+                    i = next((i for i in range(min(len(out), len(ref))) if out[i] != ref[i]), None)
+                    print("first differing byte:", i, flush=True)
                     dec = None
                     try:
                         dec = _oracle.decode(out)[0] == data
