@@ -48,13 +48,10 @@ __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {
     k(w);
 }
 
-// ring ordinals after a sweep (orz_parse.h): thread = (chunk k of 4, ctx c)
-__global__ __launch_bounds__(1024) void orz_rank_scan_kernel(RankScanArgs a) {
-    __shared__ uint32_t partial[4 * 256];
-    const uint32_t k = threadIdx.x >> 8, c = threadIdx.x & 255;
-    rank_scan_pass1(a, k, c, partial);
-    __syncthreads();
-    rank_scan_pass2(a, k, c, partial);
+// ring ordinals after a sweep (orz_parse.h): block = chunk of kRankChunk segments, thread = ctx
+__global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a) {
+    __shared__ uint32_t rows[(kRankChunk + 1) * 256];
+    rank_chunk(a, blockIdx.x, threadIdx.x, rows, [] __device__() { __syncthreads(); });
 }
 
 // SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context, the 389-entry value and
@@ -173,8 +170,8 @@ class HipBackend {
         hipLaunchKernelGGL(orz_wave_kernel<K>, dim3((unsigned)nblocks), dim3(64), lds_bytes, stream_, k);
         ORZ_HIP_CHECK(hipGetLastError());
     }
-    void rank_scan(const RankScanArgs& a) {
-        hipLaunchKernelGGL(orz_rank_scan_kernel, dim3(1), dim3(1024), 0, stream_, a);
+    void rank(const RankArgs& a, uint32_t nchunks) {
+        hipLaunchKernelGGL(orz_rank_kernel, dim3(nchunks), dim3(256), 0, stream_, a);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits) {

@@ -33,6 +33,7 @@ namespace orz {
 constexpr uint32_t kSegMax = 64;            // positions per segment == lanes per wavefront
 constexpr uint32_t kNPMax = kSegMax + 2;    // + the two lazy probe positions past the segment
 constexpr uint32_t kNoChange = 0xffffffffu;
+constexpr uint32_t kRankChunk = 32;         // segments per RankKernel block
 constexpr uint32_t kLbPre = 8;              // bytes staged in LDS before the segment start
 constexpr uint32_t kLbLen = kLbPre + kNPMax + kMaxLen + 14;  // 330 -> bytes up to x+240+8 readable
 
@@ -70,6 +71,7 @@ struct ParseArgs {
     uint32_t* SRC;
     uint8_t* W0;
     uint8_t* LR;
+    uint32_t* partial;        // [2][kRankChunks max][256] per-chunk ctx item counts of the sweep, by parity
     ParseCtl* ctl;
 };
 
@@ -94,17 +96,17 @@ ORZ_D int ctz64(uint64_t v) { return __builtin_ctzll(v); }
 #endif
 
 // common prefix of a[0..) and b[0..), capped at 240, eight bytes a step (== src/mem.rs:41-51)
-ORZ_D uint32_t lcp240u(const uint8_t* a, const uint8_t* b) {
+ORZ_D uint32_t lcp240u(const uint8_t* a, const uint8_t* b, uint32_t cap = kMaxLen) {
     uint32_t l = 0;
-    while (l < kMaxLen) {
+    while (l < cap) {
         uint64_t x = ldu64(a + l) ^ ldu64(b + l);
         if (x) {
             l += (uint32_t)ctz64(x) >> 3;
-            return l < kMaxLen ? l : kMaxLen;
+            return l < cap ? l : cap;
         }
         l += 8;
     }
-    return kMaxLen;
+    return cap;
 }
 
 // byte offsets of the per-wave LDS arrays (all sizes for the kNPMax = 66 position case)
@@ -258,14 +260,33 @@ struct ParseWave {
             uint32_t* myco = co + x * D;
             uint8_t* myml = cml + x * D;
             uint8_t* mycl = cl + x * D;
-            for (uint32_t k = 0; k < found; k++) {
-                const uint32_t slot = mycq[k];
-                const uint32_t q = a.epos[slot];
-                const uint32_t m = a.sml[slot];
-                myco[k] = a.sord[slot];
-                myml[k] = (uint8_t)m;
-                mycq[k] = q;
-                mycl[k] = m == 255 ? 0 : (uint8_t)lcp240u(b + q, lb + kLbPre + x);
+            const uint8_t* px = lb + kLbPre + x;
+            const uint64_t x0 = ldu64(px);
+            // eight candidates a round: all slot reads, then all first-8-byte compares, in flight together
+            for (uint32_t k0 = 0; k0 < found; k0 += 8) {
+                uint32_t sl[8], q[8], m[8], o[8];
+                uint64_t d0[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) sl[i] = mycq[k0 + i < found ? k0 + i : k0];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    q[i] = a.epos[sl[i]];
+                    m[i] = a.sml[sl[i]];
+                    o[i] = a.sord[sl[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) d0[i] = ldu64(b + q[i]) ^ x0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (k0 + i >= found) break;
+                    uint32_t l;
+                    if (d0[i]) l = (uint32_t)ctz64(d0[i]) >> 3;
+                    else l = 8 + lcp240u(b + q[i] + 8, px + 8, kMaxLen - 8);
+                    myco[k0 + i] = o[i];
+                    myml[k0 + i] = (uint8_t)m[i];
+                    mycq[k0 + i] = q[i];
+                    mycl[k0 + i] = m[i] == 255 ? 0 : (uint8_t)l;
+                }
             }
             ncand[x] = (uint8_t)found;
             if (x < npos) {  // words[hash2(pos-1)] as older segments leave it
@@ -438,7 +459,13 @@ struct ParseWave {
                 changed = true;
             }
         }
-        for (uint32_t c = lane; c < 256; c += 64) a.hist[(size_t)(sg % a.ring) * 256 + c] = cnt[c];
+        {
+            uint32_t* part = a.partial + ((size_t)a.par * (a.wsegs / kRankChunk + 1) + w.block() / kRankChunk) * 256;
+            for (uint32_t c = lane; c < 256; c += 64) {
+                a.hist[(size_t)(sg % a.ring) * 256 + c] = cnt[c];
+                if (cnt[c]) atom_add32(&part[c], cnt[c]);
+            }
+        }
         if (lane == 0) {
             const uint32_t v = (scal[0] << 2) | scal[1];
             if (a.exitst[sg + 1] != v) {
@@ -485,37 +512,58 @@ struct ParseWave {
 };
 
 // ---------------------------------------------------------------------------------------------
-// After a sweep: ring ordinals.  base[s+1][c] = base[s][c] + hist[s][c] over the window, and the
-// front moves to just past the first changed segment.  One block of 1024 threads:
-// thread = (chunk k of 4, ctx c).
-struct RankScanArgs {
+// After a sweep: ring ordinals.  One block of 256 threads (thread = ctx c) per chunk of
+// kRankChunk segments of the window:
+//   off[c]       = base[front][c] + sum of the partial[chunk' < chunk][c] that ParseWave accumulated
+//   base[s+1][c] = base[s][c] + hist[s][c] over the chunk's segments            (ring of R rows)
+//   sord         = base[seg][ctx] + LR for every current item of the chunk      (what RankApply was)
+// Block 0 also moves the front to just past the first changed segment and re-arms the other parity.
+struct RankArgs {
+    const uint8_t* win;
     ParseCtl* ctl;
     const uint8_t* hist;
     uint32_t* base;
-    uint32_t nseg, wsegs, ring, par;
+    uint32_t* partial;
+    const uint32_t* idx;
+    const uint8_t* sml;
+    const uint8_t* LR;
+    uint32_t* sord;
+    uint32_t nseg, seg, wsegs, ring, len, par;
 };
-// body for thread (k, c) split in two passes around a block barrier; `partial` = LDS [4][256]
-ORZ_HD void rank_scan_pass1(const RankScanArgs& a, uint32_t k, uint32_t c, uint32_t* partial) {
+// `rows` = LDS [kRankChunk + 1][256] u32 ; sync() = block barrier ; c = thread id (0..255)
+template <class SYNC>
+ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* rows, SYNC sync) {
     const uint32_t f = a.ctl->front[a.par];
     const uint32_t wend = f + a.wsegs < a.nseg ? f + a.wsegs : a.nseg;
-    const uint32_t n = wend > f ? wend - f : 0, per = (n + 3) / 4;
-    const uint32_t s0 = f + k * per, s1 = s0 + per < wend ? s0 + per : wend;
-    uint32_t sum = 0;
-    for (uint32_t s = s0; s < s1; s++) sum += a.hist[(size_t)(s % a.ring) * 256 + c];
-    partial[k * 256 + c] = sum;
-}
-ORZ_HD void rank_scan_pass2(const RankScanArgs& a, uint32_t k, uint32_t c, const uint32_t* partial) {
-    const uint32_t f = a.ctl->front[a.par];
-    const uint32_t wend = f + a.wsegs < a.nseg ? f + a.wsegs : a.nseg;
-    const uint32_t n = wend > f ? wend - f : 0, per = (n + 3) / 4;
-    const uint32_t s0 = f + k * per, s1 = s0 + per < wend ? s0 + per : wend;
-    uint32_t run = a.base[(size_t)(f % a.ring) * 256 + c];
-    for (uint32_t i = 0; i < k; i++) run += partial[i * 256 + c];
-    for (uint32_t s = s0; s < s1; s++) {
-        run += a.hist[(size_t)(s % a.ring) * 256 + c];
-        a.base[(size_t)((s + 1) % a.ring) * 256 + c] = run;
+    const uint32_t nchunk = a.wsegs / kRankChunk + 1;
+    const uint32_t s0 = f + chunk * kRankChunk;
+    const uint32_t s1 = s0 + kRankChunk < wend ? s0 + kRankChunk : wend;
+    uint32_t* part = a.partial + (size_t)a.par * nchunk * 256;
+    if (s0 < wend) {
+        uint32_t run = a.base[(size_t)(f % a.ring) * 256 + c];
+        for (uint32_t i = 0; i < chunk; i++) run += part[i * 256 + c];
+        rows[c] = run;
+        for (uint32_t s = s0; s < s1; s++) {
+            run += a.hist[(size_t)(s % a.ring) * 256 + c];
+            rows[(s - s0 + 1) * 256 + c] = run;
+            a.base[(size_t)((s + 1) % a.ring) * 256 + c] = run;
+        }
     }
-    if (k == 0 && c == 0) {  // the next sweep's front
+    sync();
+    if (s0 < wend) {
+        const uint32_t x0 = kPre + s0 * a.seg;
+        const uint32_t npos = (s1 - s0) * a.seg;
+        for (uint32_t i = c; i < npos; i += 256) {
+            const uint32_t x = x0 + i;
+            if (x >= a.len) break;
+            const uint32_t j = a.idx[x];
+            if (a.sml[j] != 255) a.sord[j] = rows[(i / a.seg) * 256 + hash1(a.win, x - 1)] + a.LR[x];
+        }
+    }
+    // re-arm the other parity's accumulators for the next sweep (nobody reads them in this launch)
+    uint32_t* other = a.partial + (size_t)(a.par ^ 1) * nchunk * 256;
+    other[chunk * 256 + c] = 0;
+    if (chunk == 0 && c == 0) {
         const uint32_t fc = a.ctl->fchg[a.par];
         uint32_t nf = fc == kNoChange ? wend : fc + 1;
         if (f >= a.nseg) nf = f;
@@ -523,27 +571,5 @@ ORZ_HD void rank_scan_pass2(const RankScanArgs& a, uint32_t k, uint32_t c, const
         a.ctl->fchg[a.par ^ 1] = kNoChange;
     }
 }
-
-struct RankApply {  // thread per window position: ring ordinal of every current item of the window
-    const uint8_t* win;
-    const ParseCtl* ctl;
-    const uint32_t* idx;
-    const uint8_t* sml;
-    const uint8_t* LR;
-    const uint32_t* base;
-    uint32_t* sord;
-    uint32_t nseg, seg, wsegs, ring, len, par;
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t f = ctl->front[par];
-        if (f >= nseg) return;
-        const uint32_t s = f + (uint32_t)(tid / seg);
-        if (s >= nseg) return;
-        const uint32_t x = kPre + s * seg + (uint32_t)(tid % seg);
-        if (x >= len) return;
-        const uint32_t j = idx[x];
-        if (sml[j] == 255) return;
-        sord[j] = base[(size_t)(s % ring) * 256 + hash1(win, x - 1)] + LR[x];
-    }
-};
 
 }  // namespace orz

@@ -193,7 +193,7 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
 
-    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 64, uint32_t win_segs = 4096)
+    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 4096)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs) {
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 64]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
@@ -230,6 +230,7 @@ class StreamEncoder {
         hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
         base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
         ctl_ = be_.template alloc<ParseCtl>(1);
+        partial_ = be_.template alloc<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
         f32_ = be_.template alloc<uint32_t>(kWLen);
         sc32_ = be_.template alloc<uint32_t>(kWLen);
         hpos_ = be_.template alloc<uint32_t>(kPre + 1);
@@ -267,7 +268,7 @@ class StreamEncoder {
     }
     ~StreamEncoder() {
         void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, epos_,
-                        kpos_, runstart_, krun_, vbits_, kbits_, sml_, sord_, exitst_, hist_, base_, ctl_, f32_, sc32_,
+                        kpos_, runstart_, krun_, vbits_, kbits_, sml_, sord_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_};
@@ -335,6 +336,7 @@ class StreamEncoder {
         be_.memset(hist_, 0, (size_t)ring_ * 256);
         be_.d2d(base_, ctxcount_, 256 * 4);
         be_.launch(1, ParseCtlInit{ctl_});
+        be_.memset(partial_, 0, (size_t)2 * (wsegs_ / kRankChunk + 1) * 256 * 4);
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
         be_.sync();
         double t1 = be_.now();
@@ -347,7 +349,7 @@ class StreamEncoder {
         pa.lt0 = lt_carry_; pa.par = 0;
         pa.epos = epos_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.sml = sml_; pa.sord = sord_; pa.kbits = kbits_; pa.exitst = exitst_;
-        pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.ctl = ctl_;
+        pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
         const size_t lds_bytes = ParseLds::make(dmax_).total;
         const uint32_t grid = std::min(wsegs_, nseg);
         uint32_t par = 0, front = 0, batch = 8;
@@ -358,9 +360,8 @@ class StreamEncoder {
                 be_.timed_begin();
                 be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
                 be_.timed_end();
-                be_.rank_scan(RankScanArgs{ctl_, hist_, base_, nseg, wsegs_, ring_, par});
-                be_.launch((size_t)grid * seg_,
-                           RankApply{win, ctl_, idx_, sml_, LR_, base_, sord_, nseg, seg_, wsegs_, ring_, len, par});
+                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, sml_, LR_, sord_, nseg, seg_, wsegs_, ring_, len, par},
+                         wsegs_ / kRankChunk + 1);
                 par ^= 1;
                 sweeps++;
             }
@@ -514,6 +515,7 @@ class StreamEncoder {
     uint8_t* hist_;
     uint32_t* base_;
     ParseCtl* ctl_;
+    uint32_t* partial_;
     uint32_t *f32_, *sc32_, *hpos_, *ctxcount_, *tailkey_;
     uint8_t* wsnap_;
     uint32_t* wlast_;

@@ -1,0 +1,75 @@
+"""Multi-GPU layer: independent members farmed across ranks, one gather of the finished bitstreams.
+
+A single orz stream does not shard (its model state is one adaptive chain); what
+shards is a job of independent *members* (input chunks encoded as complete orz streams).  Member m
+goes to rank m % world; each rank encodes its members on its own GPU with no data-path collective;
+the only exchange is the final variable-length gather of the compressed members to rank 0
+(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Container: the members of a job are concatenated in member order.  Each member is a complete orz
+stream ending in its own 0x00 EOF chunk, so `split_members` can cut the container again and every
+piece decodes with the reference decoder (which reads one stream and stops, src/lib.rs:108-110).
+"""
+import torch
+import torch.distributed as dist
+
+
+def members_of_rank(n_members, rank, world):
+    """member indices encoded by `rank` (round robin)"""
+    return list(range(rank, n_members, world))
+
+
+def gather_members(local, n_members, rank, world, device=None):
+    """local: {member index: bytes} encoded on this rank.  Returns the list of all members in member
+    order on rank 0 (None elsewhere).  One size all-gather + one padded byte gather."""
+    mine = members_of_rank(n_members, rank, world)
+    assert sorted(local) == mine
+    dev = device if device is not None else torch.device("cpu")
+    per_rank = (n_members + world - 1) // world
+    sizes = torch.zeros(per_rank, dtype=torch.int64, device=dev)
+    for i, m in enumerate(mine):
+        sizes[i] = len(local[m])
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    cap = int(max(int(s.sum()) for s in all_sizes))
+    payload = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    blob = b"".join(local[m] for m in mine)
+    if blob:
+        payload[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    if rank == 0:
+        bufs = [torch.zeros_like(payload) for _ in range(world)]
+        dist.gather(payload, bufs, dst=0)
+        out = [None] * n_members
+        for r in range(world):
+            raw = bufs[r].cpu().numpy().tobytes()
+            at = 0
+            for i, m in enumerate(members_of_rank(n_members, r, world)):
+                ln = int(all_sizes[r][i])
+                out[m] = raw[at:at + ln]
+                at += ln
+        return out
+    dist.gather(payload, None, dst=0)
+    return None
+
+
+def split_members(container):
+    """Cut a concatenation of orz streams at their EOF chunks (LEB128 framing, src/ioutil.rs:60-88)."""
+    out, at, start = [], 0, 0
+    n = len(container)
+    while at < n:
+        t, shift = 0, 0
+        while True:
+            b = container[at]
+            at += 1
+            t |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                break
+        if t == 0:
+            out.append(container[start:at])
+            start = at
+        else:
+            at += t
+    if start != n:
+        raise ValueError("container does not end on an EOF chunk")
+    return out

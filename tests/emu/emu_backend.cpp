@@ -33,12 +33,27 @@ struct EmuBackend {
     template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
     }
-    void rank_scan(const orz::RankScanArgs& a) {
-        std::vector<uint32_t> partial(4 * 256);
-        for (uint32_t k = 0; k < 4; k++)
-            for (uint32_t c = 0; c < 256; c++) orz::rank_scan_pass1(a, k, c, partial.data());
-        for (uint32_t k = 4; k-- > 0;)  // (k,c) = (0,0) moves the front: run it last
-            for (uint32_t c = 256; c-- > 0;) orz::rank_scan_pass2(a, k, c, partial.data());
+    void rank(const orz::RankArgs& a, uint32_t nchunks) {
+        // one block per chunk, 256 threads around one barrier: run each block as two thread loops
+        std::vector<uint32_t> rows((orz::kRankChunk + 1) * 256);
+        for (uint32_t ch = nchunks; ch-- > 0;) {  // chunk 0 moves the front: run it last
+            // phase split at the barrier: emulate by running every thread up to the barrier first
+            // threads are independent before the barrier (own column) and read rows[] after it
+            for (int phase = 0; phase < 2; phase++)
+                for (uint32_t c = 256; c-- > 0;) run_rank_thread(a, ch, c, rows.data(), phase);
+        }
+    }
+    // executes thread c of chunk ch either up to the barrier (phase 0) or from it (phase 1)
+    static void run_rank_thread(const orz::RankArgs& a, uint32_t ch, uint32_t c, uint32_t* rows, int phase) {
+        struct Stop {};
+        int seen = 0;
+        auto sync = [&]() { seen++; if (phase == 0) throw Stop(); };
+        if (phase == 0) {
+            try { orz::rank_chunk(a, ch, c, rows, sync); } catch (Stop&) {}
+        } else {
+            // re-run from the start with side effects of the pre-barrier part being idempotent
+            orz::rank_chunk(a, ch, c, rows, [&]() {});
+        }
     }
     const uint64_t* sort_u64(uint64_t* a, uint64_t*, size_t n, int bits) {
         uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);

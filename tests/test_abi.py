@@ -1,0 +1,67 @@
+"""The C-ABI library: loads, exports every symbol include/orz_hip.h declares, and fails loudly
+without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "orz_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(orz_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if not n.endswith("_fn")))
+
+
+def test_library_is_built_in_tree():
+    from orz_amd import _native
+
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    assert _native.LIB_PATH.startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from orz_amd import _native
+
+    lib = _native.load()
+    declared = _declared()
+    assert len(declared) >= 14
+    bound = {n for n, _, _ in _native.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name), "liborz_hip.so does not export " + name
+        assert name in bound, "orz_amd/_native.py does not bind " + name
+
+
+def test_level_map_matches_reference_cli():
+    # src/main.rs:97-102
+    import orz_amd
+
+    assert [(c.match_depth, c.lazy_match_depth1, c.lazy_match_depth2) for c in map(orz_amd.cfg_for_level, (0, 1, 2))] == [
+        (5, 3, 2), (15, 9, 6), (45, 27, 18)]
+    with pytest.raises(ValueError):
+        orz_amd.cfg_for_level(3)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a HIP device the product must refuse to encode (the oracle is never a fallback)."""
+    import orz_amd
+    from orz_amd import _native
+
+    if _native.load().orz_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(Exception):
+        orz_amd.StreamEncoder(device=0, level=1)
+    with pytest.raises(Exception):
+        orz_amd.LZEncoder(device=0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "orz_amd")
+    for d, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(d, f), errors="replace").read()
+                assert "orz_oracle" not in src and "_oracle" not in src, f

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the multi-GPU layer's host logic (member sharding + bitstream gather)."""
+import os
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_members, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from orz_amd import dist as od
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # stand-in payloads: member m is a fake "stream" of m-dependent length ending in the EOF byte
+        local = {m: bytes([1 + (m * 7 + i) % 250 for i in range(100 + 37 * m)]) for m in od.members_of_rank(n_members, rank, world)}
+        got = od.gather_members(local, n_members, rank, world)
+        if rank == 0:
+            q.put([len(x) for x in got] + [sum(x[0] for x in got)])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_member_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_members = 5
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_members, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = q.get(timeout=10)
+    assert res[:-1] == [100 + 37 * m for m in range(n_members)]
+    assert res[-1] == sum(1 + (m * 7) % 250 for m in range(n_members))
+
+
+def test_split_members_roundtrip(oracle):
+    from orz_amd import dist as od
+
+    parts = [oracle.encode(b"member %d " % i * (50 + i), 1) for i in range(4)]
+    assert od.split_members(b"".join(parts)) == parts
+    for i, p in enumerate(parts):
+        assert oracle.decode(p)[0] == b"member %d " % i * (50 + i)
+
+
+def test_round_robin_assignment():
+    from orz_amd import dist as od
+
+    seen = sorted(m for r in range(8) for m in od.members_of_rank(61, r, 8))
+    assert seen == list(range(61))

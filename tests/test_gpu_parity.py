@@ -1,0 +1,145 @@
+"""GPU tier: the HIP encoder, driven through the C ABI (liborz_hip.so via orz_amd), against the CPU
+oracle -- bit-exact, on seeded inputs at sizes the oracle finishes in seconds, on the committed
+golden streams, and at the BASELINE size through round trips with the oracle's decoder."""
+import ctypes
+import glob
+import os
+
+import pytest
+
+import _data
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(_data.SMALL_CASES))
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_small_cases(gpu_encoder_factory, oracle, name, level):
+    data = _data.SMALL_CASES[name]
+    assert gpu_encoder_factory(level).encode(data) == oracle.encode(data, level)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.orz"))))
+def test_golden_streams(gpu_encoder_factory, path):
+    name, lvl, _ = os.path.basename(path).rsplit(".", 2)
+    data = open(os.path.join(GOLD, name + ".in"), "rb").read()
+    assert gpu_encoder_factory(int(lvl[1])).encode(data) == open(path, "rb").read()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("maker", ["text", "mixed", "zeros", "random", "p1", "p3"])
+def test_shapes_bit_exact(gpu_encoder_factory, oracle, maker, level):
+    n = 1_500_000
+    data = {"text": lambda: _data.text(n), "mixed": lambda: _data.mixed(n), "zeros": lambda: _data.zeros_noise(n),
+            "random": lambda: _data.random_bytes(n), "p1": lambda: _data.periodic(n, 1), "p3": lambda: _data.periodic(n, 3)}[maker]()
+    assert gpu_encoder_factory(level).encode(data) == oracle.encode(data, level)
+
+
+@pytest.mark.parametrize("seg,win", [(62, 512), (62, 16384), (32, 2048), (64, 4096), (17, 1000)])
+def test_tuning_does_not_change_the_stream(gpu_encoder_factory, oracle, seg, win):
+    data = _data.mixed(3_000_000, seed=31)
+    enc = gpu_encoder_factory(1)
+    enc.set_tuning(seg, win)
+    try:
+        assert enc.encode(data) == oracle.encode(data, 1)
+    finally:
+        enc.set_tuning(62, 4096)
+
+
+def test_more_than_one_chunk_per_block(gpu_encoder_factory, oracle):
+    data = _data.random_bytes(1_300_000) + _data.text(400_000)
+    out, st = gpu_encoder_factory(1).encode(data, stats=True)
+    assert st["chunks"] >= 2
+    assert out == oracle.encode(data, 1)
+
+
+def test_block_slide_and_short_final_block(gpu_encoder_factory, oracle):
+    # two full 16 MiB blocks + a short one: window slide, ring rebasing, tail-key hazard, stale tail bytes
+    data = _data.mixed(2 * 16_777_216 + 1_234_567, seed=41)
+    out, st = gpu_encoder_factory(1).encode(data, stats=True)
+    assert st["blocks"] == 3
+    assert out == oracle.encode(data, 1)
+
+
+def test_item_trace_matches_oracle_parse(gpu_encoder_factory, oracle):
+    """stage-level parity: every item's position, raw symbol, context, rank and length code"""
+    data = _data.mixed(800_000, seed=51)
+    enc = gpu_encoder_factory(1)
+    enc.set_item_trace(True)
+    try:
+        out = enc.encode(data)
+        tr = enc.item_trace()
+    finally:
+        enc.set_item_trace(False)
+    ref, items = oracle.encode(data, 1, trace_cap=len(data) + 8)
+    assert out == ref and len(tr) == len(items)
+    for i in range(0, len(items), 97):
+        o, g = items[i], tr[i]
+        assert (g["pos"], g["symbol"], g["rank"], g["ctx"], g["enc_len"], g["unlikely"]) == (
+            o.pos, o.symbol, o.rank, o.ctx, o.enc_len, o.unlikely)
+
+
+def test_object_level_encoder_matches_reference_call_pattern(oracle):
+    """LZEncoder::encode chunk by chunk + forward, exactly as orz::encode drives it (src/lib.rs:72-84)"""
+    import orz_amd
+
+    P, B, SENT = orz_amd.SBVEC_PREMATCH_LEN, orz_amd.LZ_BLOCK_SIZE, orz_amd.SBVEC_SENTINEL_LEN
+    data = _data.random_bytes(1_150_000) + _data.mixed(16_777_216 - 1_150_000 + 500_000, seed=61)
+    cfg = orz_amd.cfg_for_level(0)
+    window = (ctypes.c_uint8 * (B + 2 * SENT))()
+    enc = orz_amd.LZEncoder(device=0)
+    stream = bytearray()
+    off = 0
+    while off < len(data):
+        take = min(B - P, len(data) - off)
+        ctypes.memmove(ctypes.addressof(window) + SENT + P, data[off:off + take], take)
+        spos, sbuf_len = P, P + take
+        nchunks = 0
+        while spos < sbuf_len:
+            spos, chunk = enc.encode(cfg, window, sbuf_len, spos)
+            t = len(chunk)
+            while t >= 128:
+                stream.append(128 + t % 128)
+                t //= 128
+            stream.append(t)
+            stream += chunk
+            nchunks += 1
+        if off == 0:
+            assert nchunks >= 2
+        off += take
+        # sbvec.copy_within(len-P.., 0) ; lzenc.forward(len - P)
+        ctypes.memmove(ctypes.addressof(window) + SENT, ctypes.addressof(window) + SENT + (B - P), P)
+        enc.forward(B - P)
+    stream.append(0)
+    enc.close()
+    assert bytes(stream) == oracle.encode(data, 0)
+
+
+def test_stream_callbacks_api(oracle):
+    import io
+
+    import orz_amd
+
+    data = _data.text(700_000, seed=71)
+    src, dst = io.BytesIO(data), io.BytesIO()
+    seen = []
+    r, w = orz_amd.encode(src, dst, orz_amd.cfg_for_level(2), progress=lambda fin, a, b: seen.append((fin, a, b)))
+    assert (r, w) == (len(data), len(dst.getvalue()))
+    assert dst.getvalue() == oracle.encode(data, 2)
+    assert seen and seen[-1][0] is True
+
+
+def test_baseline_size_roundtrip_properties(gpu_encoder_factory, oracle):
+    """100,000,000 bytes (BASELINE config 1 size): decode(encode(x)) == x through the oracle's decoder,
+    encoding is deterministic, and the size equals the oracle encoder's (well inside the +-0.5 % band)."""
+    import corpus
+
+    data = corpus.text_corpus(100_000_000)
+    enc = gpu_encoder_factory(1)
+    out = enc.encode(data)
+    back, used = oracle.decode(out)
+    assert used == len(out) and back == data
+    ref = oracle.encode(data, 1)
+    assert abs(len(out) - len(ref)) <= 0.005 * len(ref)
+    assert out == ref
