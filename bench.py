@@ -156,7 +156,7 @@ def main():
                 "lzcfg": [15, 9, 6],
                 "members": world,
                 "segment_bytes": 62,
-                "window_segments": 4096,
+                "window_segments": 2048,
                 "input": "resident in HBM",
             },
             "compressed_bytes": len(out),

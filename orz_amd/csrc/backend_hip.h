@@ -40,6 +40,16 @@ struct DevWave {
     __device__ __forceinline__ uint8_t* lds() const { return lds_; }
     __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // value of lane `src` (wave-uniform index) in every lane: v_readlane_b32
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) const {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+    }
+    __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t src) const {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    __device__ __forceinline__ unsigned long long clock() const { return __builtin_amdgcn_s_memtime(); }
 };
 template <class K>
 __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {

@@ -30,7 +30,7 @@ bool cfg_ok(const orz_lzcfg* c) {
            c->lazy_match_depth2 <= 200;
 }
 
-constexpr unsigned kDefaultSeg = 64, kDefaultWin = 4096;
+constexpr unsigned kDefaultSeg = 62, kDefaultWin = 2048;
 
 unsigned env_u(const char* name, unsigned dflt) {
     const char* v = std::getenv(name);

@@ -6,7 +6,7 @@
 //   Bucket::update / BucketMatcher::update  src/matcher.rs:62-80,115-121
 //   words[] predictor                       src/lz.rs:132-136,203,233
 // The reference runs them as one serial chain over the stream.  Here the block is cut into
-// segments of <= 64 positions; one wavefront owns one segment and re-derives its items with the
+// segments of <= 62 positions; one wavefront owns one segment and re-derives its items with the
 // reference's exact decision rules, reading every other segment's items as they currently stand
 // (speculation).  A sweep evaluates a window of segments beyond the `front` (first non-final
 // segment); segments that sit before the first segment whose result changed are final, because
@@ -14,14 +14,14 @@
 //
 // Data layout (one block, HBM):
 //   static, built by the prep kernels once per block
-//     epos[slot]      positions sorted by (ctx8, hash_dword % 4627, position)  ("candidate lists")
+//     srec[slot].pos  positions sorted by (ctx8, hash_dword % 4627, position)  ("candidate lists")
 //     idx[x]          slot of window offset x
 //     runstart[key]   first slot of a (ctx8, hash) run
 //     kpos/kidx/krun  the same for the word predictor, keyed by hash2 (15 bit)
 //   speculative, updated in place by the owning segment's wavefront (only when a value changes)
 //     vbits           1 bit per slot: position is an item start (ring member)
-//     sml[slot]       the item's match_len_expected (0 literal/word, 255 = not an item)
-//     sord[slot]      the item's ordinal in its ctx ring (recomputed per sweep by RankApply)
+//     srec[slot].ml   the item's match_len_expected (0 literal/word, 255 = not an item)
+//     srec[slot].ord  the item's ordinal in its ctx ring (recomputed per sweep by the rank kernel)
 //     kbits           1 bit per word-predictor slot: words[] was updated at that position + 2
 //     exitst[s]       where segment s-1 left the stream: (next item position << 2) | last type
 //     hist[s][ctx]    items per context of segment s (ring of R segments) -> base[s][ctx] prefix
@@ -30,40 +30,55 @@
 
 namespace orz {
 
-constexpr uint32_t kSegMax = 64;            // positions per segment == lanes per wavefront
-constexpr uint32_t kNPMax = kSegMax + 2;    // + the two lazy probe positions past the segment
+constexpr uint32_t kSegMax = 62;            // positions per segment; + 2 lazy probe positions = 64 lanes
+constexpr uint32_t kNPMax = kSegMax + 2;
 constexpr uint32_t kNoChange = 0xffffffffu;
-constexpr uint32_t kRankChunk = 32;         // segments per RankKernel block
+constexpr uint32_t kRankChunk = 32;         // segments per rank-kernel block
 constexpr uint32_t kLbPre = 8;              // bytes staged in LDS before the segment start
-constexpr uint32_t kLbLen = kLbPre + kNPMax + kMaxLen + 14;  // 330 -> bytes up to x+240+8 readable
+constexpr uint32_t kLbLen = 336;            // kLbPre + 64 + 240 + 8 rounded up to dwords: x+240+8 readable
+constexpr uint32_t kCntSlack = 64;          // own items a segment can add to one context (robustness margin)
+
+struct SlotRec {  // one candidate-list slot, 16 bytes = one load
+    uint32_t pos;
+    uint32_t ord;
+    uint32_t ml;
+    uint32_t pad;
+};
 
 struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t front[2];      // first non-final segment, by sweep parity
     uint32_t fchg[2];       // lowest segment whose result changed in the sweep, by parity
     uint32_t evals;         // segments evaluated so far (statistics)
-    uint32_t pad[3];
+    uint32_t nprof;         // waves sampled into prof[]
+    uint32_t slow;          // items that needed the serial evaluation (statistics)
+    uint32_t pad;
+    unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
+    unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
 };
 
 struct ParseArgs {
     const uint8_t* win;       // window offset 0 (480 readable bytes before it)
     uint32_t len;             // kPre + n
-    uint32_t nseg, seg;       // segments in the block, positions per segment (<= 64)
+    uint32_t nseg, seg;       // segments in the block, positions per segment (<= 62)
     uint32_t wsegs;           // segments per sweep window
     uint32_t ring;            // R: rows of the hist/base rings (>= wsegs + 1)
     uint32_t depth, lazy1, lazy2, dmax;  // LZCfg, dmax = max of the three = candidates kept per position
     uint32_t lt0;             // type of the last item of the previous block (after_literal carry)
     uint32_t par;             // sweep parity
-    const uint32_t* epos;
+    uint32_t prof;            // sample phase timings into ctl->prof (diagnostics)
+    SlotRec* srec;
     const uint32_t* idx;
     const uint32_t* runstart;
     const uint32_t* kpos;
     const uint32_t* kidx;
     const uint32_t* krun;
     const uint8_t* wsnap;     // words[] as of the block start, [32768][2]
-    uint64_t* vbits;
-    uint8_t* sml;
-    uint32_t* sord;
-    uint64_t* kbits;
+    uint64_t* vbits;          // level 0: one bit per slot
+    uint64_t* v1;             // level 1: one bit per vbits word that may be non-zero (set-only inside a block)
+    uint64_t* v2;             // level 2: one bit per v1 word that may be non-zero
+    uint64_t* kbits;          // word-predictor slots, same three levels
+    uint64_t* k1;
+    uint64_t* k2;
     uint32_t* exitst;         // [nseg + 1]
     uint8_t* hist;            // [ring][256]
     uint32_t* base;           // [ring][256]
@@ -71,7 +86,7 @@ struct ParseArgs {
     uint32_t* SRC;
     uint8_t* W0;
     uint8_t* LR;
-    uint32_t* partial;        // [2][kRankChunks max][256] per-chunk ctx item counts of the sweep, by parity
+    uint32_t* partial;        // [2][chunks][256] per-chunk ctx item counts of the sweep, by parity
     ParseCtl* ctl;
 };
 
@@ -80,22 +95,35 @@ ORZ_D uint32_t ldu32(const uint8_t* p) { return *reinterpret_cast<const __attrib
 ORZ_D uint64_t ldu64(const uint8_t* p) { return *reinterpret_cast<const __attribute__((aligned(1))) uint64_t*>(p); }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
+ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { return atomicAnd((unsigned long long*)p, (unsigned long long)v); }
+ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { return atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+ORZ_D void fence_agent() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
 ORZ_D int clz64(uint64_t v) { return __clzll((long long)v); }
 ORZ_D int ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }
+ORZ_D SlotRec ld_rec(const SlotRec* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    return SlotRec{v.x, v.y, v.z, v.w};
+}
 #else
 ORZ_D uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 ORZ_D uint64_t ldu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { *p |= v; }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { *p &= v; }
+ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p &= v; return o; }
+ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p |= v; return o; }
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
+ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { *p += v; }
+ORZ_D void fence_agent() {}
 ORZ_D int clz64(uint64_t v) { return __builtin_clzll(v); }
 ORZ_D int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+ORZ_D SlotRec ld_rec(const SlotRec* p) { return *p; }
 #endif
 
-// common prefix of a[0..) and b[0..), capped at 240, eight bytes a step (== src/mem.rs:41-51)
+// common prefix of a[0..) and b[0..), capped, eight bytes a step (== src/mem.rs:41-51)
 ORZ_D uint32_t lcp240u(const uint8_t* a, const uint8_t* b, uint32_t cap = kMaxLen) {
     uint32_t l = 0;
     while (l < cap) {
@@ -109,26 +137,124 @@ ORZ_D uint32_t lcp240u(const uint8_t* a, const uint8_t* b, uint32_t cap = kMaxLe
     return cap;
 }
 
-// byte offsets of the per-wave LDS arrays (all sizes for the kNPMax = 66 position case)
+// Three-level bitmap over the candidate slots: vbits (bit per slot), v1 (bit per vbits word that is
+// non-zero -- kept exact), v2 (bit per v1 word that has ever been non-zero in this block -- set-only).
+// Setting goes bottom-up (word, then summaries); clearing the last bit of a word clears its v1 bit
+// and then re-reads the word at L2: a concurrent setter either is seen by that re-read or sets v1
+// after our clear, so "word != 0 implies v1 bit set" holds whenever the kernel is quiescent.
+ORZ_D void slot_set(uint64_t* vbits, uint64_t* v1, uint64_t* v2, uint32_t j) {
+    const uint32_t w = j >> 6;
+    const uint64_t old = atom_fetch_or64(&vbits[w], 1ull << (j & 63));
+    if (old == 0) {
+        fence_agent();
+        const uint64_t o1 = atom_fetch_or64(&v1[w >> 6], 1ull << (w & 63));
+        if (o1 == 0) atom_or64(&v2[w >> 12], 1ull << ((w >> 6) & 63));
+    }
+}
+ORZ_D void slot_clear(uint64_t* vbits, uint64_t* v1, uint32_t j) {
+    const uint32_t w = j >> 6;
+    const uint64_t bit = 1ull << (j & 63);
+    const uint64_t old = atom_fetch_and64(&vbits[w], ~bit);
+    if ((old & ~bit) == 0 && (old & bit)) {
+        atom_fetch_and64(&v1[w >> 6], ~(1ull << (w & 63)));
+        fence_agent();  // the re-read must not overtake the summary clear
+        if (atom_fetch_or64(&vbits[w], 0) != 0) atom_or64(&v1[w >> 6], 1ull << (w & 63));
+    }
+}
+
+// Newest-first list of the set slots in [lo, hi) of a three-level bitmap, at most D of them.
+// `word` is the already loaded level-0 word of slot hi-1.  Older words are reached through the
+// summaries: only non-empty ones are loaded, four in flight a round.
+ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint64_t* L2, uint64_t word, uint32_t hi,
+                             uint32_t lo, uint32_t D, uint32_t* out, uint32_t& nwords) {
+    uint32_t found = 0;
+    if (hi <= lo) return 0;
+    const uint32_t w0 = (hi - 1) >> 6, wmin = lo >> 6;
+    if (hi & 63) word &= (1ull << (hi & 63)) - 1;
+    if ((w0 << 6) < lo) word &= ~0ull << (lo - (w0 << 6));
+    while (word && found < D) {
+        int bit = 63 - clz64(word);
+        out[found++] = (w0 << 6) + (uint32_t)bit;
+        word &= ~(1ull << bit);
+    }
+    uint32_t u = w0 >> 6;
+    bool more = found < D && w0 > wmin;
+    uint64_t m1 = more ? L1[u] : 0;
+    if (w0 & 63) m1 &= (1ull << (w0 & 63)) - 1; else m1 = 0;
+    while (more) {
+        if ((u << 6) < wmin) m1 &= ~0ull << (wmin - (u << 6));
+        while (m1 && found < D) {
+            uint32_t ww[4];
+            uint64_t wd[4];
+            int nw = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ww[i] = 0;
+                if (m1) {
+                    const int bit = 63 - clz64(m1);
+                    m1 &= ~(1ull << bit);
+                    ww[i] = (u << 6) + (uint32_t)bit;
+                    nw = i + 1;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) wd[i] = i < nw ? L0[ww[i]] : 0;
+            nwords += (uint32_t)nw;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint64_t v = wd[i];
+                if (i < nw && (ww[i] << 6) < lo) v &= ~0ull << (lo - (ww[i] << 6));
+                while (v && found < D) {
+                    int bit = 63 - clz64(v);
+                    out[found++] = (ww[i] << 6) + (uint32_t)bit;
+                    v &= ~(1ull << bit);
+                }
+            }
+        }
+        if (found >= D || (u << 6) <= wmin || u == 0) break;
+        uint32_t u2 = (u - 1) >> 6;  // next non-empty level-1 word below u, through level 2
+        uint64_t m2 = L2[u2];
+        if (u & 63) m2 &= (1ull << (u & 63)) - 1;
+        for (;;) {
+            if (m2) { u = (u2 << 6) + (uint32_t)(63 - clz64(m2)); break; }
+            if (u2 == 0 || (u2 << 12) <= wmin) { more = false; break; }
+            u2--;
+            m2 = L2[u2];
+        }
+        if (!more || ((u << 6) + 63) < wmin) break;
+        m1 = L1[u];
+        nwords++;
+    }
+    return found;
+}
+
+// decision record of one position (u64): what the item starting there would be
+constexpr uint64_t kDecMatch = 1ull << 33, kDecLazy1 = 1ull << 34, kDecLazy2a = 1ull << 35, kDecLazy2b = 1ull << 36,
+                   kDecRobust = 1ull << 37;
+ORZ_D uint32_t dec_src(uint64_t d) { return (uint32_t)(d & 0x1ffffff); }
+ORZ_D uint32_t dec_len(uint64_t d) { return (uint32_t)(d >> 25) & 0xff; }
+
+// byte offsets of the per-wave LDS arrays
 struct ParseLds {
-    uint32_t lb, idxL, keyL, kkL, ownord, srcL, basec, cq, co;  // u8 / u32 arrays ...
-    uint32_t ctxL, ncand, wg, ownv, ownml, ownE, oldml, oldE, tyL, w0L, lrL, cnt, cml, cl, scal, total;
+    uint32_t lb, cdat, dec, idxL, keyL, kkL, ownord, srcL, basec, cq;
+    uint32_t wg, ctxL, ncand, ownv, ownml, ownE, oldml, oldE, tyL, w0L, lrL, cnt, dbg, total;
     ORZ_HD static ParseLds make(uint32_t dmax) {
         ParseLds o;
         uint32_t at = 0;
-        auto take = [&](uint32_t bytes) { uint32_t r = at; at += (bytes + 7) & ~7u; return r; };
-        o.lb = take(kLbLen + 8);
+        auto take = [&](uint32_t bytes) { uint32_t r = at; at += (bytes + 15) & ~15u; return r; };
+        o.lb = take(kLbLen + 16);
+        o.cdat = take(kNPMax * dmax * 8);  // per candidate: ord | lcp << 32 | ml << 40
+        o.dec = take(kNPMax * 8);
         o.idxL = take(kNPMax * 4);
         o.keyL = take(kNPMax * 4);
         o.kkL = take((kNPMax + 2) * 4);
         o.ownord = take(kNPMax * 4);
         o.srcL = take(kNPMax * 4);
         o.basec = take(256 * 4);
-        o.cq = take(kNPMax * dmax * 4);
-        o.co = take(kNPMax * dmax * 4);
+        o.cq = take(kNPMax * dmax * 4);    // candidate position (slot while the list is being built)
+        o.wg = take(kNPMax * 2);
         o.ctxL = take(kNPMax);
         o.ncand = take(kNPMax);
-        o.wg = take(kNPMax * 2);
         o.ownv = take(kNPMax);
         o.ownml = take(kNPMax);
         o.ownE = take(kNPMax);
@@ -138,9 +264,7 @@ struct ParseLds {
         o.w0L = take(kNPMax);
         o.lrL = take(kNPMax);
         o.cnt = take(256);
-        o.cml = take(kNPMax * dmax);
-        o.cl = take(kNPMax * dmax);
-        o.scal = take(64);
+        o.dbg = take(64 * 8 * 4);          // profiling stamps of sampled waves
         o.total = at;
         return o;
     }
@@ -151,6 +275,16 @@ struct ParseLds {
 struct ParseWave {
     ParseArgs a;
 
+    // pointers into the wave's LDS
+    struct Sh {
+        uint8_t* lb;
+        uint64_t* cdat;
+        uint64_t* dec;
+        uint32_t *idxL, *keyL, *kkL, *ownord, *srcL, *basec, *cq;
+        uint16_t* wg;
+        uint8_t *ctxL, *ncand, *ownv, *ownml, *ownE, *oldml, *oldE, *tyL, *w0L, *lrL, *cnt;
+    };
+
     template <class W>
     ORZ_D void operator()(W& w) const {
         const uint32_t lane = w.lane();
@@ -159,353 +293,481 @@ struct ParseWave {
         if (sg >= a.nseg) return;
         const ParseLds L = ParseLds::make(a.dmax);
         uint8_t* lds = w.lds();
-        uint8_t* lb = lds + L.lb;  // lb[kLbPre + i] = win[seg_start + i]
-        uint32_t* idxL = (uint32_t*)(lds + L.idxL);
-        uint32_t* keyL = (uint32_t*)(lds + L.keyL);
-        uint32_t* kkL = (uint32_t*)(lds + L.kkL);  // kkL[i] = hash2(seg_start - 2 + i - 1)
-        uint32_t* ownord = (uint32_t*)(lds + L.ownord);
-        uint32_t* srcL = (uint32_t*)(lds + L.srcL);
-        uint32_t* basec = (uint32_t*)(lds + L.basec);
-        uint32_t* cq = (uint32_t*)(lds + L.cq);
-        uint32_t* co = (uint32_t*)(lds + L.co);
-        uint8_t* ctxL = lds + L.ctxL;
-        uint8_t* ncand = lds + L.ncand;
-        uint16_t* wg = (uint16_t*)(lds + L.wg);
-        uint8_t* ownv = lds + L.ownv;
-        uint8_t* ownml = lds + L.ownml;
-        uint8_t* ownE = lds + L.ownE;
-        uint8_t* oldml = lds + L.oldml;
-        uint8_t* oldE = lds + L.oldE;
-        uint8_t* tyL = lds + L.tyL;
-        uint8_t* w0L = lds + L.w0L;
-        uint8_t* lrL = lds + L.lrL;
-        uint8_t* cnt = lds + L.cnt;
-        uint8_t* cml = lds + L.cml;
-        uint8_t* cl = lds + L.cl;
-        uint32_t* scal = (uint32_t*)(lds + L.scal);  // [0] p, [1] lt, [2] changed
+        Sh s;
+        s.lb = lds + L.lb;  // lb[kLbPre + i] = win[seg_start + i]
+        s.cdat = (uint64_t*)(lds + L.cdat);
+        s.dec = (uint64_t*)(lds + L.dec);
+        s.idxL = (uint32_t*)(lds + L.idxL);
+        s.keyL = (uint32_t*)(lds + L.keyL);
+        s.kkL = (uint32_t*)(lds + L.kkL);  // kkL[i] = hash2(seg_start - 2 + i - 1)
+        s.ownord = (uint32_t*)(lds + L.ownord);
+        s.srcL = (uint32_t*)(lds + L.srcL);
+        s.basec = (uint32_t*)(lds + L.basec);
+        s.cq = (uint32_t*)(lds + L.cq);
+        s.wg = (uint16_t*)(lds + L.wg);
+        s.ctxL = lds + L.ctxL; s.ncand = lds + L.ncand; s.ownv = lds + L.ownv; s.ownml = lds + L.ownml;
+        s.ownE = lds + L.ownE; s.oldml = lds + L.oldml; s.oldE = lds + L.oldE; s.tyL = lds + L.tyL;
+        s.w0L = lds + L.w0L; s.lrL = lds + L.lrL; s.cnt = lds + L.cnt;
 
         const uint8_t* b = a.win;
         const uint32_t seg_start = kPre + sg * a.seg;
         const uint32_t seg_end = seg_start + a.seg < a.len ? seg_start + a.seg : a.len;
-        const uint32_t npos = seg_end - seg_start;          // item-start positions of the segment
-        const uint32_t nprobe = npos + 2;                   // + lazy probe positions
+        const uint32_t npos = seg_end - seg_start;  // item-start positions of the segment (<= 62)
+        const uint32_t nprobe = npos + 2;           // + lazy probe positions (<= 64 = one per lane)
         const uint32_t D = a.dmax;
+        const bool prof = a.prof && (w.block() & 63) == 5;
+        unsigned long long tk0 = prof ? w.clock() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
 
         // ---- phase 0: stage the segment's bytes, slots, old state and the ctx ordinals in LDS
-        for (uint32_t i = lane; i < kLbLen; i += 64) lb[i] = b[(int64_t)seg_start - kLbPre + i];
-        for (uint32_t x = lane; x < nprobe; x += 64) {
+        {
+            const uint8_t* src = b + (int64_t)seg_start - kLbPre;
+            for (uint32_t i = lane * 4; i < kLbLen; i += 256) {
+                uint32_t v = ldu32(src + i);
+                __builtin_memcpy(s.lb + i, &v, 4);
+            }
+            const uint32_t x = lane;
             const uint32_t pos = seg_start + x;
-            uint32_t j = pos < a.len ? a.idx[pos] : 0;
-            idxL[x] = j;
-            ncand[x] = 0;
+            uint32_t j = 0;
+            if (x < nprobe && pos < a.len) j = a.idx[pos];
+            uint32_t ks = 0;
+            const bool hasE = x < npos && pos >= kPre + 1;
+            if (hasE) ks = a.kidx[pos - 2];
+            for (uint32_t c = lane; c < 256; c += 64) {
+                s.basec[c] = a.base[(size_t)(sg % a.ring) * 256 + c];
+                s.cnt[c] = 0;
+            }
+            if (x < nprobe) {
+                s.idxL[x] = j;
+                s.ncand[x] = 0;
+                s.dec[x] = 0;
+            }
             if (x < npos) {
-                oldml[x] = a.sml[j];
-                uint32_t oe = 0;
-                if (pos >= kPre + 1) {
-                    uint32_t ks = a.kidx[pos - 2];
-                    oe = (uint32_t)((a.kbits[ks >> 6] >> (ks & 63)) & 1);
-                }
-                oldE[x] = (uint8_t)oe;
-                ownv[x] = 0; ownml[x] = 0; ownE[x] = 0;
+                s.oldml[x] = (uint8_t)a.srec[j].ml;
+                s.oldE[x] = hasE ? (uint8_t)((a.kbits[ks >> 6] >> (ks & 63)) & 1) : 0;
+                s.ownv[x] = 0; s.ownml[x] = 0; s.ownE[x] = 0;
             }
         }
-        for (uint32_t c = lane; c < 256; c += 64) {
-            basec[c] = a.base[(size_t)(sg % a.ring) * 256 + c];
-            cnt[c] = 0;
-        }
         w.sync();
-        for (uint32_t x = lane; x < nprobe; x += 64) {
-            const uint8_t* px = lb + kLbPre + x;
+        if (lane < nprobe) {
+            const uint32_t x = lane;
+            const uint8_t* px = s.lb + kLbPre + x;
             uint32_t c = (uint32_t)(px[-1] & 0x7f) | ((uint32_t)is_alnum(px[-2]) << 7);  // hash1(pos-1)
-            ctxL[x] = (uint8_t)c;
-            keyL[x] = c * kHash + hash_entry(px);
+            s.ctxL[x] = (uint8_t)c;
+            s.keyL[x] = c * kHash + hash_entry(px);
         }
         for (uint32_t i = lane; i < nprobe + 2; i += 64) {  // position u = seg_start - 2 + i: hash2(u - 1)
-            const uint8_t* pu = lb + kLbPre - 2 + i;
+            const uint8_t* pu = s.lb + kLbPre - 2 + i;
             uint32_t h1 = (uint32_t)(pu[-2] & 0x7f) | ((uint32_t)is_alnum(pu[-3]) << 7);
-            kkL[i] = (uint32_t)(pu[-1] & 0x7f) | (h1 << 7);
+            s.kkL[i] = (uint32_t)(pu[-1] & 0x7f) | (h1 << 7);
         }
         w.sync();
+        if (prof) tk1 = w.clock();
 
         // ---- phase 1: every position of the segment collects, on its own lane, the candidates that
         // older segments offer it: the most recent <= D ring members of its (ctx, hash) run, their
         // ordinals, expected lengths and common-prefix lengths; and the word predictor's answer.
-        for (uint32_t x = lane; x < nprobe; x += 64) {
-            const uint32_t pos = seg_start + x;
-            if (pos >= a.len) continue;
-            const uint32_t key = keyL[x];
-            uint32_t hi = idxL[x];
-            for (uint32_t y = 0; y < x; y++)
-                if (keyL[y] == key) { hi = idxL[y]; break; }  // slots >= hi belong to this segment
-            const uint32_t lo = a.runstart[key];
-            uint32_t found = 0;
-            uint32_t* mycq = cq + x * D;
-            if (hi > lo) {
-                uint32_t wi = (hi - 1) >> 6;
-                uint64_t word = a.vbits[wi];
-                if (hi & 63) word &= (1ull << (hi & 63)) - 1;
-                for (;;) {
-                    const uint32_t wlo = wi << 6;
-                    if (wlo < lo) word &= ~0ull << (lo - wlo);
-                    while (word && found < D) {
-                        int bit = 63 - clz64(word);
-                        mycq[found++] = wlo + (uint32_t)bit;
-                        word &= ~(1ull << bit);
-                    }
-                    if (found >= D || wlo <= lo) break;
-                    wi--;
-                    word = a.vbits[wi];
-                }
-            }
-            uint32_t* myco = co + x * D;
-            uint8_t* myml = cml + x * D;
-            uint8_t* mycl = cl + x * D;
-            const uint8_t* px = lb + kLbPre + x;
-            const uint64_t x0 = ldu64(px);
-            // eight candidates a round: all slot reads, then all first-8-byte compares, in flight together
-            for (uint32_t k0 = 0; k0 < found; k0 += 8) {
-                uint32_t sl[8], q[8], m[8], o[8];
-                uint64_t d0[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) sl[i] = mycq[k0 + i < found ? k0 + i : k0];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    q[i] = a.epos[sl[i]];
-                    m[i] = a.sml[sl[i]];
-                    o[i] = a.sord[sl[i]];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++) d0[i] = ldu64(b + q[i]) ^ x0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (k0 + i >= found) break;
-                    uint32_t l;
-                    if (d0[i]) l = (uint32_t)ctz64(d0[i]) >> 3;
-                    else l = 8 + lcp240u(b + q[i] + 8, px + 8, kMaxLen - 8);
-                    myco[k0 + i] = o[i];
-                    myml[k0 + i] = (uint8_t)m[i];
-                    mycq[k0 + i] = q[i];
-                    mycl[k0 + i] = m[i] == 255 ? 0 : (uint8_t)l;
-                }
-            }
-            ncand[x] = (uint8_t)found;
-            if (x < npos) {  // words[hash2(pos-1)] as older segments leave it
-                const uint32_t kk = kkL[x + 2];
-                uint32_t khi = a.kidx[pos];
-                for (uint32_t i = 0; i < x + 2; i++) {
-                    const uint32_t u = seg_start - 2 + i;
-                    if (u >= kPre - 1 && kkL[i] == kk) { khi = a.kidx[u]; break; }
-                }
-                const uint32_t klo = a.krun[kk];
-                uint32_t wv = (uint32_t)a.wsnap[kk * 2] | ((uint32_t)a.wsnap[kk * 2 + 1] << 8);
-                if (khi > klo) {
-                    uint32_t wi = (khi - 1) >> 6;
-                    uint64_t word = a.kbits[wi];
-                    if (khi & 63) word &= (1ull << (khi & 63)) - 1;
-                    for (;;) {
-                        const uint32_t wlo = wi << 6;
-                        if (wlo < klo) word &= ~0ull << (klo - wlo);
-                        if (word) {
-                            const uint32_t u = a.kpos[wlo + (uint32_t)(63 - clz64(word))];
-                            wv = (uint32_t)b[u] | ((uint32_t)b[u + 1] << 8);
-                            break;
-                        }
-                        if (wlo <= klo) break;
-                        wi--;
-                        word = a.kbits[wi];
-                    }
-                }
-                wg[x] = (uint16_t)wv;
+        // how many of this segment's earlier positions share my (ctx, hash) key / my words[] key:
+        // their slots sit right below mine in the run and are this sweep's business, not older segments'
+        uint32_t same = 0, samek = 0;
+        {
+            const uint32_t kmine = lane < nprobe ? s.keyL[lane] : 0xfffffffeu;
+            const uint32_t kkmine = s.kkL[lane];                      // key of entry u = seg_start - 2 + lane
+            const uint32_t kkq = lane + 2 < nprobe + 2 ? s.kkL[lane + 2] : 0xfffffffeu;  // my lookup key
+            for (uint32_t y = 0; y < 64; y++) {
+                const uint64_t both = w.bcast64((uint64_t)kmine | ((uint64_t)kkmine << 32), y);
+                const uint32_t ky = (uint32_t)both, kky = (uint32_t)(both >> 32);
+                same += (y < lane && ky == kmine) ? 1u : 0u;
+                samek += (y < lane + 2 && seg_start - 2 + y >= kPre - 1 && kky == kkq) ? 1u : 0u;
             }
         }
-        // ---- entry state: where the previous segment left the stream (look through skipped ones)
-        if (lane == 0) {
-            uint32_t p, lt;
-            if (sg == 0) {
-                p = kPre;
-                lt = a.lt0;
-            } else {
-                uint32_t v = a.exitst[sg];
-                for (uint32_t d = 1; d <= 4 && d < sg; d++) {
-                    uint32_t v2 = a.exitst[sg - d];
-                    if (v2 > v) v = v2;
+        if (lane < nprobe && seg_start + lane < a.len) {
+            const uint32_t x = lane;
+            const uint32_t pos = seg_start + x;
+            const uint32_t key = s.keyL[x];
+            // slots of this segment's own positions sit right below idx[x] in the run (same key, ascending
+            // position): they are this sweep's business, not the older segments'
+            const bool wantw = x < npos;
+            const uint32_t kk = s.kkL[x + 2];
+            const uint32_t hi = s.idxL[x] - same;
+            uint32_t* dbg = (uint32_t*)(lds + L.dbg) + lane * 8;
+            if (prof) dbg[0] = (uint32_t)(w.clock() - tk1);
+            const uint32_t khi = wantw ? a.kidx[pos] - samek : 0;
+            // first round trip: run starts and the first bitmap words of both lists
+            const uint32_t lo = a.runstart[key];
+            const uint32_t klo = wantw ? a.krun[kk] : 0;
+            uint64_t word = hi ? a.vbits[(hi - 1) >> 6] : 0;
+            uint64_t kword = (wantw && khi) ? a.kbits[(khi - 1) >> 6] : 0;
+            uint32_t wsn = wantw ? (uint32_t)a.wsnap[kk * 2] | ((uint32_t)a.wsnap[kk * 2 + 1] << 8) : 0;
+
+            uint32_t found = 0, nwords = 0;
+            uint32_t* mycq = s.cq + x * D;
+            if (prof) dbg[1] = (uint32_t)(w.clock() - tk1) + (uint32_t)(word & 0) + (uint32_t)(kword & 0) + (lo & 0) + (klo & 0) + (wsn & 0);
+            found = collect_slots(a.vbits, a.v1, a.v2, word, hi, lo, D, mycq, nwords);
+            if (prof) dbg[2] = (uint32_t)(w.clock() - tk1);
+            uint32_t kslot = 0xffffffffu;
+            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, khi, klo, 1, &kslot, nwords) == 0) kslot = 0xffffffffu;
+            if (prof) { dbg[3] = (uint32_t)(w.clock() - tk1); dbg[7] = nwords; }
+            // second round trip: the slot records (16 B each), sixteen in flight; third: their bytes
+            const uint32_t ku = kslot != 0xffffffffu ? a.kpos[kslot] : 0;
+            const uint8_t* px = s.lb + kLbPre + x;
+            const uint64_t x0 = ldu64(px);
+            uint64_t* mydat = s.cdat + x * D;
+            for (uint32_t k0 = 0; k0 < found; k0 += 16) {
+                SlotRec r[16];
+                uint32_t l[16];
+                uint32_t act = 0;  // candidates whose common prefix is still growing
+#pragma unroll
+                for (int i = 0; i < 16; i++) r[i] = ld_rec(&a.srec[mycq[k0 + i < found ? k0 + i : k0]]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint64_t d0 = ldu64(b + r[i].pos) ^ x0;
+                    if (d0) l[i] = (uint32_t)ctz64(d0) >> 3;
+                    else { l[i] = 8; if (k0 + i < found && r[i].ml != 255) act |= 1u << i; }
                 }
-                p = v >> 2;
-                lt = v & 3;
-                if (p < seg_end) ownE[p - seg_start] = (lt != kTyWord);
+                // the long ones advance together, one 16-byte step a round (loads of a round overlap)
+                while (act) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (act & (1u << i)) {
+                            const uint8_t* qa = b + r[i].pos + l[i];
+                            const uint8_t* pa = px + l[i];
+                            const uint64_t d0 = ldu64(qa) ^ ldu64(pa), d1 = ldu64(qa + 8) ^ ldu64(pa + 8);
+                            const uint64_t d2 = ldu64(qa + 16) ^ ldu64(pa + 16), d3 = ldu64(qa + 24) ^ ldu64(pa + 24);
+                            uint32_t adv = 32;
+                            if (d0) adv = (uint32_t)ctz64(d0) >> 3;
+                            else if (d1) adv = 8 + ((uint32_t)ctz64(d1) >> 3);
+                            else if (d2) adv = 16 + ((uint32_t)ctz64(d2) >> 3);
+                            else if (d3) adv = 24 + ((uint32_t)ctz64(d3) >> 3);
+                            l[i] += adv;
+                            if (adv < 32) act &= ~(1u << i);
+                            if (l[i] >= kMaxLen) { l[i] = kMaxLen; act &= ~(1u << i); }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (k0 + i < found) {
+                        const uint32_t ll = r[i].ml == 255 ? 0 : l[i];
+                        mycq[k0 + i] = r[i].pos;
+                        mydat[k0 + i] = (uint64_t)r[i].ord | ((uint64_t)ll << 32) | ((uint64_t)(r[i].ml & 0xff) << 40);
+                    }
+                }
             }
-            scal[0] = p; scal[1] = lt; scal[2] = 0;
+            if (prof) dbg[4] = (uint32_t)(w.clock() - tk1);
+            s.ncand[x] = (uint8_t)found;
+            if (wantw) {
+                if (kslot != 0xffffffffu) wsn = (uint32_t)b[ku] | ((uint32_t)b[ku + 1] << 8);
+                s.wg[x] = (uint16_t)wsn;
+            }
         }
         w.sync();
-
-        // ---- phase 2: the segment's items, one after another, with the reference's decision rules
-        for (;;) {
-            const uint32_t p = scal[0];
-            if (p >= seg_end) break;
-            const uint32_t x = p - seg_start;
-            // this sweep's own earlier items are the most recent candidates (and word updates)
-            const bool ownc = lane < x && ownv[lane];
-            const uint32_t kl = lane < npos ? keyL[lane] : 0xffffffffu;
-            const uint64_t m0 = w.ballot(ownc && kl == keyL[x]);
-            const uint64_t m1 = w.ballot(ownc && kl == keyL[x + 1]);
-            const uint64_t m2 = w.ballot(ownc && kl == keyL[x + 2]);
-            const uint64_t mE = w.ballot(lane <= x && lane < npos && ownE[lane] && kkL[lane] == kkL[x + 2]);
+        if (prof) {
+            tk2 = w.clock();
             if (lane == 0) {
-                const uint8_t* px = lb + kLbPre + x;
-                uint32_t lt = scal[1];
-                const uint32_t c = ctxL[x];
-                uint32_t w0, w1;
-                if (mE) {
-                    const uint32_t y = 63 - (uint32_t)clz64(mE);
-                    w0 = lb[kLbPre + y - 2];
-                    w1 = lb[kLbPre + y - 1];
-                } else {
-                    w0 = wg[x] & 0xff;
-                    w1 = wg[x] >> 8;
+                const uint32_t* dg = (const uint32_t*)(lds + L.dbg);
+                for (int k = 0; k < 5; k++) {
+                    uint32_t mx = 0;
+                    for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + k] > mx) mx = dg[i * 8 + k];
+                    atom_add64(&a.ctl->prof2[k], mx);
                 }
-                const uint32_t lwm = (px[0] == w0 && px[1] == w1);
-                // find_match, src/matcher.rs:135-192
-                const uint32_t hcnt = basec[c] + cnt[c];
-                uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0, cntv = 0;
-                bool stop = false;
-                for (uint64_t m = m0; m && !stop;) {
-                    const uint32_t y = 63 - (uint32_t)clz64(m);
-                    m &= ~(1ull << y);
-                    const uint32_t oq = ownord[y];
-                    if (hcnt - 1 - oq > kRing - 1 || cntv >= a.depth) { stop = true; break; }
-                    cntv++;
-                    const uint32_t l = lcp240u(lb + kLbPre + y, px);
-                    if (l > max_len) {
-                        mlexp = ownml[y]; max_len = l; bestq = seg_start + y; besto = oq;
-                        if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop = true;
-                    } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
-                        if (ldu32(lb + kLbPre + y + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
-                    }
-                }
-                const uint32_t nc = ncand[x];
-                for (uint32_t k = 0; k < nc && !stop; k++) {
-                    const uint32_t ml = cml[x * D + k];
-                    if (ml == 255) continue;
-                    const uint32_t oq = co[x * D + k];
-                    if (hcnt - 1 - oq > kRing - 1 || cntv >= a.depth) break;
-                    cntv++;
-                    const uint32_t l = cl[x * D + k];
-                    if (l > max_len) {
-                        mlexp = ml; max_len = l; bestq = cq[x * D + k]; besto = oq;
-                        if (l == kMaxLen || (mlexp > 0 && l > mlexp)) break;
-                    } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
-                        // the reference's 4-byte prefilter can pass by chance past the mismatch; it then
-                        // leaves the walk without a better match (src/matcher.rs:150-168)
-                        if (ldu32(b + cq[x * D + k] + max_len - 3) == ldu32(px + max_len - 3)) break;
-                    }
-                }
-                const bool is_match = max_len >= kMinLen && p + max_len < a.len;
-                uint32_t lazy = 0;
-                if (is_match && max_len < kMaxLen / 2) {  // src/lz.rs:151-170
-                    const uint32_t ro = hcnt - 1 - besto;
-                    const uint32_t l1 = max_len + 1 + (roid_bitlen(ro) < 8), l2 = l1 - lwm;
-                    if (has_lazy(lds, L, D, m1, x + 1, l1, a.lazy1)) lazy = 1;
-                    else if (has_lazy(lds, L, D, m2, x + 2, l2, a.lazy2)) lazy = 2;
-                }
-                // commit, src/lz.rs:172-234
-                ownv[x] = 1;
-                ownord[x] = hcnt;
-                lrL[x] = cnt[c];
-                cnt[c]++;
-                w0L[x] = (uint8_t)w0;
-                const uint8_t al = (lt == kTyLit) ? 4 : 0;
-                uint32_t np;
-                if (is_match && !lazy) {
-                    ownml[x] = (uint8_t)max_len; srcL[x] = bestq; tyL[x] = kTyMatch | al;
-                    np = p + max_len; lt = kTyMatch;
-                } else if (p + 1 < a.len && lazy != 1 && lwm) {
-                    ownml[x] = 0; tyL[x] = kTyWord | al;
-                    np = p + 2; lt = kTyWord;
-                } else {
-                    ownml[x] = 0; tyL[x] = kTyLit | al;
-                    np = p + 1; lt = kTyLit;
-                }
-                if (np < seg_end) ownE[np - seg_start] = (lt != kTyWord);
-                scal[0] = np; scal[1] = lt;
+                uint32_t mw = 0;
+                for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + 7] > mw) mw = dg[i * 8 + 7];
+                atom_add64(&a.ctl->prof2[7], mw);
             }
             w.sync();
         }
 
+        // ---- phase 2a: every position decides, on its own lane, what the item starting there would be
+        // if the segment's own earlier items do not interfere (no same-key item, no words[] update of
+        // its key, ring ordinals within kCntSlack of no threshold): kDecRobust marks those decisions.
+        if (lane < npos) s.dec[lane] = eval_item(s, b, seg_start, lane, 0, 0, 0, 2, true);
+        uint32_t p, lt;
+        if (sg == 0) {
+            p = kPre;
+            lt = a.lt0;
+        } else {  // where the previous segment left the stream (look through skipped segments)
+            uint32_t v = a.exitst[sg];
+            for (uint32_t d = 1; d <= 4 && d < sg; d++) {
+                uint32_t v2 = a.exitst[sg - d];
+                if (v2 > v) v = v2;
+            }
+            p = v >> 2;
+            lt = v & 3;
+        }
+        // each lane keeps its own position's flags in registers: item start / words[] update there
+        bool myv = false, myE = false;
+        if (sg != 0 && p < seg_end) {
+            if (lane == p - seg_start) myE = (lt != kTyWord);
+            if (lane == 0) s.ownE[p - seg_start] = (lt != kTyWord);
+        }
+        const uint32_t mykey = lane < npos ? s.keyL[lane] : 0xffffffffu;
+        const uint32_t mykk = lane < npos ? s.kkL[lane] : 0xffffffffu;
+        w.sync();
+        if (prof) tk3 = w.clock();
+
+        // ---- phase 2b: walk the items.  Robust decisions are taken as they are; the others are
+        // evaluated on the spot with this sweep's own items as the most recent candidates.
+        uint32_t nslow = 0;
+        while (p < seg_end) {
+            const uint32_t x = p - seg_start;
+            const bool older = lane < x && myv;
+            const uint64_t m0 = w.ballot(older && mykey == s.keyL[x]);
+            const uint64_t m1 = w.ballot(older && mykey == s.keyL[x + 1]);
+            const uint64_t m2 = w.ballot(older && mykey == s.keyL[x + 2]);
+            const uint64_t mE = w.ballot(lane <= x && myE && mykk == s.kkL[x + 2]);
+            const uint8_t* px = s.lb + kLbPre + x;
+            uint32_t w0, w1;
+            if (mE) {  // words[hash2(p-1)] was last written by this segment: at position e = seg_start + y
+                const uint32_t y = 63 - (uint32_t)clz64(mE);
+                w0 = s.lb[kLbPre + y - 2];
+                w1 = s.lb[kLbPre + y - 1];
+            } else {
+                w0 = s.wg[x] & 0xff;
+                w1 = s.wg[x] >> 8;
+            }
+            const uint32_t lwm = (px[0] == w0 && px[1] == w1);
+            uint64_t d = s.dec[x];
+#ifdef ORZ_FORCE_SLOW
+            if (true) {
+#else
+            if (!(d & kDecRobust) || (m0 | m1 | m2)) {
+#endif
+                if (lane == 0) s.dec[x] = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
+                w.sync();
+                d = s.dec[x];
+                nslow++;
+            }
+#ifdef ORZ_DEBUG_ROBUST
+            else if (lane == 0) {
+                uint64_t d2 = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
+                const uint32_t lz1 = (d & kDecLazy1) ? 1 : ((d & (lwm ? kDecLazy2b : kDecLazy2a)) ? 2 : 0);
+                const uint32_t lz2 = (d2 & kDecLazy1) ? 1 : ((d2 & kDecLazy2a) ? 2 : 0);
+                if ((d & 0x3ffffffffull) != (d2 & 0x3ffffffffull) || lz1 != lz2)
+                {
+                    fprintf(stderr, "ROBUST MISMATCH sg=%u p=%u x=%u lwm=%u d=%llx d2=%llx lz %u %u cnt=%u basec=%u nc=%u m0=%llx\n", sg, p, x, lwm,
+                            (unsigned long long)d, (unsigned long long)d2, lz1, lz2, (unsigned)s.cnt[s.ctxL[x]], s.basec[s.ctxL[x]], (unsigned)s.ncand[x], (unsigned long long)m0);
+                    for (uint32_t k = 0; k < s.ncand[x]; k++) fprintf(stderr, "   cand %u q=%u ord=%u l=%u ml=%u\n", k, s.cq[x * a.dmax + k], (uint32_t)s.cdat[x * a.dmax + k], (uint32_t)(s.cdat[x * a.dmax + k] >> 32) & 0xff, (uint32_t)(s.cdat[x * a.dmax + k] >> 40) & 0xff);
+                    uint64_t d3 = eval_item(s, b, seg_start, x, 0, 0, 0, 2, true);
+                    fprintf(stderr, "   re-eval check now: %llx\n", (unsigned long long)d3);
+                }
+            }
+#endif
+            const bool is_match = (d & kDecMatch) != 0;
+            const uint32_t max_len = dec_len(d);
+            const uint32_t lazy = (d & kDecLazy1) ? 1 : ((d & (lwm ? kDecLazy2b : kDecLazy2a)) ? 2 : 0);
+            // commit, src/lz.rs:172-234
+            const uint32_t c = s.ctxL[x];
+            const uint32_t cc = s.cnt[c];
+            const uint8_t al = (lt == kTyLit) ? 4 : 0;
+            uint32_t np, ty, ml = 0;
+            if (is_match && !lazy) {
+                ty = kTyMatch; ml = max_len; np = p + max_len;
+            } else if (p + 1 < a.len && lazy != 1 && lwm) {
+                ty = kTyWord; np = p + 2;
+            } else {
+                ty = kTyLit; np = p + 1;
+            }
+            if (lane == 0) {
+                s.ownv[x] = 1;
+                s.ownord[x] = s.basec[c] + cc;
+                s.lrL[x] = (uint8_t)cc;
+                s.cnt[c] = (uint8_t)(cc + 1);
+                s.w0L[x] = (uint8_t)w0;
+                s.tyL[x] = (uint8_t)(ty | al);
+                s.ownml[x] = (uint8_t)ml;
+                s.srcL[x] = dec_src(d);
+                if (np < seg_end) s.ownE[np - seg_start] = (ty != kTyWord);
+            }
+            if (lane == x) myv = true;
+            if (np < seg_end && lane == np - seg_start) myE = (ty != kTyWord);
+#ifdef ORZ_DEBUG_ROBUST
+            if (sg == 233) fprintf(stderr, "   lane %u x=%u d=%llx lwm=%u lazy=%u np=%u mE=%llx w=%u,%u\n", lane, x, (unsigned long long)d, lwm, lazy, np, (unsigned long long)mE, w0, w1);
+#endif
+            p = np;
+            lt = ty;
+            w.sync();
+        }
+        if (prof) tk4 = w.clock();
+
         // ---- phase 3: publish what changed, the per-ctx item counts and the exit state
         bool changed = false;
-        for (uint32_t x = lane; x < npos; x += 64) {
+        if (lane < npos) {
+            const uint32_t x = lane;
             const uint32_t pos = seg_start + x;
-            const uint32_t j = idxL[x];
-            const uint32_t nm = ownv[x] ? ownml[x] : 255u;
-            const uint32_t om = oldml[x];
+            const uint32_t j = s.idxL[x];
+            const uint32_t nm = s.ownv[x] ? s.ownml[x] : 255u;
+            const uint32_t om = s.oldml[x];
             if (nm != om) {
-                a.sml[j] = (uint8_t)nm;
+                a.srec[j].ml = nm;
                 if ((nm == 255) != (om == 255)) {
-                    if (nm == 255) atom_and64(&a.vbits[j >> 6], ~(1ull << (j & 63)));
-                    else atom_or64(&a.vbits[j >> 6], 1ull << (j & 63));
+                    if (nm == 255) slot_clear(a.vbits, a.v1, j);
+                    else slot_set(a.vbits, a.v1, a.v2, j);
                 }
                 changed = true;
             }
-            if (ownv[x]) {
-                a.TY[pos] = tyL[x];
-                a.W0[pos] = w0L[x];
-                a.LR[pos] = lrL[x];
-                if ((tyL[x] & 3) == kTyMatch) a.SRC[pos] = srcL[x];
+            if (s.ownv[x]) {
+                a.TY[pos] = s.tyL[x];
+                a.W0[pos] = s.w0L[x];
+                a.LR[pos] = s.lrL[x];
+                if ((s.tyL[x] & 3) == kTyMatch) a.SRC[pos] = s.srcL[x];
             }
-            if (pos >= kPre + 1 && ownE[x] != oldE[x]) {
+            if (pos >= kPre + 1 && s.ownE[x] != s.oldE[x]) {
                 const uint32_t ks = a.kidx[pos - 2];
-                if (ownE[x]) atom_or64(&a.kbits[ks >> 6], 1ull << (ks & 63));
-                else atom_and64(&a.kbits[ks >> 6], ~(1ull << (ks & 63)));
+                if (s.ownE[x]) slot_set(a.kbits, a.k1, a.k2, ks);
+                else slot_clear(a.kbits, a.k1, ks);
                 changed = true;
             }
         }
         {
             uint32_t* part = a.partial + ((size_t)a.par * (a.wsegs / kRankChunk + 1) + w.block() / kRankChunk) * 256;
             for (uint32_t c = lane; c < 256; c += 64) {
-                a.hist[(size_t)(sg % a.ring) * 256 + c] = cnt[c];
-                if (cnt[c]) atom_add32(&part[c], cnt[c]);
+                const uint32_t v = s.cnt[c];
+                a.hist[(size_t)(sg % a.ring) * 256 + c] = (uint8_t)v;
+                if (v) atom_add32(&part[c], v);
             }
         }
         if (lane == 0) {
-            const uint32_t v = (scal[0] << 2) | scal[1];
+            const uint32_t v = (p << 2) | lt;
             if (a.exitst[sg + 1] != v) {
                 a.exitst[sg + 1] = v;
                 changed = true;
             }
             atom_add32(&a.ctl->evals, 1);
+            if (nslow) atom_add32(&a.ctl->slow, nslow);
         }
+#ifdef ORZ_DEBUG_ROBUST
+        if (sg >= 232 && sg <= 234) {
+            uint64_t chm = w.ballot(changed);
+            if (lane == 0) {
+                fprintf(stderr, "EVAL sg=%u front=%u par=%u exit p=%u lt=%u changed=%llx items:", sg, front, a.par, p, lt, (unsigned long long)chm);
+                for (uint32_t x = 0; x < npos; x++) if (s.ownv[x]) fprintf(stderr, " %u:%u(old %u)", x, s.ownml[x], s.oldml[x]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (w.ballot(changed) && lane == 0) atom_min32(&a.ctl->fchg[a.par], sg);
+        if (prof && lane == 0) {
+            const unsigned long long tk5 = w.clock();
+            atom_add64(&a.ctl->prof[0], tk1 - tk0);
+            atom_add64(&a.ctl->prof[1], tk2 - tk1);
+            atom_add64(&a.ctl->prof[2], tk3 - tk2);
+            atom_add64(&a.ctl->prof[3], tk4 - tk3);
+            atom_add64(&a.ctl->prof[4], tk5 - tk4);
+            atom_add32(&a.ctl->nprof, 1);
+        }
+    }
+
+    // What the item starting at segment position x is (src/lz.rs:131-235 for one spos):
+    // find_match over this sweep's own items (masks m0/m1/m2, newest first) and then the list
+    // collected in phase 1, followed by the two lazy probes.  `lwm`: 0/1 = last_word_matched is
+    // known; 2 = unknown, both lazy2 variants are computed.  With `check` the decision also reports
+    // whether it stays the same for every own-item count in [0, kCntSlack] (kDecRobust).
+    ORZ_D uint64_t eval_item(const Sh& s, const uint8_t* b, uint32_t seg_start, uint32_t x, uint64_t m0, uint64_t m1,
+                             uint64_t m2, uint32_t lwm, bool check) const {
+        const uint32_t D = a.dmax;
+        const uint8_t* px = s.lb + kLbPre + x;
+        const uint32_t p = seg_start + x;
+        const uint32_t c = s.ctxL[x];
+        const uint32_t hcnt = s.basec[c] + s.cnt[c];
+        bool robust = true;
+        // find_match, src/matcher.rs:135-192
+        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0, cntv = 0;
+        bool stop = false;
+        for (uint64_t m = m0; m && !stop;) {
+            const uint32_t y = 63 - (uint32_t)clz64(m);
+            m &= ~(1ull << y);
+            const uint32_t oq = s.ownord[y];
+            if (hcnt - 1 - oq > kRing - 1 || cntv >= a.depth) { stop = true; break; }
+            cntv++;
+            const uint32_t l = lcp240u(s.lb + kLbPre + y, px);
+            if (l > max_len) {
+                mlexp = s.ownml[y]; max_len = l; bestq = seg_start + y; besto = oq;
+                if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop = true;
+            } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
+                if (ldu32(s.lb + kLbPre + y + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
+            }
+        }
+        const uint32_t nc = s.ncand[x];
+        const uint64_t* dat = s.cdat + x * D;
+        for (uint32_t k0 = 0; k0 < nc && !stop; k0 += 16) {
+            uint64_t cdv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint64_t cd = cdv[i];
+                const uint32_t ml = (uint32_t)(cd >> 40) & 0xff;
+                if (stop || ml == 255) continue;
+                const uint32_t oq = (uint32_t)cd;
+                const uint32_t ro = hcnt - 1 - oq;
+                if (check && ro <= kRing - 1 && ro + kCntSlack > kRing - 1) robust = false;
+                if (ro > kRing - 1 || cntv >= a.depth) { stop = true; continue; }
+                cntv++;
+                const uint32_t l = (uint32_t)(cd >> 32) & 0xff;
+                if (l > max_len) {
+                    mlexp = ml; max_len = l; bestq = s.cq[x * D + k0 + i]; besto = oq;
+                    if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop = true;
+                } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
+                    // the reference's 4-byte prefilter can pass by chance past the mismatch; it then
+                    // leaves the walk without a better match (src/matcher.rs:150-168)
+                    if (ldu32(b + s.cq[x * D + k0 + i] + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
+                }
+            }
+        }
+        const bool is_match = max_len >= kMinLen && p + max_len < a.len;
+        uint64_t d = (uint64_t)bestq | ((uint64_t)max_len << 25);
+        if (is_match) d |= kDecMatch;
+        if (is_match && max_len < kMaxLen / 2) {  // src/lz.rs:151-170
+            const uint32_t ro = hcnt - 1 - besto;
+            if (check && (roid_bitlen(ro) < 8) != (roid_bitlen(ro + kCntSlack) < 8)) robust = false;
+            const uint32_t l1 = max_len + 1 + (roid_bitlen(ro) < 8);
+            if (has_lazy(s, m1, x + 1, l1, a.lazy1, check, robust)) {
+                d |= kDecLazy1;
+            } else if (lwm == 2) {
+                if (has_lazy(s, m2, x + 2, l1, a.lazy2, check, robust)) d |= kDecLazy2a | kDecLazy2b;
+                else if (has_lazy(s, m2, x + 2, l1 - 1, a.lazy2, check, robust)) d |= kDecLazy2b;
+            } else if (has_lazy(s, m2, x + 2, l1 - lwm, a.lazy2, check, robust)) {
+                d |= kDecLazy2a | kDecLazy2b;
+            }
+        }
+        if (robust && check) d |= kDecRobust;  // an on-the-spot evaluation is never reused as a robust one
+        return d;
     }
 
     // has_lazy_match (src/matcher.rs:194-228) for probe position xx in {x+1, x+2}: candidates are the
     // ring members inserted before p, newest first: this sweep's own items (mask), then the older
     // segments' list collected in phase 1.
-    ORZ_D static bool has_lazy(uint8_t* lds, const ParseLds& L, uint32_t D, uint64_t mown, uint32_t xx, uint32_t min_len,
-                               uint32_t depth) {
-        const uint8_t* lb = lds + L.lb;
-        const uint32_t* ownord = (const uint32_t*)(lds + L.ownord);
-        const uint32_t* basec = (const uint32_t*)(lds + L.basec);
-        const uint8_t* cnt = lds + L.cnt;
-        const uint8_t* ctxL = lds + L.ctxL;
-        const uint32_t cx = ctxL[xx];
-        const uint32_t hx = basec[cx] + cnt[cx];
+    ORZ_D bool has_lazy(const Sh& s, uint64_t mown, uint32_t xx, uint32_t min_len, uint32_t depth, bool check,
+                        bool& robust) const {
+        const uint32_t D = a.dmax;
+        const uint32_t cx = s.ctxL[xx];
+        const uint32_t hx = s.basec[cx] + s.cnt[cx];
         uint32_t cntv = 0;
         for (uint64_t m = mown; m;) {
             const uint32_t y = 63 - (uint32_t)clz64(m);
             m &= ~(1ull << y);
-            if (hx - 1 - ownord[y] > kRing - 1 || cntv >= depth) return false;
+            if (hx - 1 - s.ownord[y] > kRing - 1 || cntv >= depth) return false;
             cntv++;
-            if (lcp240u(lb + kLbPre + y, lb + kLbPre + xx) >= min_len) return true;
+            if (lcp240u(s.lb + kLbPre + y, s.lb + kLbPre + xx) >= min_len) return true;
         }
-        const uint32_t* co = (const uint32_t*)(lds + L.co);
-        const uint8_t* cml = lds + L.cml;
-        const uint8_t* cl = lds + L.cl;
-        const uint32_t nc = (lds + L.ncand)[xx];
-        for (uint32_t k = 0; k < nc; k++) {
-            if (cml[xx * D + k] == 255) continue;
-            if (hx - 1 - co[xx * D + k] > kRing - 1 || cntv >= depth) return false;
-            cntv++;
-            if (cl[xx * D + k] >= min_len) return true;
+        const uint64_t* dat = s.cdat + xx * D;
+        const uint32_t nc = s.ncand[xx];
+        for (uint32_t k0 = 0; k0 < nc; k0 += 16) {
+            uint64_t cdv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+            int res = -1;  // -1 undecided, 0 false, 1 true
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint64_t cd = cdv[i];
+                if (res >= 0 || ((uint32_t)(cd >> 40) & 0xff) == 255) continue;
+                const uint32_t ro = hx - 1 - (uint32_t)cd;
+                if (check && ro <= kRing - 1 && ro + kCntSlack > kRing - 1) robust = false;
+                if (ro > kRing - 1 || cntv >= depth) { res = 0; continue; }
+                cntv++;
+                if (((uint32_t)(cd >> 32) & 0xff) >= min_len) res = 1;
+            }
+            if (res >= 0) return res == 1;
         }
         return false;
     }
@@ -516,7 +778,7 @@ struct ParseWave {
 // kRankChunk segments of the window:
 //   off[c]       = base[front][c] + sum of the partial[chunk' < chunk][c] that ParseWave accumulated
 //   base[s+1][c] = base[s][c] + hist[s][c] over the chunk's segments            (ring of R rows)
-//   sord         = base[seg][ctx] + LR for every current item of the chunk      (what RankApply was)
+//   srec.ord     = base[seg][ctx] + LR for every current item of the chunk
 // Block 0 also moves the front to just past the first changed segment and re-arms the other parity.
 struct RankArgs {
     const uint8_t* win;
@@ -525,9 +787,8 @@ struct RankArgs {
     uint32_t* base;
     uint32_t* partial;
     const uint32_t* idx;
-    const uint8_t* sml;
+    SlotRec* srec;
     const uint8_t* LR;
-    uint32_t* sord;
     uint32_t nseg, seg, wsegs, ring, len, par;
 };
 // `rows` = LDS [kRankChunk + 1][256] u32 ; sync() = block barrier ; c = thread id (0..255)
@@ -538,15 +799,21 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
     const uint32_t nchunk = a.wsegs / kRankChunk + 1;
     const uint32_t s0 = f + chunk * kRankChunk;
     const uint32_t s1 = s0 + kRankChunk < wend ? s0 + kRankChunk : wend;
-    uint32_t* part = a.partial + (size_t)a.par * nchunk * 256;
+    const uint32_t* part = a.partial + (size_t)a.par * nchunk * 256;
     if (s0 < wend) {
         uint32_t run = a.base[(size_t)(f % a.ring) * 256 + c];
         for (uint32_t i = 0; i < chunk; i++) run += part[i * 256 + c];
+        uint32_t h[kRankChunk];
+#pragma unroll
+        for (uint32_t i = 0; i < kRankChunk; i++) h[i] = s0 + i < s1 ? a.hist[(size_t)((s0 + i) % a.ring) * 256 + c] : 0;
         rows[c] = run;
-        for (uint32_t s = s0; s < s1; s++) {
-            run += a.hist[(size_t)(s % a.ring) * 256 + c];
-            rows[(s - s0 + 1) * 256 + c] = run;
-            a.base[(size_t)((s + 1) % a.ring) * 256 + c] = run;
+#pragma unroll
+        for (uint32_t i = 0; i < kRankChunk; i++) {
+            if (s0 + i < s1) {
+                run += h[i];
+                rows[(i + 1) * 256 + c] = run;
+                a.base[(size_t)((s0 + i + 1) % a.ring) * 256 + c] = run;
+            }
         }
     }
     sync();
@@ -557,7 +824,7 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
             const uint32_t x = x0 + i;
             if (x >= a.len) break;
             const uint32_t j = a.idx[x];
-            if (a.sml[j] != 255) a.sord[j] = rows[(i / a.seg) * 256 + hash1(a.win, x - 1)] + a.LR[x];
+            if (a.srec[j].ml != 255) a.srec[j].ord = rows[(i / a.seg) * 256 + hash1(a.win, x - 1)] + a.LR[x];
         }
     }
     // re-arm the other parity's accumulators for the next sweep (nobody reads them in this launch)

@@ -111,23 +111,16 @@ struct SlotInit {  // history slots carry their final item state, new slots star
     uint32_t n;
     const uint8_t* ML;
     const uint32_t* ORD;
-    uint8_t* sml;
-    uint32_t* sord;
-    uint64_t* vbits;  // zeroed
+    SlotRec* srec;
+    uint64_t *vbits, *v1, *v2;  // zeroed
     ORZ_HD void operator()(size_t tid) const {
         if (tid >= n) return;
         uint32_t x = epos[tid];
         if (x < kPre) {
-            sml[tid] = ML[x];
-            sord[tid] = ORD[x];
-#if defined(__HIP_DEVICE_COMPILE__)
-            atomicOr((unsigned long long*)&vbits[tid >> 6], 1ull << (tid & 63));
-#else
-            vbits[tid >> 6] |= 1ull << (tid & 63);
-#endif
+            srec[tid] = SlotRec{x, ORD[x], ML[x], 0};
+            slot_set(vbits, v1, v2, (uint32_t)tid);
         } else {
-            sml[tid] = 255;
-            sord[tid] = 0;
+            srec[tid] = SlotRec{x, 0, 255, 0};
         }
     }
 };
@@ -145,13 +138,15 @@ struct ParseCtlInit {
         ctl->front[0] = 0; ctl->front[1] = 0;
         ctl->fchg[0] = kNoChange; ctl->fchg[1] = kNoChange;
         ctl->evals = 0;
+        ctl->nprof = 0;
+        ctl->slow = 0;
+        for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; }
     }
 };
 struct FinalizeBlock {  // slot state -> per-position arrays of the new region
     const uint32_t* idx;
     const uint32_t* kidx;
-    const uint8_t* sml;
-    const uint32_t* sord;
+    const SlotRec* srec;
     const uint64_t* kbits;
     uint32_t len;
     uint8_t *S, *ML, *E;
@@ -160,10 +155,10 @@ struct FinalizeBlock {  // slot state -> per-position arrays of the new region
         uint32_t x = kPre + (uint32_t)tid;
         if (x >= len) return;
         uint32_t j = idx[x];
-        uint32_t m = sml[j];
+        uint32_t m = srec[j].ml;
         S[x] = m != 255;
         ML[x] = m == 255 ? 0 : (uint8_t)m;
-        ORD[x] = sord[j];
+        ORD[x] = srec[j].ord;
         uint32_t e = 0;
         if (x >= kPre + 1) {
             uint32_t ks = kidx[x - 2];
@@ -193,9 +188,9 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
 
-    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 4096)
+    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 2048)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs) {
-        if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 64]");
+        if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
         dmax_ = (uint32_t)std::max(cfg.depth, std::max(cfg.lazy1, cfg.lazy2));
         if (cfg.depth < 1 || dmax_ > 200) throw std::runtime_error("LZCfg depth out of range");
@@ -223,9 +218,12 @@ class StreamEncoder {
         runstart_ = be_.template alloc<uint32_t>(kNumKeys + 1);
         krun_ = be_.template alloc<uint32_t>(32768 + 1);
         vbits_ = be_.template alloc<uint64_t>(kWLen / 64 + 2);
+        v1_ = be_.template alloc<uint64_t>(kWLen / 4096 + 2);
+        v2_ = be_.template alloc<uint64_t>(kWLen / 262144 + 2);
         kbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 2);
-        sml_ = be_.template alloc<uint8_t>(kWLen);
-        sord_ = be_.template alloc<uint32_t>(kWLen);
+        k1_ = be_.template alloc<uint64_t>(kNewMax / 4096 + 2);
+        k2_ = be_.template alloc<uint64_t>(kNewMax / 262144 + 2);
+        srec_ = be_.template alloc<SlotRec>(kWLen);
         exitst_ = be_.template alloc<uint32_t>((size_t)nseg_max_ + 2);
         hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
         base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
@@ -268,7 +266,7 @@ class StreamEncoder {
     }
     ~StreamEncoder() {
         void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, epos_,
-                        kpos_, runstart_, krun_, vbits_, kbits_, sml_, sord_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
+                        kpos_, runstart_, krun_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_};
@@ -330,8 +328,12 @@ class StreamEncoder {
         be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
         be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_});
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 1) * 8);
+        be_.memset(v1_, 0, ((size_t)kWLen / 4096 + 2) * 8);
+        be_.memset(v2_, 0, ((size_t)kWLen / 262144 + 2) * 8);
         be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
-        be_.launch(nent, SlotInit{epos_, nent, ML_, ORD_, sml_, sord_, vbits_});
+        be_.memset(k1_, 0, ((size_t)kNewMax / 4096 + 2) * 8);
+        be_.memset(k2_, 0, ((size_t)kNewMax / 262144 + 2) * 8);
+        be_.launch(nent, SlotInit{epos_, nent, ML_, ORD_, srec_, vbits_, v1_, v2_});
         be_.launch((size_t)nseg + 1, FillExit{exitst_, nseg, seg_});
         be_.memset(hist_, 0, (size_t)ring_ * 256);
         be_.d2d(base_, ctxcount_, 256 * 4);
@@ -346,9 +348,9 @@ class StreamEncoder {
         ParseArgs pa;
         pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
         pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
-        pa.lt0 = lt_carry_; pa.par = 0;
-        pa.epos = epos_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
-        pa.wsnap = wsnap_; pa.vbits = vbits_; pa.sml = sml_; pa.sord = sord_; pa.kbits = kbits_; pa.exitst = exitst_;
+        pa.lt0 = lt_carry_; pa.par = 0; pa.prof = getenv("ORZ_PROF") ? 1 : 0;
+        pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
+        pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
         const size_t lds_bytes = ParseLds::make(dmax_).total;
         const uint32_t grid = std::min(wsegs_, nseg);
@@ -360,7 +362,7 @@ class StreamEncoder {
                 be_.timed_begin();
                 be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
                 be_.timed_end();
-                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, sml_, LR_, sord_, nseg, seg_, wsegs_, ring_, len, par},
+                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, par},
                          wsegs_ / kRankChunk + 1);
                 par ^= 1;
                 sweeps++;
@@ -381,12 +383,37 @@ class StreamEncoder {
             ParseCtl h;
             be_.d2h(&h, ctl_, sizeof h);
             stats.seg_evals += h.evals;
+            if (getenv("ORZ_PROF") && h.nprof)
+                fprintf(stderr, "parse phases (avg shader cycles / sampled wave, %u waves): load %llu  candidates %llu  decide %llu  walk %llu  publish %llu ; slow items %u ; phase-1 slowest-lane stamps: own-count %llu  first-loads %llu  slot-walk %llu  word-walk %llu  records+lcp %llu ; max-lane bitmap words %llu\n",
+                        h.nprof, h.prof[0] / h.nprof, h.prof[1] / h.nprof, h.prof[2] / h.nprof, h.prof[3] / h.nprof, h.prof[4] / h.nprof, h.slow, h.prof2[0] / h.nprof, h.prof2[1] / h.nprof, h.prof2[2] / h.nprof, h.prof2[3] / h.nprof, h.prof2[4] / h.nprof, h.prof2[7] / h.nprof);
         }
         stats.sweeps += sweeps;
-        be_.launch(n, FinalizeBlock{idx_, kidx_, sml_, sord_, kbits_, len, S_, ML_, E_, ORD_});
+        be_.launch(n, FinalizeBlock{idx_, kidx_, srec_, kbits_, len, S_, ML_, E_, ORD_});
         be_.sync();
         double t2 = be_.now();
         stats.t_parse += t2 - t1;
+#ifdef ORZ_DEBUG_ROBUST
+        {   // consistency of the final ring ordinals: ORD[x] == number of earlier items of the same ctx
+            std::vector<uint8_t> hS(len), hw(len + 8);
+            std::vector<uint32_t> hO(len), cnt(256, 0), hb(256);
+            be_.d2h(hS.data(), S_, len); be_.d2h(hO.data(), ORD_, (size_t)len * 4); be_.d2h(hw.data(), win, len);
+            be_.d2h(cnt.data(), ctxcount_, 256 * 4);
+            int bad = 0;
+            for (uint32_t x = kPre; x < len; x++) if (hS[x]) {
+                uint32_t c = (hw[x - 1] & 0x7f) | ((uint32_t)is_alnum(hw[x - 2]) << 7);
+                if (hO[x] != cnt[c] && bad++ < 10) fprintf(stderr, "ORD mismatch x=%u seg=%u ctx=%u ord=%u want=%u\n", x, (x - kPre) / seg_, c, hO[x], cnt[c]);
+                cnt[c]++;
+            }
+            fprintf(stderr, "ORD check: %d bad\n", bad);
+            if (const char* dp = getenv("ORZ_DUMP_ITEMS")) {
+                std::vector<uint8_t> hT(len), hM(len); std::vector<uint32_t> hR(len);
+                be_.d2h(hT.data(), TY_, len); be_.d2h(hM.data(), ML_, len); be_.d2h(hR.data(), SRC_, (size_t)len * 4);
+                FILE* f = fopen(dp, "w");
+                for (uint32_t x = kPre; x < len; x++) if (hS[x]) fprintf(f, "%u ty=%u ml=%u src=%u ord=%u\n", x, hT[x] & 3, hM[x], (hT[x] & 3) == 2 ? hR[x] : 0, hO[x]);
+                fclose(f);
+            }
+        }
+#endif
 
         // ---- items
         be_.launch(n, Flags32{S_, n, f32_});
@@ -508,9 +535,8 @@ class StreamEncoder {
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
     uint32_t *ORD_, *SRC_;
     uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_;
-    uint64_t *entA_, *entB_, *vbits_, *kbits_;
-    uint8_t* sml_;
-    uint32_t* sord_;
+    uint64_t *entA_, *entB_, *vbits_, *v1_, *v2_, *kbits_, *k1_, *k2_;
+    SlotRec* srec_;
     uint32_t* exitst_;
     uint8_t* hist_;
     uint32_t* base_;

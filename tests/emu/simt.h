@@ -12,6 +12,7 @@
 #endif
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -115,7 +116,12 @@ struct WaveCtx {
         uint32_t g = deposit(v);
         return w->tag[g & 1][src] == g ? (uint32_t)w->val[g & 1][src] : 0;
     }
+    uint64_t bcast64(uint64_t v, uint32_t src) {
+        uint32_t g = deposit(v);
+        return w->tag[g & 1][src] == g ? w->val[g & 1][src] : 0;
+    }
     void sync() { deposit(0); }
+    unsigned long long clock() const { return 0; }
 };
 
 enum Order { kAscending = 0, kDescending = 1, kShuffled = 2 };
@@ -175,6 +181,19 @@ void launch_waves(size_t nblocks, const K& k, size_t lds_bytes, Order order = kA
                 w->cur = i;
                 orz_simt_switch(&w->sched_sp, l.sp);
                 if (!l.done) live = true;
+            }
+            // every lane still alive must be parked in the SAME collective: wave collectives under
+            // divergent control flow would deadlock or mis-pair on real hardware
+            uint32_t g = 0;
+            bool have = false;
+            for (int i = 0; i < kLanes; i++) {
+                if (w->lanes[i].done) continue;
+                if (!have) { g = w->lanes[i].gen; have = true; }
+                else if (w->lanes[i].gen != g) {
+                    std::fprintf(stderr, "simt: divergent wave collective in block %u (lane %d at %u, expected %u)\n",
+                                 w->block, i, w->lanes[i].gen, g);
+                    std::abort();
+                }
             }
         }
     }

@@ -32,7 +32,7 @@ def test_sweep_order_does_not_matter(emu, oracle, order):
     assert out == oracle.encode(data, 1)
 
 
-@pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (64, 128), (8, 4096)])
+@pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (33, 128), (8, 4096)])
 def test_segment_and_window_sizes(emu, oracle, seg, win):
     data = _data.mixed(50_000, seed=seg)
     out, _ = emu(data, seg=seg, win=win)

@@ -30,21 +30,21 @@ def test_golden_streams(gpu_encoder_factory, path):
 @pytest.mark.parametrize("level", [0, 1, 2])
 @pytest.mark.parametrize("maker", ["text", "mixed", "zeros", "random", "p1", "p3"])
 def test_shapes_bit_exact(gpu_encoder_factory, oracle, maker, level):
-    n = 1_500_000
+    n = 600_000
     data = {"text": lambda: _data.text(n), "mixed": lambda: _data.mixed(n), "zeros": lambda: _data.zeros_noise(n),
             "random": lambda: _data.random_bytes(n), "p1": lambda: _data.periodic(n, 1), "p3": lambda: _data.periodic(n, 3)}[maker]()
     assert gpu_encoder_factory(level).encode(data) == oracle.encode(data, level)
 
 
-@pytest.mark.parametrize("seg,win", [(62, 512), (62, 16384), (32, 2048), (64, 4096), (17, 1000)])
+@pytest.mark.parametrize("seg,win", [(62, 512), (62, 8192), (32, 2048), (17, 1000)])
 def test_tuning_does_not_change_the_stream(gpu_encoder_factory, oracle, seg, win):
-    data = _data.mixed(3_000_000, seed=31)
+    data = _data.mixed(1_000_000, seed=31)
     enc = gpu_encoder_factory(1)
     enc.set_tuning(seg, win)
     try:
         assert enc.encode(data) == oracle.encode(data, 1)
     finally:
-        enc.set_tuning(62, 4096)
+        enc.set_tuning(62, 2048)
 
 
 def test_more_than_one_chunk_per_block(gpu_encoder_factory, oracle):
@@ -56,7 +56,7 @@ def test_more_than_one_chunk_per_block(gpu_encoder_factory, oracle):
 
 def test_block_slide_and_short_final_block(gpu_encoder_factory, oracle):
     # two full 16 MiB blocks + a short one: window slide, ring rebasing, tail-key hazard, stale tail bytes
-    data = _data.mixed(2 * 16_777_216 + 1_234_567, seed=41)
+    data = _data.mixed(2 * 16_777_216 + 234_567, seed=41)
     out, st = gpu_encoder_factory(1).encode(data, stats=True)
     assert st["blocks"] == 3
     assert out == oracle.encode(data, 1)
