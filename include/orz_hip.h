@@ -69,6 +69,21 @@ typedef void (*orz_progress_fn)(void* ctx, int is_finish, size_t in_bytes, size_
 int orz_encode(orz_read_fn, void* rctx, orz_write_fn, void* wctx, const orz_lzcfg*, orz_progress_fn, void* pctx,
                int device);
 
+/* ---- decode side (host code: a stream decodes as one serial chain) ------------- */
+typedef struct orz_lz_decoder orz_lz_decoder;
+/* LZDecoder::new / decode / forward, src/lz.rs:352-478.  decode() writes the chunk's bytes at
+ * sbuf[spos..] (sbuf laid out like the encoder's window, 480-byte pads, >= 2*LZ_BLOCK_SIZE long as in
+ * src/lib.rs:102) and returns the new spos in *spos_end_out; ORZ_EINVAL = InvalidData. */
+orz_lz_decoder* orz_lz_decoder_new(void);
+void orz_lz_decoder_free(orz_lz_decoder*);
+int orz_lz_decoder_decode(orz_lz_decoder*, const uint8_t* tbuf, size_t tlen, uint8_t* sbuf, size_t spos,
+                          size_t* spos_end_out);
+int orz_lz_decoder_forward(orz_lz_decoder*, size_t forward_len);
+/* orz::decode, src/lib.rs:94-129 */
+int orz_decode(orz_read_fn, void* rctx, orz_write_fn, void* wctx, orz_progress_fn, void* pctx);
+/* whole-buffer convenience: decodes the first stream found at src; *consumed = bytes of src it used */
+int orz_decode_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* consumed);
+
 /* ---- reusable stream encoder on caller memory (what bench.py and the Python mirror drive) ---- */
 typedef struct {
     uint64_t blocks, sweeps, seg_evals, items, chunks, in_bytes, out_bytes;

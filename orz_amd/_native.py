@@ -71,6 +71,21 @@ SYMBOLS = [
         [READ_FN, ctypes.c_void_p, WRITE_FN, ctypes.c_void_p, ctypes.POINTER(LZCfg), PROGRESS_FN, ctypes.c_void_p,
          ctypes.c_int],
     ),
+    ("orz_lz_decoder_new", ctypes.c_void_p, []),
+    ("orz_lz_decoder_free", None, [ctypes.c_void_p]),
+    (
+        "orz_lz_decoder_decode",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)],
+    ),
+    ("orz_lz_decoder_forward", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    ("orz_decode", ctypes.c_int, [READ_FN, ctypes.c_void_p, WRITE_FN, ctypes.c_void_p, PROGRESS_FN, ctypes.c_void_p]),
+    (
+        "orz_decode_mem",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t),
+         ctypes.POINTER(ctypes.c_size_t)],
+    ),
     ("orz_stream_new", ctypes.c_void_p, [ctypes.c_int, ctypes.POINTER(LZCfg)]),
     ("orz_stream_free", None, [ctypes.c_void_p]),
     ("orz_stream_set_tuning", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),

@@ -139,6 +139,54 @@ def encode(src, dst, cfg, progress=None, device=0):
     return tuple(counts)
 
 
+def decode_bytes(stream):
+    """orz stream -> (bytes, consumed).  Host decoder of the library (orz::decode, src/lib.rs:94-129);
+    stops after the first stream's EOF chunk like the reference."""
+    lib = _native.load()
+    stream = bytes(stream)
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n, used = ctypes.c_size_t(), ctypes.c_size_t()
+    buf = ctypes.create_string_buffer(stream, len(stream)) if stream else ctypes.create_string_buffer(1)
+    rc = lib.orz_decode_mem(ctypes.cast(buf, ctypes.c_void_p), len(stream), ctypes.byref(dst), ctypes.byref(n), ctypes.byref(used))
+    _check(rc, "orz_decode_mem")
+    try:
+        return ctypes.string_at(dst, n.value), used.value
+    finally:
+        lib.orz_free(dst)
+
+
+def decode(src, dst, progress=None):
+    """orz::decode (src/lib.rs:94-129) between file-like objects; returns (bytes_read, bytes_written)."""
+    lib = _native.load()
+    counts = [0, 0]
+
+    def _rd(_ctx, buf, cap):
+        try:
+            chunk = src.read(cap)
+        except Exception:
+            return -1
+        if chunk:
+            ctypes.memmove(buf, chunk, len(chunk))
+            counts[0] += len(chunk)
+        return len(chunk)
+
+    def _wr(_ctx, buf, n):
+        try:
+            dst.write(ctypes.string_at(buf, n))
+        except Exception:
+            return -1
+        counts[1] += n
+        return 0
+
+    def _pg(_ctx, fin, a, b):
+        if progress:
+            progress(bool(fin), a, b)
+
+    rd, wr, pg = _native.READ_FN(_rd), _native.WRITE_FN(_wr), _native.PROGRESS_FN(_pg)
+    _check(lib.orz_decode(rd, None, wr, None, pg, None), "orz_decode")
+    return tuple(counts)
+
+
 class LZEncoder:
     """Object-level mirror of the reference's LZEncoder (src/lz.rs:69-95).
 

@@ -12,6 +12,7 @@
 
 #include "../../include/orz_hip.h"
 #include "backend_hip.h"
+#include "orz_host_decode.h"
 #include "orz_stream.h"
 
 namespace {
@@ -260,6 +261,85 @@ int orz_lz_encoder_forward(orz_lz_encoder* e, size_t forward_len) {
         return ORZ_OK;
     } catch (const std::exception& ex) {
         return fail(ORZ_ENODEV, ex.what());
+    }
+}
+
+// ------------------------------------------------------------------------------ decode (host)
+struct orz_lz_decoder {
+    orz::host::Decoder dec;
+};
+orz_lz_decoder* orz_lz_decoder_new(void) {
+    try {
+        return new orz_lz_decoder();
+    } catch (const std::exception& e) {
+        fail(ORZ_ENOMEM, e.what());
+        return nullptr;
+    }
+}
+void orz_lz_decoder_free(orz_lz_decoder* d) { delete d; }
+int orz_lz_decoder_decode(orz_lz_decoder* d, const uint8_t* tbuf, size_t tlen, uint8_t* sbuf, size_t spos,
+                          size_t* spos_end_out) {
+    if (!d || !tbuf || !sbuf || !spos_end_out || spos < 3) return fail(ORZ_EINVAL, "bad argument");
+    try {
+        *spos_end_out = d->dec.decode(tbuf, tlen, sbuf, spos);
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
+}
+int orz_lz_decoder_forward(orz_lz_decoder* d, size_t forward_len) {
+    if (!d) return fail(ORZ_EINVAL, "null decoder");
+    d->dec.forward(forward_len);
+    return ORZ_OK;
+}
+int orz_decode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, orz_progress_fn prog, void* pctx) {
+    if (!rd || !wr) return fail(ORZ_EINVAL, "bad argument");
+    int io = ORZ_OK;
+    try {
+        orz::host::decode_stream(
+            [&](uint8_t* buf, size_t n) {
+                size_t got = 0;
+                while (got < n) {
+                    ssize_t r = rd(rctx, buf + got, n - got);
+                    if (r < 0) { io = ORZ_EIO; return false; }
+                    if (r == 0) return false;
+                    got += (size_t)r;
+                }
+                return true;
+            },
+            [&](const uint8_t* buf, size_t n) {
+                if (n && wr(wctx, buf, n) != 0) { io = ORZ_EIO; throw std::runtime_error("write failed"); }
+            },
+            [&](bool fin, size_t a, size_t b) {
+                if (prog) prog(pctx, fin ? 1 : 0, a, b);
+            });
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(io != ORZ_OK ? io : ORZ_EINVAL, e.what());
+    }
+}
+int orz_decode_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* consumed) {
+    if ((!src && n) || !dst || !dst_len) return fail(ORZ_EINVAL, "bad argument");
+    try {
+        std::vector<uint8_t> out;
+        size_t at = 0;
+        orz::host::decode_stream(
+            [&](uint8_t* buf, size_t k) {
+                if (at + k > n) return false;
+                std::memcpy(buf, src + at, k);
+                at += k;
+                return true;
+            },
+            [&](const uint8_t* buf, size_t k) { out.insert(out.end(), buf, buf + k); }, [](bool, size_t, size_t) {});
+        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+        std::memcpy(p, out.data(), out.size());
+        *dst = p;
+        *dst_len = out.size();
+        if (consumed) *consumed = at;
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
     }
 }
 

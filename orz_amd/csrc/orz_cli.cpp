@@ -1,0 +1,90 @@
+// orz_cli.cpp -- the `orz` command line on top of liborz_hip.so.
+// Same grammar as the reference binary (/root/reference/src/main.rs:21-52,97-113):
+//   orz encode [-s|--silent] [-l|--level 0..2 (default 2)] [source] [target]
+//   orz decode [-s|--silent] [source] [target]
+// source/target default to stdin/stdout.  Additive flag: --device N (HIP device of the encoder).
+// Progress lines mirror SimpleProgressLogger (src/progress.rs:48-98) on stderr.
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orz_hip.h"
+
+namespace {
+struct Io {
+    FILE* in;
+    FILE* out;
+};
+ssize_t rd(void* c, uint8_t* buf, size_t cap) {
+    Io* io = (Io*)c;
+    size_t n = fread(buf, 1, cap, io->in);
+    if (n == 0 && ferror(io->in)) return -1;
+    return (ssize_t)n;
+}
+int wr(void* c, const uint8_t* buf, size_t n) { return fwrite(buf, 1, n, ((Io*)c)->out) == n ? 0 : -1; }
+struct Prog {
+    bool encode;
+    std::chrono::steady_clock::time_point t0;
+};
+void progress(void* c, int fin, size_t a, size_t b) {
+    Prog* p = (Prog*)c;
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - p->t0).count();
+    size_t src = p->encode ? a : b, dst = p->encode ? b : a;  // decode reports (compressed in, raw out)
+    double mbs = s > 0 ? src / s / 1e6 : 0;
+    if (fin)
+        fprintf(stderr, "%s: %zu bytes => %zu bytes, ratio %.3f, %.3f MB/s, %.3f s\n", p->encode ? "encode" : "decode",
+                p->encode ? a : a, p->encode ? b : b, src ? (double)(p->encode ? dst : a) / (double)(p->encode ? src : b) : 0.0, mbs, s);
+    else
+        fprintf(stderr, "%s: %zu bytes => %zu bytes, %.3f MB/s\n", p->encode ? "encode" : "decode", a, b, mbs);
+}
+int usage() {
+    fprintf(stderr,
+            "an optimized ROLZ data compressor (MI355X encoder)\n\nUsage: orz <COMMAND>\n\nCommands:\n"
+            "  encode  Encode   [-s|--silent] [-l|--level <0..2>] [--device N] [source] [target]\n"
+            "  decode  Decode   [-s|--silent] [source] [target]\n");
+    return 2;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) return usage();
+    const std::string cmd = argv[1];
+    if (cmd != "encode" && cmd != "decode") return usage();
+    bool silent = false;
+    long level = 2, device = 0;
+    std::vector<std::string> pos;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "-s" || a == "--silent") silent = true;
+        else if (cmd == "encode" && (a == "-l" || a == "--level")) { if (++i >= argc) return usage(); level = strtol(argv[i], nullptr, 10); }
+        else if (cmd == "encode" && a.rfind("--level=", 0) == 0) level = strtol(a.c_str() + 8, nullptr, 10);
+        else if (cmd == "encode" && a.rfind("-l", 0) == 0 && a.size() > 2) level = strtol(a.c_str() + 2, nullptr, 10);
+        else if (cmd == "encode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }
+        else if (a.size() > 1 && a[0] == '-' ) return usage();
+        else pos.push_back(a);
+    }
+    if (pos.size() > 2) return usage();
+    Io io{stdin, stdout};
+    if (pos.size() >= 1 && !(io.in = fopen(pos[0].c_str(), "rb"))) { fprintf(stderr, "Error: %s: %s\n", pos[0].c_str(), strerror(errno)); return 1; }
+    if (pos.size() >= 2 && !(io.out = fopen(pos[1].c_str(), "wb"))) { fprintf(stderr, "Error: %s: %s\n", pos[1].c_str(), strerror(errno)); return 1; }
+    Prog pg{cmd == "encode", std::chrono::steady_clock::now()};
+    int rc;
+    if (cmd == "encode") {
+        orz_lzcfg cfg;
+        if (orz_lzcfg_from_level((int)level, &cfg) != ORZ_OK) {  // src/main.rs:101
+            fprintf(stderr, "Error: \"invalid level: %ld\"\n", level);
+            return 1;
+        }
+        rc = orz_encode(rd, &io, wr, &io, &cfg, silent ? nullptr : progress, &pg, (int)device);
+        if (rc != ORZ_OK) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
+    } else {
+        rc = orz_decode(rd, &io, wr, &io, silent ? nullptr : progress, &pg);
+        if (rc != ORZ_OK) { fprintf(stderr, "Error: \"decoding failed: %s\"\n", orz_last_error()); return 1; }
+    }
+    if (fflush(io.out) != 0) { fprintf(stderr, "Error: write failed\n"); return 1; }
+    return 0;
+}

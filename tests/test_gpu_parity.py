@@ -143,3 +143,25 @@ def test_baseline_size_roundtrip_properties(gpu_encoder_factory, oracle):
     ref = oracle.encode(data, 1)
     assert abs(len(out) - len(ref)) <= 0.005 * len(ref)
     assert out == ref
+
+
+def test_cli_encode_roundtrip(oracle, tmp_path):
+    """`orz encode -l1 in out` (GPU) -> reference-format stream: equals the oracle's, and `orz decode` restores it"""
+    import subprocess
+
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "orz")
+    data = _data.mixed(900_000, seed=81)
+    src, enc, dec = tmp_path / "in.bin", tmp_path / "in.orz", tmp_path / "out.bin"
+    src.write_bytes(data)
+    subprocess.check_call([cli, "encode", "-s", "-l1", str(src), str(enc)])
+    assert enc.read_bytes() == oracle.encode(data, 1)
+    subprocess.check_call([cli, "decode", "-s", str(enc), str(dec)])
+    assert dec.read_bytes() == data
+
+
+def test_gpu_stream_decodes_with_product_decoder(gpu_encoder_factory):
+    import orz_amd
+
+    data = _data.text(2_000_000, seed=91)
+    out = gpu_encoder_factory(2).encode(data)
+    assert orz_amd.decode_bytes(out)[0] == data
