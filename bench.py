@@ -135,6 +135,14 @@ def main():
         avg_launch_s = agg["parse_kernel_ms"] / 1e3 / launches
         bytes_per_launch = ALGO_BYTES_PER_INPUT_BYTE * len(data) * args.steps / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
+        # WRITE_SIZE collected in separate rocprofv3 runs on one 16 MiB block, profiles/): not live
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_16MiB_l1.json")) as f:
+                traffic = json.load(f).get("parse_wave_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         res = {
             "metric": "orz -l1 encode throughput (enwik8-shaped text, 100 MB, one 16 MiB block in flight)",
             "value": round(value, 3),
@@ -168,7 +176,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 8),
-                "traffic": None,
+                "traffic": traffic,
                 "launches_per_step": launches // args.steps,
                 "avg_launch_us": round(avg_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
