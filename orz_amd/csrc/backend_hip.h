@@ -59,9 +59,14 @@ __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {
 }
 
 // ring ordinals after a sweep (orz_parse.h): block = chunk of kRankChunk segments, thread = ctx
-__global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a) {
+__global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchunks, uint32_t nvblk) {
     __shared__ uint32_t rows[(kRankChunk + 1) * 256];
-    rank_chunk(a, blockIdx.x, threadIdx.x, rows, [] __device__() { __syncthreads(); });
+    auto sync = [] __device__() { __syncthreads(); };
+    if (blockIdx.x < nchunks) rank_chunk(a, blockIdx.x, threadIdx.x, rows, sync);
+    else if (blockIdx.x < nchunks + nvblk)  // the other blocks refresh the bitmap summaries for the next sweep
+        rebuild_summaries(a.vbits, a.v1, a.v2, a.nvwords, blockIdx.x - nchunks, threadIdx.x, (uint64_t*)rows, sync);
+    else
+        rebuild_summaries(a.kbits, a.k1, a.k2, a.nkwords, blockIdx.x - nchunks - nvblk, threadIdx.x, (uint64_t*)rows, sync);
 }
 
 // SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context, the 389-entry value and
@@ -100,7 +105,10 @@ class HipBackend {
    public:
     explicit HipBackend(int device) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
-        ORZ_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[0], hipStreamNonBlocking));
+        ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[1], hipStreamNonBlocking));
+        stream_ = streams_[0];
+        for (int i = 0; i < 2; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
         // temp storage big enough for the largest sort / scan of a block
         size_t s1 = 0, s2 = 0;
         uint64_t* k = nullptr;
@@ -111,19 +119,29 @@ class HipBackend {
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, s3, u, u, u, u, (size_t)kWLen, 0, 32, stream_));
         if (s3 > s1) s1 = s3;
         tmp_bytes_ = (s1 > s2 ? s1 : s2) + 256;
-        ORZ_HIP_CHECK(hipMalloc(&tmp_, tmp_bytes_));
+        ORZ_HIP_CHECK(hipMalloc(&tmps_[0], tmp_bytes_));
+        ORZ_HIP_CHECK(hipMalloc(&tmps_[1], tmp_bytes_));
+        tmp_ = tmps_[0];
     }
     ~HipBackend() {
         (void)hipSetDevice(device_);
-        (void)hipStreamSynchronize(stream_);
-        (void)hipFree(tmp_);
+        (void)hipStreamSynchronize(streams_[0]);
+        (void)hipStreamSynchronize(streams_[1]);
+        (void)hipFree(tmps_[0]);
+        (void)hipFree(tmps_[1]);
+        for (int i = 0; i < 2; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(stream_);
+        (void)hipStreamDestroy(streams_[0]);
+        (void)hipStreamDestroy(streams_[1]);
     }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;
 
-    hipStream_t stream() const { return stream_; }
+    hipStream_t stream() const { return streams_[0]; }
+    // second stream: the tail stage of a block overlaps the next block's parse (orz_stream.h)
+    void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
+    void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
+    void wait(int ev) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, sev_[ev], 0)); }
     int device() const { return device_; }
 
     template <class T>
@@ -181,7 +199,8 @@ class HipBackend {
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void rank(const RankArgs& a, uint32_t nchunks) {
-        hipLaunchKernelGGL(orz_rank_kernel, dim3(nchunks), dim3(256), 0, stream_, a);
+        const uint32_t nvblk = (a.nvwords + 4095) / 4096, nkblk = (a.nkwords + 4095) / 4096;
+        hipLaunchKernelGGL(orz_rank_kernel, dim3(nchunks + nvblk + nkblk), dim3(256), 0, stream_, a, nchunks, nvblk);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits) {
@@ -202,7 +221,7 @@ class HipBackend {
     }
     // HIP-event bracket around the dominant kernel's launches (bench.py roofline leg)
     void timed_begin() {
-        if (!timing_) return;
+        if (!timing_ || cur_ != 0) return;
         if (ev_used_ + 2 > ev_.size()) {
             for (int i = 0; i < 256; i++) {
                 hipEvent_t e;
@@ -213,14 +232,14 @@ class HipBackend {
         ORZ_HIP_CHECK(hipEventRecord(ev_[ev_used_], stream_));
     }
     void timed_end() {
-        if (!timing_) return;
+        if (!timing_ || cur_ != 0) return;
         ORZ_HIP_CHECK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
     }
     void set_timing(bool on) { timing_ = on; }
     // sum of the bracketed intervals in ms since the last call; also returns their count
     double collect_timed(uint64_t* launches) {
-        sync();
+        ORZ_HIP_CHECK(hipStreamSynchronize(streams_[0]));
         double ms = 0;
         for (size_t i = 0; i + 1 < ev_used_; i += 2) {
             float t = 0;
@@ -239,6 +258,10 @@ class HipBackend {
    private:
     int device_;
     hipStream_t stream_ = nullptr;
+    hipStream_t streams_[2] = {nullptr, nullptr};
+    hipEvent_t sev_[2];
+    void* tmps_[2] = {nullptr, nullptr};
+    int cur_ = 0;
     void* tmp_ = nullptr;
     size_t tmp_bytes_ = 0;
     bool timing_ = false;

@@ -372,11 +372,17 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
             be.h2d(enc.dwin() + orz::kPre, in.data(), got);
             out.clear();
             enc.encode_block((uint32_t)got, out);
-            if (wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }
+            if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }
             in_total += got;
             out_total += out.size();
             if (prog) prog(pctx, 0, in_total, out_total);
             if (got < in.size()) break;
+        }
+        if (rc == ORZ_OK) {  // the last block's tail stage is still in flight: take its bytes
+            out.clear();
+            enc.finish(out);
+            if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) rc = fail(ORZ_EIO, "write failed");
+            out_total += out.size();
         }
         if (rc == ORZ_OK) {
             const uint8_t eof = 0;  // write_len(0), src/lib.rs:89

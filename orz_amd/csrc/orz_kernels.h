@@ -147,36 +147,38 @@ struct CensusCount {
 };
 // symrank table state: per context {value[389], index[389], cnt, sum}
 constexpr uint32_t kSrWords = kSyms * 2 + 4;
-struct CensusInit {  // one thread: stable order by count (src/lz.rs:247-263); fills all 512 tables
+// Stable order by descending max(count, 1) (src/lz.rs:247-250): thread per symbol, its place is the
+// number of symbols that sort before it.
+struct CensusOrder {
     const uint32_t* counts;
     uint16_t* order;     // [389] out: initial rank order
-    uint32_t* ncounted;  // out
-    uint16_t* srstate;   // [512][kSrWords]
+    uint32_t* ncounted;  // out: symbols with count > 1 (src/lz.rs:253)
     ORZ_HD void operator()(size_t tid) const {
-        if (tid != 0) return;
-        uint16_t vs[kSyms];
-        uint32_t k = 0;
-        for (uint32_t sy = 0; sy < kSyms; sy++) {
-            uint32_t key = counts[sy] > 1 ? counts[sy] : 1;
-            k += counts[sy] > 1;
-            uint32_t j = sy;
-            while (j > 0) {
-                uint32_t kp = counts[vs[j - 1]] > 1 ? counts[vs[j - 1]] : 1;
-                if (kp >= key) break;
-                vs[j] = vs[j - 1];
-                j--;
-            }
-            vs[j] = (uint16_t)sy;
+        if (tid >= kSyms) return;
+        const uint32_t key = counts[tid] > 1 ? counts[tid] : 1;
+        uint32_t place = 0, k = 0;
+        for (uint32_t t = 0; t < kSyms; t++) {
+            const uint32_t kt = counts[t] > 1 ? counts[t] : 1;
+            place += (kt > key || (kt == key && t < tid)) ? 1u : 0u;
+            k += counts[t] > 1;
         }
-        *ncounted = k;
-        for (uint32_t i = 0; i < kSyms; i++) order[i] = vs[i];
-        for (uint32_t c = 0; c < 512; c++) {
-            uint16_t* t = srstate + (size_t)c * kSrWords;
-            for (uint32_t i = 0; i < kSyms; i++) {
-                t[i] = vs[i];
-                t[kSyms + vs[i]] = (uint16_t)i;
-            }
-            uint32_t cnt = 0, sum = 1000000;  // src/symrank.rs:26-27
+        order[place] = (uint16_t)tid;
+        if (tid == 0) *ncounted = k;
+    }
+};
+// all 512 SymRankCoders start from that order (src/lz.rs:259-263, src/symrank.rs:22-36): thread = (ctx, rank)
+struct CensusFill {
+    const uint16_t* order;
+    uint16_t* srstate;  // [512][kSrWords]
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = (uint32_t)(tid / kSyms), i = (uint32_t)(tid % kSyms);
+        if (c >= 512) return;
+        uint16_t* t = srstate + (size_t)c * kSrWords;
+        const uint16_t v = order[i];
+        t[i] = v;
+        t[kSyms + v] = (uint16_t)i;
+        if (i == 0) {
+            const uint32_t cnt = 0, sum = 1000000;  // src/symrank.rs:26-27
             t[2 * kSyms + 0] = (uint16_t)cnt; t[2 * kSyms + 1] = (uint16_t)(cnt >> 16);
             t[2 * kSyms + 2] = (uint16_t)sum; t[2 * kSyms + 3] = (uint16_t)(sum >> 16);
         }

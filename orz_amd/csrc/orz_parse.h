@@ -38,11 +38,13 @@ constexpr uint32_t kLbPre = 8;              // bytes staged in LDS before the se
 constexpr uint32_t kLbLen = 336;            // kLbPre + 64 + 240 + 8 rounded up to dwords: x+240+8 readable
 constexpr uint32_t kCntSlack = 64;          // own items a segment can add to one context (robustness margin)
 
-struct SlotRec {  // one candidate-list slot, 16 bytes = one load
+struct SlotRec {  // one candidate-list slot: 32 bytes, half a cache line, fetched as one request
     uint32_t pos;
     uint32_t ord;
     uint32_t ml;
     uint32_t pad;
+    uint64_t t0, t1;  // the 16 text bytes at pos (static): most common-prefix lengths are settled without
+                      // touching the window
 };
 
 struct ParseCtl {           // device-resident sweep control of one stream
@@ -51,7 +53,7 @@ struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t evals;         // segments evaluated so far (statistics)
     uint32_t nprof;         // waves sampled into prof[]
     uint32_t slow;          // items that needed the serial evaluation (statistics)
-    uint32_t pad;
+    uint32_t wend;          // end of the last sweep's window: segments >= wend were never evaluated
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
 };
@@ -104,8 +106,9 @@ ORZ_D void fence_agent() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
 ORZ_D int clz64(uint64_t v) { return __clzll((long long)v); }
 ORZ_D int ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }
 ORZ_D SlotRec ld_rec(const SlotRec* p) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
-    return SlotRec{v.x, v.y, v.z, v.w};
+    const uint4 v = reinterpret_cast<const uint4*>(p)[0];
+    const uint4 t = reinterpret_cast<const uint4*>(p)[1];
+    return SlotRec{v.x, v.y, v.z, v.w, (uint64_t)t.x | ((uint64_t)t.y << 32), (uint64_t)t.z | ((uint64_t)t.w << 32)};
 }
 #else
 ORZ_D uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -137,36 +140,52 @@ ORZ_D uint32_t lcp240u(const uint8_t* a, const uint8_t* b, uint32_t cap = kMaxLe
     return cap;
 }
 
-// Three-level bitmap over the candidate slots: vbits (bit per slot), v1 (bit per vbits word that is
-// non-zero -- kept exact), v2 (bit per v1 word that has ever been non-zero in this block -- set-only).
-// Setting goes bottom-up (word, then summaries); clearing the last bit of a word clears its v1 bit
-// and then re-reads the word at L2: a concurrent setter either is seen by that re-read or sets v1
-// after our clear, so "word != 0 implies v1 bit set" holds whenever the kernel is quiescent.
-ORZ_D void slot_set(uint64_t* vbits, uint64_t* v1, uint64_t* v2, uint32_t j) {
+// Three-level bitmap over the candidate slots: L0 (bit per slot), L1 (bit per non-zero L0 word),
+// L2 (bit per non-zero L1 word).  ParseWave updates level 0 only (plain atomics, nothing to wait
+// for); the rank kernel rebuilds both summary levels from level 0 after every sweep
+// (`rebuild_summaries`), so they are exact whenever a sweep starts; inside a sweep setters also set the
+// summary bits (never clear them).  A walker that misses a bit set during its own sweep has merely
+// speculated; the setter reports the change.
+ORZ_D void slot_set(uint64_t* L0, uint64_t* L1, uint64_t* L2, uint32_t j) {
     const uint32_t w = j >> 6;
-    const uint64_t old = atom_fetch_or64(&vbits[w], 1ull << (j & 63));
-    if (old == 0) {
-        fence_agent();
-        const uint64_t o1 = atom_fetch_or64(&v1[w >> 6], 1ull << (w & 63));
-        if (o1 == 0) atom_or64(&v2[w >> 12], 1ull << ((w >> 6) & 63));
-    }
+    atom_or64(&L0[w], 1ull << (j & 63));
+    atom_or64(&L1[w >> 6], 1ull << (w & 63));  // fire-and-forget: lets walkers of this very sweep find the bit
+    atom_or64(&L2[w >> 12], 1ull << ((w >> 6) & 63));
 }
-ORZ_D void slot_clear(uint64_t* vbits, uint64_t* v1, uint32_t j) {
-    const uint32_t w = j >> 6;
-    const uint64_t bit = 1ull << (j & 63);
-    const uint64_t old = atom_fetch_and64(&vbits[w], ~bit);
-    if ((old & ~bit) == 0 && (old & bit)) {
-        atom_fetch_and64(&v1[w >> 6], ~(1ull << (w & 63)));
-        fence_agent();  // the re-read must not overtake the summary clear
-        if (atom_fetch_or64(&vbits[w], 0) != 0) atom_or64(&v1[w >> 6], 1ull << (w & 63));
+ORZ_D void slot_clear(uint64_t* L0, uint32_t j) { atom_and64(&L0[j >> 6], ~(1ull << (j & 63))); }
+
+// One block (256 threads) per level-2 word = 4096 level-0 words: writes its 64 level-1 words and its
+// level-2 word.  `sh` = 64 u64 of LDS; sync() = block barrier; t = thread id.
+template <class SYNC>
+ORZ_D void rebuild_summaries(const uint64_t* L0, uint64_t* L1, uint64_t* L2, uint32_t nwords0, uint32_t blk, uint32_t t,
+                             uint64_t* sh, SYNC sync) {
+    // thread t owns level-1 bits [16 t', ...): 16 consecutive level-0 words -> a quarter of level-1 word t/4
+    const uint32_t w0 = blk * 4096 + t * 16;
+    uint64_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = w0 + i < nwords0 ? L0[w0 + i] : 0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) bits |= (uint32_t)(v[i] != 0) << i;
+    uint16_t* piece = (uint16_t*)sh;  // [256] sixteen level-1 bits per thread
+    piece[t] = (uint16_t)bits;
+    sync();
+    if (t < 64)
+        L1[blk * 64 + t] = (uint64_t)piece[4 * t] | ((uint64_t)piece[4 * t + 1] << 16) | ((uint64_t)piece[4 * t + 2] << 32) |
+                           ((uint64_t)piece[4 * t + 3] << 48);
+    if (t == 64) {
+        uint64_t m = 0;
+        for (int i = 0; i < 64; i++)
+            m |= (uint64_t)((piece[4 * i] | piece[4 * i + 1] | piece[4 * i + 2] | piece[4 * i + 3]) != 0) << i;
+        L2[blk] = m;
     }
 }
 
 // Newest-first list of the set slots in [lo, hi) of a three-level bitmap, at most D of them.
 // `word` is the already loaded level-0 word of slot hi-1.  Older words are reached through the
 // summaries: only non-empty ones are loaded, four in flight a round.
-ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint64_t* L2, uint64_t word, uint32_t hi,
-                             uint32_t lo, uint32_t D, uint32_t* out, uint32_t& nwords) {
+ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint64_t* L2, uint64_t word, uint64_t l1word,
+                             uint32_t hi, uint32_t lo, uint32_t D, uint32_t* out, uint32_t& nwords) {
     uint32_t found = 0;
     if (hi <= lo) return 0;
     const uint32_t w0 = (hi - 1) >> 6, wmin = lo >> 6;
@@ -179,7 +198,7 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
     }
     uint32_t u = w0 >> 6;
     bool more = found < D && w0 > wmin;
-    uint64_t m1 = more ? L1[u] : 0;
+    uint64_t m1 = more ? l1word : 0;  // level-1 word of slot hi-1, loaded together with `word`
     if (w0 & 63) m1 &= (1ull << (w0 & 63)) - 1; else m1 = 0;
     while (more) {
         if ((u << 6) < wmin) m1 &= ~0ull << (wmin - (u << 6));
@@ -229,14 +248,14 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
 }
 
 // decision record of one position (u64): what the item starting there would be
-constexpr uint64_t kDecMatch = 1ull << 33, kDecLazy1 = 1ull << 34, kDecLazy2a = 1ull << 35, kDecLazy2b = 1ull << 36,
+constexpr uint64_t kDecFull = 1ull << 39, kDecBl = 1ull << 38, kDecMatch = 1ull << 33, kDecLazy1 = 1ull << 34, kDecLazy2a = 1ull << 35, kDecLazy2b = 1ull << 36,
                    kDecRobust = 1ull << 37;
 ORZ_D uint32_t dec_src(uint64_t d) { return (uint32_t)(d & 0x1ffffff); }
 ORZ_D uint32_t dec_len(uint64_t d) { return (uint32_t)(d >> 25) & 0xff; }
 
 // byte offsets of the per-wave LDS arrays
 struct ParseLds {
-    uint32_t lb, cdat, dec, idxL, keyL, kkL, ownord, srcL, basec, cq;
+    uint32_t lb, cdat, dec, idxL, keyL, kkL, ownord, srcL, basec, cq, mlz;
     uint32_t wg, ctxL, ncand, ownv, ownml, ownE, oldml, oldE, tyL, w0L, lrL, cnt, dbg, total;
     ORZ_HD static ParseLds make(uint32_t dmax) {
         ParseLds o;
@@ -252,6 +271,7 @@ struct ParseLds {
         o.srcL = take(kNPMax * 4);
         o.basec = take(256 * 4);
         o.cq = take(kNPMax * dmax * 4);    // candidate position (slot while the list is being built)
+        o.mlz = take(kNPMax * 4);          // per position: what its list offers a lazy probe (see precompute)
         o.wg = take(kNPMax * 2);
         o.ctxL = take(kNPMax);
         o.ncand = take(kNPMax);
@@ -280,7 +300,7 @@ struct ParseWave {
         uint8_t* lb;
         uint64_t* cdat;
         uint64_t* dec;
-        uint32_t *idxL, *keyL, *kkL, *ownord, *srcL, *basec, *cq;
+        uint32_t *idxL, *keyL, *kkL, *ownord, *srcL, *basec, *cq, *mlz;
         uint16_t* wg;
         uint8_t *ctxL, *ncand, *ownv, *ownml, *ownE, *oldml, *oldE, *tyL, *w0L, *lrL, *cnt;
     };
@@ -304,6 +324,7 @@ struct ParseWave {
         s.srcL = (uint32_t*)(lds + L.srcL);
         s.basec = (uint32_t*)(lds + L.basec);
         s.cq = (uint32_t*)(lds + L.cq);
+        s.mlz = (uint32_t*)(lds + L.mlz);
         s.wg = (uint16_t*)(lds + L.wg);
         s.ctxL = lds + L.ctxL; s.ncand = lds + L.ncand; s.ownv = lds + L.ownv; s.ownml = lds + L.ownml;
         s.ownE = lds + L.ownE; s.oldml = lds + L.oldml; s.oldE = lds + L.oldE; s.tyL = lds + L.tyL;
@@ -315,7 +336,7 @@ struct ParseWave {
         const uint32_t npos = seg_end - seg_start;  // item-start positions of the segment (<= 62)
         const uint32_t nprobe = npos + 2;           // + lazy probe positions (<= 64 = one per lane)
         const uint32_t D = a.dmax;
-        const bool prof = a.prof && (w.block() & 63) == 5;
+        const bool prof = (a.prof & 1) && (w.block() & 63) == 5;
         unsigned long long tk0 = prof ? w.clock() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
 
         // ---- phase 0: stage the segment's bytes, slots, old state and the ctx ordinals in LDS
@@ -332,8 +353,12 @@ struct ParseWave {
             uint32_t ks = 0;
             const bool hasE = x < npos && pos >= kPre + 1;
             if (hasE) ks = a.kidx[pos - 2];
+            // a segment that enters the window for the first time has no ordinal row of its own yet: the row
+            // of the previous window end is a far better guess than a stale ring row
+            const uint32_t wprev = a.ctl->wend;
+            const uint32_t brow = ((a.prof & 2) == 0 && sg > wprev ? wprev : sg) % a.ring;
             for (uint32_t c = lane; c < 256; c += 64) {
-                s.basec[c] = a.base[(size_t)(sg % a.ring) * 256 + c];
+                s.basec[c] = a.base[(size_t)brow * 256 + c];
                 s.cnt[c] = 0;
             }
             if (x < nprobe) {
@@ -396,21 +421,23 @@ struct ParseWave {
             const uint32_t lo = a.runstart[key];
             const uint32_t klo = wantw ? a.krun[kk] : 0;
             uint64_t word = hi ? a.vbits[(hi - 1) >> 6] : 0;
+            const uint64_t l1word = hi ? a.v1[(hi - 1) >> 12] : 0;
             uint64_t kword = (wantw && khi) ? a.kbits[(khi - 1) >> 6] : 0;
+            const uint64_t kl1word = (wantw && khi) ? a.k1[(khi - 1) >> 12] : 0;
             uint32_t wsn = wantw ? (uint32_t)a.wsnap[kk * 2] | ((uint32_t)a.wsnap[kk * 2 + 1] << 8) : 0;
 
             uint32_t found = 0, nwords = 0;
             uint32_t* mycq = s.cq + x * D;
-            if (prof) dbg[1] = (uint32_t)(w.clock() - tk1) + (uint32_t)(word & 0) + (uint32_t)(kword & 0) + (lo & 0) + (klo & 0) + (wsn & 0);
-            found = collect_slots(a.vbits, a.v1, a.v2, word, hi, lo, D, mycq, nwords);
+            if (prof) dbg[1] = (uint32_t)(w.clock() - tk1) + (uint32_t)(word & 0) + (uint32_t)(kword & 0) + (uint32_t)(l1word & 0) + (uint32_t)(kl1word & 0) + (lo & 0) + (klo & 0) + (wsn & 0);
+            found = collect_slots(a.vbits, a.v1, a.v2, word, l1word, hi, lo, D, mycq, nwords);
             if (prof) dbg[2] = (uint32_t)(w.clock() - tk1);
             uint32_t kslot = 0xffffffffu;
-            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, khi, klo, 1, &kslot, nwords) == 0) kslot = 0xffffffffu;
+            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, kl1word, khi, klo, 1, &kslot, nwords) == 0) kslot = 0xffffffffu;
             if (prof) { dbg[3] = (uint32_t)(w.clock() - tk1); dbg[7] = nwords; }
-            // second round trip: the slot records (16 B each), sixteen in flight; third: their bytes
+            // second round trip: the slot records (32 B each, text included), sixteen in flight
             const uint32_t ku = kslot != 0xffffffffu ? a.kpos[kslot] : 0;
             const uint8_t* px = s.lb + kLbPre + x;
-            const uint64_t x0 = ldu64(px);
+            const uint64_t x0 = ldu64(px), x1 = ldu64(px + 8);
             uint64_t* mydat = s.cdat + x * D;
             for (uint32_t k0 = 0; k0 < found; k0 += 16) {
                 SlotRec r[16];
@@ -420,26 +447,29 @@ struct ParseWave {
                 for (int i = 0; i < 16; i++) r[i] = ld_rec(&a.srec[mycq[k0 + i < found ? k0 + i : k0]]);
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const uint64_t d0 = ldu64(b + r[i].pos) ^ x0;
+                    const uint64_t d0 = r[i].t0 ^ x0, d1 = r[i].t1 ^ x1;
                     if (d0) l[i] = (uint32_t)ctz64(d0) >> 3;
-                    else { l[i] = 8; if (k0 + i < found && r[i].ml != 255) act |= 1u << i; }
+                    else if (d1) l[i] = 8 + ((uint32_t)ctz64(d1) >> 3);
+                    else { l[i] = 16; if (k0 + i < found && r[i].ml != 255) act |= 1u << i; }
                 }
-                // the long ones advance together, one 16-byte step a round (loads of a round overlap)
-                while (act) {
+                // the long ones advance together (all at the same offset), 64 bytes a round; the position's
+                // own bytes are read from LDS once per round
+                for (uint32_t off = 16; act && off < kMaxLen; off += 64) {
+                    uint64_t xb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) xb[k] = ldu64(px + off + 8 * k);
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
                         if (act & (1u << i)) {
-                            const uint8_t* qa = b + r[i].pos + l[i];
-                            const uint8_t* pa = px + l[i];
-                            const uint64_t d0 = ldu64(qa) ^ ldu64(pa), d1 = ldu64(qa + 8) ^ ldu64(pa + 8);
-                            const uint64_t d2 = ldu64(qa + 16) ^ ldu64(pa + 16), d3 = ldu64(qa + 24) ^ ldu64(pa + 24);
-                            uint32_t adv = 32;
-                            if (d0) adv = (uint32_t)ctz64(d0) >> 3;
-                            else if (d1) adv = 8 + ((uint32_t)ctz64(d1) >> 3);
-                            else if (d2) adv = 16 + ((uint32_t)ctz64(d2) >> 3);
-                            else if (d3) adv = 24 + ((uint32_t)ctz64(d3) >> 3);
-                            l[i] += adv;
-                            if (adv < 32) act &= ~(1u << i);
+                            const uint8_t* qa = b + r[i].pos + off;
+                            uint64_t d[8];
+#pragma unroll
+                            for (int k = 0; k < 8; k++) d[k] = ldu64(qa + 8 * k) ^ xb[k];
+                            uint32_t adv = 64;
+#pragma unroll
+                            for (int k = 7; k >= 0; k--) if (d[k]) adv = 8 * (uint32_t)k + ((uint32_t)ctz64(d[k]) >> 3);
+                            l[i] = off + adv;
+                            if (adv < 64) act &= ~(1u << i);
                             if (l[i] >= kMaxLen) { l[i] = kMaxLen; act &= ~(1u << i); }
                         }
                     }
@@ -461,26 +491,12 @@ struct ParseWave {
             }
         }
         w.sync();
-        if (prof) {
-            tk2 = w.clock();
-            if (lane == 0) {
-                const uint32_t* dg = (const uint32_t*)(lds + L.dbg);
-                for (int k = 0; k < 5; k++) {
-                    uint32_t mx = 0;
-                    for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + k] > mx) mx = dg[i * 8 + k];
-                    atom_add64(&a.ctl->prof2[k], mx);
-                }
-                uint32_t mw = 0;
-                for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + 7] > mw) mw = dg[i * 8 + 7];
-                atom_add64(&a.ctl->prof2[7], mw);
-            }
-            w.sync();
-        }
+        if (prof) tk2 = w.clock();
 
         // ---- phase 2a: every position decides, on its own lane, what the item starting there would be
         // if the segment's own earlier items do not interfere (no same-key item, no words[] update of
         // its key, ring ordinals within kCntSlack of no threshold): kDecRobust marks those decisions.
-        if (lane < npos) s.dec[lane] = eval_item(s, b, seg_start, lane, 0, 0, 0, 2, true);
+        if (lane < nprobe && seg_start + lane < a.len) precompute(s, b, seg_start, lane, lane < npos);
         uint32_t p, lt;
         if (sg == 0) {
             p = kPre;
@@ -527,34 +543,28 @@ struct ParseWave {
             }
             const uint32_t lwm = (px[0] == w0 && px[1] == w1);
             uint64_t d = s.dec[x];
+            bool is_match = (d & kDecMatch) != 0;
+            uint32_t max_len = dec_len(d), lazy = 0;
+            bool robust = (d & kDecRobust) != 0 && !m0;
+            if (is_match && max_len < kMaxLen / 2) {  // the lazy probes read what the lists of x+1 / x+2 offer
+                const uint32_t l1 = max_len + 1 + ((d & kDecBl) ? 1u : 0u);
+                const uint32_t z1 = s.mlz[x + 1], z2 = s.mlz[x + 2];
+                if ((z1 & 0xff) >= l1) lazy = 1;
+                else if (((z2 >> 8) & 0xff) >= l1 - lwm) lazy = 2;
+                robust = robust && ((z1 >> 16) & 1) && ((z2 >> 17) & 1) && !(m1 | m2);
+            }
 #ifdef ORZ_FORCE_SLOW
-            if (true) {
-#else
-            if (!(d & kDecRobust) || (m0 | m1 | m2)) {
+            robust = false;
 #endif
+            if (!robust) {  // this sweep's own items interfere (or a ring threshold is near): evaluate on the spot
                 if (lane == 0) s.dec[x] = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
                 w.sync();
                 d = s.dec[x];
                 nslow++;
+                is_match = (d & kDecMatch) != 0;
+                max_len = dec_len(d);
+                lazy = (d & kDecLazy1) ? 1 : ((d & kDecLazy2a) ? 2 : 0);
             }
-#ifdef ORZ_DEBUG_ROBUST
-            else if (lane == 0) {
-                uint64_t d2 = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
-                const uint32_t lz1 = (d & kDecLazy1) ? 1 : ((d & (lwm ? kDecLazy2b : kDecLazy2a)) ? 2 : 0);
-                const uint32_t lz2 = (d2 & kDecLazy1) ? 1 : ((d2 & kDecLazy2a) ? 2 : 0);
-                if ((d & 0x3ffffffffull) != (d2 & 0x3ffffffffull) || lz1 != lz2)
-                {
-                    fprintf(stderr, "ROBUST MISMATCH sg=%u p=%u x=%u lwm=%u d=%llx d2=%llx lz %u %u cnt=%u basec=%u nc=%u m0=%llx\n", sg, p, x, lwm,
-                            (unsigned long long)d, (unsigned long long)d2, lz1, lz2, (unsigned)s.cnt[s.ctxL[x]], s.basec[s.ctxL[x]], (unsigned)s.ncand[x], (unsigned long long)m0);
-                    for (uint32_t k = 0; k < s.ncand[x]; k++) fprintf(stderr, "   cand %u q=%u ord=%u l=%u ml=%u\n", k, s.cq[x * a.dmax + k], (uint32_t)s.cdat[x * a.dmax + k], (uint32_t)(s.cdat[x * a.dmax + k] >> 32) & 0xff, (uint32_t)(s.cdat[x * a.dmax + k] >> 40) & 0xff);
-                    uint64_t d3 = eval_item(s, b, seg_start, x, 0, 0, 0, 2, true);
-                    fprintf(stderr, "   re-eval check now: %llx\n", (unsigned long long)d3);
-                }
-            }
-#endif
-            const bool is_match = (d & kDecMatch) != 0;
-            const uint32_t max_len = dec_len(d);
-            const uint32_t lazy = (d & kDecLazy1) ? 1 : ((d & (lwm ? kDecLazy2b : kDecLazy2a)) ? 2 : 0);
             // commit, src/lz.rs:172-234
             const uint32_t c = s.ctxL[x];
             const uint32_t cc = s.cnt[c];
@@ -580,9 +590,6 @@ struct ParseWave {
             }
             if (lane == x) myv = true;
             if (np < seg_end && lane == np - seg_start) myE = (ty != kTyWord);
-#ifdef ORZ_DEBUG_ROBUST
-            if (sg == 233) fprintf(stderr, "   lane %u x=%u d=%llx lwm=%u lazy=%u np=%u mE=%llx w=%u,%u\n", lane, x, (unsigned long long)d, lwm, lazy, np, (unsigned long long)mE, w0, w1);
-#endif
             p = np;
             lt = ty;
             w.sync();
@@ -600,7 +607,7 @@ struct ParseWave {
             if (nm != om) {
                 a.srec[j].ml = nm;
                 if ((nm == 255) != (om == 255)) {
-                    if (nm == 255) slot_clear(a.vbits, a.v1, j);
+                    if (nm == 255) slot_clear(a.vbits, j);
                     else slot_set(a.vbits, a.v1, a.v2, j);
                 }
                 changed = true;
@@ -614,7 +621,7 @@ struct ParseWave {
             if (pos >= kPre + 1 && s.ownE[x] != s.oldE[x]) {
                 const uint32_t ks = a.kidx[pos - 2];
                 if (s.ownE[x]) slot_set(a.kbits, a.k1, a.k2, ks);
-                else slot_clear(a.kbits, a.k1, ks);
+                else slot_clear(a.kbits, ks);
                 changed = true;
             }
         }
@@ -635,16 +642,6 @@ struct ParseWave {
             atom_add32(&a.ctl->evals, 1);
             if (nslow) atom_add32(&a.ctl->slow, nslow);
         }
-#ifdef ORZ_DEBUG_ROBUST
-        if (sg >= 232 && sg <= 234) {
-            uint64_t chm = w.ballot(changed);
-            if (lane == 0) {
-                fprintf(stderr, "EVAL sg=%u front=%u par=%u exit p=%u lt=%u changed=%llx items:", sg, front, a.par, p, lt, (unsigned long long)chm);
-                for (uint32_t x = 0; x < npos; x++) if (s.ownv[x]) fprintf(stderr, " %u:%u(old %u)", x, s.ownml[x], s.oldml[x]);
-                fprintf(stderr, "\n");
-            }
-        }
-#endif
         if (w.ballot(changed) && lane == 0) atom_min32(&a.ctl->fchg[a.par], sg);
         if (prof && lane == 0) {
             const unsigned long long tk5 = w.clock();
@@ -654,7 +651,80 @@ struct ParseWave {
             atom_add64(&a.ctl->prof[3], tk4 - tk3);
             atom_add64(&a.ctl->prof[4], tk5 - tk4);
             atom_add32(&a.ctl->nprof, 1);
+            {
+                const uint32_t* dg = (const uint32_t*)(lds + L.dbg);
+                for (int k = 0; k < 5; k++) {
+                    uint32_t mx = 0;
+                    for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + k] > mx) mx = dg[i * 8 + k];
+                    atom_add64(&a.ctl->prof2[k], mx);
+                }
+                uint32_t mw = 0;
+                for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + 7] > mw) mw = dg[i * 8 + 7];
+                atom_add64(&a.ctl->prof2[7], mw);
+            }
         }
+    }
+
+    // One pass of a position over its own candidate list, on its own lane, assuming none of the segment's
+    // own items interfere: (a) find_match for an item starting here -> dec[x]; (b) what the list offers a
+    // lazy probe AT this position: the longest common prefix among its first lazy1 / lazy2 ring members
+    // (has_lazy_match(min_len) <=> that maximum >= min_len) -> mlz[x].  Robust bits: the result does not
+    // change for any own-item count in [0, kCntSlack].
+    ORZ_D void precompute(const Sh& s, const uint8_t* b, uint32_t seg_start, uint32_t x, bool item_start) const {
+        const uint32_t D = a.dmax;
+        const uint8_t* px = s.lb + kLbPre + x;
+        const uint32_t p = seg_start + x;
+        const uint32_t c = s.ctxL[x];
+        const uint32_t hcnt = s.basec[c] + s.cnt[c];
+        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0, nmain = 0, n1 = 0, n2 = 0, M1 = 0, M2 = 0;
+        bool rmain = true, r1 = true, r2 = true, stop_main = false, stop_all = false;
+        const uint32_t nc = s.ncand[x];
+        const uint64_t* dat = s.cdat + x * D;
+        for (uint32_t k0 = 0; k0 < nc && !stop_all; k0 += 16) {
+            uint64_t cdv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint64_t cd = cdv[i];
+                const uint32_t ml = (uint32_t)(cd >> 40) & 0xff;
+                if (stop_all || ml == 255) continue;
+                const uint32_t oq = (uint32_t)cd;
+                const uint32_t ro = hcnt - 1 - oq;
+                const bool near = ro <= kRing - 1 && ro + kCntSlack > kRing - 1;
+                const bool want_main = !stop_main && nmain < a.depth, want1 = n1 < a.lazy1, want2 = n2 < a.lazy2;
+                if (near) { if (want_main) rmain = false; if (want1) r1 = false; if (want2) r2 = false; }
+                if (ro > kRing - 1) { stop_all = true; continue; }
+                const uint32_t l = (uint32_t)(cd >> 32) & 0xff;
+                if (want1) { n1++; if (l > M1) M1 = l; }
+                if (want2) { n2++; if (l > M2) M2 = l; }
+                if (want_main) {
+                    nmain++;
+                    if (l > max_len) {
+                        mlexp = ml; max_len = l; bestq = s.cq[x * D + k0 + i]; besto = oq;
+                        if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop_main = true;
+                    } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
+                        if (ldu32(b + s.cq[x * D + k0 + i] + max_len - 3) == ldu32(px + max_len - 3)) stop_main = true;
+                    }
+                } else {
+                    stop_main = true;
+                }
+                if (stop_main && !want1 && !want2) stop_all = true;
+            }
+        }
+        s.mlz[x] = M1 | (M2 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)r2 << 17);
+        if (!item_start) return;
+        const bool is_match = max_len >= kMinLen && p + max_len < a.len;
+        uint64_t d = (uint64_t)bestq | ((uint64_t)max_len << 25);
+        if (is_match) {
+            d |= kDecMatch;
+            const uint32_t ro = hcnt - 1 - besto;
+            const bool bl = roid_bitlen(ro) < 8;
+            if (bl != (roid_bitlen(ro + kCntSlack) < 8)) rmain = false;
+            if (bl) d |= kDecBl;
+        }
+        if (rmain) d |= kDecRobust;
+        s.dec[x] = d;
     }
 
     // What the item starting at segment position x is (src/lz.rs:131-235 for one spos):
@@ -731,7 +801,7 @@ struct ParseWave {
             }
         }
         if (robust && check) d |= kDecRobust;  // an on-the-spot evaluation is never reused as a robust one
-        return d;
+        return d | kDecFull;
     }
 
     // has_lazy_match (src/matcher.rs:194-228) for probe position xx in {x+1, x+2}: candidates are the
@@ -790,6 +860,9 @@ struct RankArgs {
     SlotRec* srec;
     const uint8_t* LR;
     uint32_t nseg, seg, wsegs, ring, len, par;
+    const uint64_t *vbits, *kbits;  // level-0 bitmaps ...
+    uint64_t *v1, *v2, *k1, *k2;     // ... and their summaries, rebuilt here after every sweep
+    uint32_t nvwords, nkwords;       // level-0 words in use
 };
 // `rows` = LDS [kRankChunk + 1][256] u32 ; sync() = block barrier ; c = thread id (0..255)
 template <class SYNC>
@@ -820,11 +893,25 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
     if (s0 < wend) {
         const uint32_t x0 = kPre + s0 * a.seg;
         const uint32_t npos = (s1 - s0) * a.seg;
-        for (uint32_t i = c; i < npos; i += 256) {
-            const uint32_t x = x0 + i;
-            if (x >= a.len) break;
-            const uint32_t j = a.idx[x];
-            if (a.srec[j].ml != 255) a.srec[j].ord = rows[(i / a.seg) * 256 + hash1(a.win, x - 1)] + a.LR[x];
+        // eight positions per thread a round, loads of a round in flight together
+        for (uint32_t i0 = c; i0 < npos; i0 += 256 * 8) {
+            uint32_t j[8], ml[8], lr[8], cx[8];
+            bool ok[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t i = i0 + (uint32_t)k * 256, x = x0 + i;
+                ok[k] = i < npos && x < a.len;
+                j[k] = ok[k] ? a.idx[x] : 0;
+                lr[k] = ok[k] ? a.LR[x] : 0;
+                cx[k] = ok[k] ? hash1(a.win, x - 1) : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) ml[k] = ok[k] ? a.srec[j[k]].ml : 255u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t i = i0 + (uint32_t)k * 256;
+                if (ok[k] && ml[k] != 255) a.srec[j[k]].ord = rows[(i / a.seg) * 256 + cx[k]] + lr[k];
+            }
         }
     }
     // re-arm the other parity's accumulators for the next sweep (nobody reads them in this launch)
@@ -836,6 +923,7 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
         if (f >= a.nseg) nf = f;
         a.ctl->front[a.par ^ 1] = nf;
         a.ctl->fchg[a.par ^ 1] = kNoChange;
+        if (wend > a.ctl->wend) a.ctl->wend = wend;
     }
 }
 

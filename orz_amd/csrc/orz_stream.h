@@ -107,20 +107,21 @@ struct ScatterSlots {  // idx[pos[j]] = j ; run starts
     }
 };
 struct SlotInit {  // history slots carry their final item state, new slots start empty
+    const uint8_t* win;
     const uint32_t* epos;
     uint32_t n;
     const uint8_t* ML;
     const uint32_t* ORD;
     SlotRec* srec;
-    uint64_t *vbits, *v1, *v2;  // zeroed
+    uint64_t* vbits;  // zeroed
     ORZ_HD void operator()(size_t tid) const {
         if (tid >= n) return;
         uint32_t x = epos[tid];
         if (x < kPre) {
-            srec[tid] = SlotRec{x, ORD[x], ML[x], 0};
-            slot_set(vbits, v1, v2, (uint32_t)tid);
+            srec[tid] = SlotRec{x, ORD[x], ML[x], 0, ldu64(win + x), ldu64(win + x + 8)};
+            atom_or64(&vbits[tid >> 6], 1ull << (tid & 63));
         } else {
-            srec[tid] = SlotRec{x, 0, 255, 0};
+            srec[tid] = SlotRec{x, 0, 255, 0, ldu64(win + x), ldu64(win + x + 8)};
         }
     }
 };
@@ -140,6 +141,7 @@ struct ParseCtlInit {
         ctl->evals = 0;
         ctl->nprof = 0;
         ctl->slow = 0;
+        ctl->wend = 0;
         for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; }
     }
 };
@@ -213,6 +215,8 @@ class StreamEncoder {
         // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
         entA_ = be_.template alloc<uint64_t>((size_t)kWLen);
         entB_ = be_.template alloc<uint64_t>((size_t)kWLen);
+        symA_ = be_.template alloc<uint64_t>((size_t)kNewMax);
+        symB_ = be_.template alloc<uint64_t>((size_t)kNewMax);
         epos_ = be_.template alloc<uint32_t>(kWLen);
         kpos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 8);
         runstart_ = be_.template alloc<uint32_t>(kNumKeys + 1);
@@ -262,10 +266,15 @@ class StreamEncoder {
         tot_ = be_.template alloc<uint32_t>(kMaxChunks);
         outoff_ = be_.template alloc<uint64_t>(kMaxChunks);
         out_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
+        {
+            std::vector<uint64_t> off(kMaxChunks);
+            for (uint32_t i = 0; i < kMaxChunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
+            be_.h2d(outoff_, off.data(), kMaxChunks * 8);
+        }
         reset();
     }
     ~StreamEncoder() {
-        void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, epos_,
+        void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, symA_, symB_, epos_,
                         kpos_, runstart_, krun_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
@@ -284,6 +293,8 @@ class StreamEncoder {
         be_.memset(LENMIN_, 0, kWLen);
         be_.memset(ctxcount_, 0, 256 * 4);
         be_.memset(wsnap_, 0, 65536);
+        be_.select(1); be_.sync(); be_.select(0);
+        pending_ = false;
         lt_carry_ = kTyLit;
         stream_start_ = true;
         stats = EncodeStats();
@@ -297,6 +308,8 @@ class StreamEncoder {
     // Encode the block whose n new bytes sit at dwin()[kPre, kPre+n).  Appends
     // { LEB128(t) chunk[t] }* (src/lib.rs:76-82, src/ioutil.rs:79-88) to `out`; optionally reports
     // each chunk's end position (the value LZEncoder::encode returns, src/lz.rs:268,346).
+    // The last stage of a block (symrank -> Huffman -> bit pack) runs on the backend's second stream and
+    // overlaps the next block's prep + parse; its output is appended by the next call, or by finish().
     void encode_block(uint32_t n, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
         double t0 = be_.now();
@@ -333,7 +346,9 @@ class StreamEncoder {
         be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
         be_.memset(k1_, 0, ((size_t)kNewMax / 4096 + 2) * 8);
         be_.memset(k2_, 0, ((size_t)kNewMax / 262144 + 2) * 8);
-        be_.launch(nent, SlotInit{epos_, nent, ML_, ORD_, srec_, vbits_, v1_, v2_});
+        be_.launch(nent, SlotInit{win, epos_, nent, ML_, ORD_, srec_, vbits_});
+        // summary levels of both bitmaps, exact before the first sweep (0 rank chunks = rebuild only)
+        be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, 0, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2}, 0);
         be_.launch((size_t)nseg + 1, FillExit{exitst_, nseg, seg_});
         be_.memset(hist_, 0, (size_t)ring_ * 256);
         be_.d2d(base_, ctxcount_, 256 * 4);
@@ -348,7 +363,7 @@ class StreamEncoder {
         ParseArgs pa;
         pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
         pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
-        pa.lt0 = lt_carry_; pa.par = 0; pa.prof = getenv("ORZ_PROF") ? 1 : 0;
+        pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
@@ -362,7 +377,7 @@ class StreamEncoder {
                 be_.timed_begin();
                 be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
                 be_.timed_end();
-                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, par},
+                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, par, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2},
                          wsegs_ / kRankChunk + 1);
                 par ^= 1;
                 sweeps++;
@@ -415,7 +430,8 @@ class StreamEncoder {
         }
 #endif
 
-        // ---- items
+        // ---- items (the item arrays are shared with the previous block's tail stage: let it finish)
+        if (pending_) be_.wait(1);
         be_.launch(n, Flags32{S_, n, f32_});
         be_.exclusive_scan_u32(f32_, sc32_, n);
         uint32_t a, b2;
@@ -435,11 +451,27 @@ class StreamEncoder {
         if (stream_start_) {  // src/lz.rs:238-265
             be_.memset(counts_, 0, (kSyms + 3) * 4);
             be_.launch(std::min(nitems, kChunkItems), CensusCount{isym_, std::min(nitems, kChunkItems), counts_});
-            be_.launch(1, CensusInit{counts_, order_, ncounted_, srstate_});
+            be_.launch(kSyms, CensusOrder{counts_, order_, ncounted_});
+            be_.launch((size_t)512 * kSyms, CensusFill{order_, srstate_});
         }
+        // ---- model state carried to the next block (still on the main stream)
+        be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
+        uint32_t ex;
+        be_.d2h(&ex, exitst_ + nseg, 4);
+        const uint8_t ltf = (uint8_t)(ex & 3);
+        be_.memset(wlast_, 0, 32768 * 4);
+        be_.launch((size_t)n + 1, WordsLast{win, E_, len, wlast_});
+        be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
+        lt_carry_ = ltf;
+
+        // ---- the previous block's tail has long finished: take its output, then start this block's tail
+        collect(out, nullptr);
+        be_.record(0);   // items of this block are ready on the main stream
+        be_.select(1);
+        be_.wait(0);
         // symbol ranking: 512 independent serial chains
-        be_.launch(nitems, SymKeys{ictx_, nitems, entA_});
-        const uint64_t* sk = be_.sort_u64(entA_, entB_, nitems, 33);
+        be_.launch(nitems, SymKeys{ictx_, nitems, symA_});
+        const uint64_t* sk = be_.sort_u64(symA_, symB_, nitems, 33);
         be_.launch(nitems, SymGather{sk, isym_, iunl_, nitems, gsym_});
         be_.launch(513, SymRunStart{sk, nitems, rstart_});
         be_.symrank(srstate_, gsym_, grank_, rstart_);
@@ -451,14 +483,30 @@ class StreamEncoder {
         be_.launch(nitems, ItemBits{irank_, ial_, ienc_, irob_, hl_, nitems, blen_});
         be_.exclusive_scan_u32(blen_, bscan_, nitems);
         // bit packing
-        std::vector<uint64_t> off(nchunks);
-        for (uint32_t i = 0; i < nchunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
-        be_.h2d(outoff_, off.data(), nchunks * 8);
         be_.memset(out_, 0, (size_t)nchunks * kChunkCapWords * 4);
         be_.launch(nchunks, ChunkHeader{hl_, nchunks, nitems, len, ipos_, order_, ncounted_, stream_start_ ? 1 : 0, out_,
                                         outoff_, hdrbits_});
         be_.launch(nitems, Pack{irank_, ial_, ienc_, irob_, hl_, hc_, bscan_, hdrbits_, outoff_, nitems, out_});
         be_.launch(nchunks, ChunkTotals{bscan_, blen_, hdrbits_, nitems, nchunks, tot_});
+        be_.record(1);  // tail of this block done (the next block's item stage waits for it)
+        be_.select(0);
+        pending_ = true;
+        pend_nitems_ = nitems; pend_nchunks_ = nchunks; pend_len_ = len;
+        stream_start_ = false;
+        stats.t_post += be_.now() - t2;
+        stats.blocks++;
+        stats.items += nitems;
+        stats.chunks += nchunks;
+        stats.in_bytes += n;
+        if (chunk_ends || trace) collect(out, chunk_ends);  // callers that need this block's bytes now
+    }
+
+    // Append the output of the block whose tail stage is in flight (if any).
+    void collect(std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends) {
+        if (!pending_) return;
+        pending_ = false;
+        const uint32_t nitems = pend_nitems_, nchunks = pend_nchunks_, len = pend_len_;
+        be_.select(1);
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), tot_, nchunks * 4);
         for (uint32_t i = 0; i < nchunks; i++) {
@@ -469,7 +517,7 @@ class StreamEncoder {
             out.push_back((uint8_t)v);
             size_t at = out.size();
             out.resize(at + t);
-            be_.d2h(out.data() + at, out_ + off[i], t);
+            be_.d2h(out.data() + at, out_ + (uint64_t)i * kChunkCapWords, t);
             if (chunk_ends) {  // end_spos of the chunk, src/lz.rs:268
                 uint32_t i1 = (i + 1) << 20, e = len;
                 if (i1 < nitems) be_.d2h(&e, ipos_ + i1, 4);
@@ -478,7 +526,7 @@ class StreamEncoder {
         }
         if (trace) {
             const size_t at = trace->pos.size();
-            trace->block.resize(at + nitems, (uint32_t)stats.blocks);
+            trace->block.resize(at + nitems, (uint32_t)(stats.blocks - 1));
             trace->pos.resize(at + nitems); trace->sym.resize(at + nitems); trace->ctx.resize(at + nitems);
             trace->rank.resize(at + nitems); trace->rob.resize(at + nitems); trace->unl.resize(at + nitems);
             trace->enc.resize(at + nitems); trace->al.resize(at + nitems);
@@ -491,23 +539,9 @@ class StreamEncoder {
             be_.d2h(trace->enc.data() + at, ienc_, nitems);
             be_.d2h(trace->al.data() + at, ial_, nitems);
         }
-        // ---- model state carried to the next block
-        be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
-        uint32_t ex;
-        be_.d2h(&ex, exitst_ + nseg, 4);
-        const uint8_t ltf = (uint8_t)(ex & 3);
-        be_.memset(wlast_, 0, 32768 * 4);
-        be_.launch((size_t)n + 1, WordsLast{win, E_, len, wlast_});
-        be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
-        lt_carry_ = ltf;
-        stream_start_ = false;
-        be_.sync();
-        stats.t_post += be_.now() - t2;
-        stats.blocks++;
-        stats.items += nitems;
-        stats.chunks += nchunks;
-        stats.in_bytes += n;
+        be_.select(0);
     }
+    void finish(std::vector<uint8_t>& out) { collect(out, nullptr); }
 
     // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
     // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.
@@ -531,6 +565,9 @@ class StreamEncoder {
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
+    bool pending_ = false;
+    uint32_t pend_nitems_ = 0, pend_nchunks_ = 0, pend_len_ = 0;
+    uint64_t *symA_, *symB_;
     uint8_t* winbuf_;
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
     uint32_t *ORD_, *SRC_;
@@ -575,6 +612,7 @@ void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n,
         off += take;
         if (off < n) enc.slide();
     }
+    enc.finish(out);
     out.push_back(0);  // EOF chunk, src/lib.rs:89
     enc.stats.out_bytes = out.size();
 }

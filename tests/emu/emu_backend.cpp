@@ -24,6 +24,9 @@ struct EmuBackend {
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
+    void select(int) {}
+    void record(int) {}
+    void wait(int) {}
     void timed_begin() {}
     void timed_end() {}
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -41,6 +44,23 @@ struct EmuBackend {
             // threads are independent before the barrier (own column) and read rows[] after it
             for (int phase = 0; phase < 2; phase++)
                 for (uint32_t c = 256; c-- > 0;) run_rank_thread(a, ch, c, rows.data(), phase);
+        }
+        // the remaining blocks of the launch refresh the bitmap summaries
+        struct Stop {};
+        for (int which = 0; which < 2; which++) {
+            const uint64_t* L0 = which ? a.kbits : a.vbits;
+            uint64_t* L1 = which ? a.k1 : a.v1;
+            uint64_t* L2 = which ? a.k2 : a.v2;
+            const uint32_t nw = which ? a.nkwords : a.nvwords;
+            for (uint32_t blk = 0; blk < (nw + 4095) / 4096; blk++)
+                for (int phase = 0; phase < 2; phase++)
+                    for (uint32_t t = 0; t < 256; t++) {
+                        if (phase == 0) {
+                            try { orz::rebuild_summaries(L0, L1, L2, nw, blk, t, (uint64_t*)rows.data(), []() { throw Stop(); }); } catch (Stop&) {}
+                        } else {
+                            orz::rebuild_summaries(L0, L1, L2, nw, blk, t, (uint64_t*)rows.data(), []() {});
+                        }
+                    }
         }
     }
     // executes thread c of chunk ch either up to the barrier (phase 0) or from it (phase 1)

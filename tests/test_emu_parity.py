@@ -18,7 +18,7 @@ def test_small_cases(emu, oracle, name):
 
 @pytest.mark.parametrize("level", [0, 1, 2])
 def test_text_levels(emu, oracle, level):
-    data = _data.text(60_000, seed=level + 1)
+    data = _data.text(30_000, seed=level + 1)
     out, st = emu(data, cfg=LEVELS[level])
     assert out == oracle.encode(data, level)
     assert st[1] >= 2  # it really iterated
@@ -27,21 +27,21 @@ def test_text_levels(emu, oracle, level):
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_sweep_order_does_not_matter(emu, oracle, order):
     """ascending = Gauss-Seidel, descending = pure Jacobi, shuffled: same fixed point"""
-    data = _data.mixed(80_000, seed=11)
+    data = _data.mixed(40_000, seed=11)
     out, _ = emu(data, order=order)
     assert out == oracle.encode(data, 1)
 
 
 @pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (33, 128), (8, 4096)])
 def test_segment_and_window_sizes(emu, oracle, seg, win):
-    data = _data.mixed(50_000, seed=seg)
+    data = _data.mixed(25_000, seed=seg)
     out, _ = emu(data, seg=seg, win=win)
     assert out == oracle.encode(data, 1)
 
 
 @pytest.mark.parametrize("maker", ["zeros", "random", "p1", "p2", "p3", "p5"])
 def test_degenerate_inputs(emu, oracle, maker):
-    n = 40_000
+    n = 20_000
     data = {"zeros": lambda: _data.zeros_noise(n), "random": lambda: _data.random_bytes(n), "p1": lambda: _data.periodic(n, 1),
             "p2": lambda: _data.periodic(n, 2), "p3": lambda: _data.periodic(n, 3), "p5": lambda: _data.periodic(n, 5)}[maker]()
     out, _ = emu(data)
@@ -50,6 +50,6 @@ def test_degenerate_inputs(emu, oracle, maker):
 
 def test_ring_wraps_within_a_context(emu, oracle):
     # > 4094 items in one context: ring reuse, reduced offsets up to 4093 (src/matcher.rs:62-91)
-    data = (b"ab " * 7000) + _data.text(30_000, seed=4) + (b"ab " * 3000)
+    data = (b"ab " * 5000) + _data.text(12_000, seed=4) + (b"ab " * 1500)
     out, _ = emu(data)
     assert out == oracle.encode(data, 1)
