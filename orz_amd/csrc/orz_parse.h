@@ -394,10 +394,10 @@ struct ParseWave {
         // how many of this segment's earlier positions share my (ctx, hash) key / my words[] key:
         // their slots sit right below mine in the run and are this sweep's business, not older segments'
         uint32_t same = 0, samek = 0;
-        {
+        {   // keys travel lane to lane through v_readlane (an LDS scan of the 64 keys measured 2x slower)
             const uint32_t kmine = lane < nprobe ? s.keyL[lane] : 0xfffffffeu;
             const uint32_t kkmine = s.kkL[lane];                      // key of entry u = seg_start - 2 + lane
-            const uint32_t kkq = lane + 2 < nprobe + 2 ? s.kkL[lane + 2] : 0xfffffffeu;  // my lookup key
+            const uint32_t kkq = lane < nprobe ? s.kkL[lane + 2] : 0xfffffffeu;  // my words[] lookup key
             for (uint32_t y = 0; y < 64; y++) {
                 const uint64_t both = w.bcast64((uint64_t)kmine | ((uint64_t)kkmine << 32), y);
                 const uint32_t ky = (uint32_t)both, kky = (uint32_t)(both >> 32);
@@ -875,17 +875,30 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
     const uint32_t* part = a.partial + (size_t)a.par * nchunk * 256;
     if (s0 < wend) {
         uint32_t run = a.base[(size_t)(f % a.ring) * 256 + c];
-        for (uint32_t i = 0; i < chunk; i++) run += part[i * 256 + c];
-        uint32_t h[kRankChunk];
+        for (uint32_t i0 = 0; i0 < chunk; i0 += 16) {  // sixteen loads in flight a round
+            uint32_t v[16];
 #pragma unroll
-        for (uint32_t i = 0; i < kRankChunk; i++) h[i] = s0 + i < s1 ? a.hist[(size_t)((s0 + i) % a.ring) * 256 + c] : 0;
+            for (int k = 0; k < 16; k++) v[k] = i0 + k < chunk ? part[(i0 + k) * 256 + c] : 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) run += v[k];
+        }
+        uint32_t h[kRankChunk];
+        const uint32_t r0 = s0 % a.ring;  // ring rows of the chunk: r0, r0+1, ... wrapping once at most
+#pragma unroll
+        for (uint32_t i = 0; i < kRankChunk; i++) {
+            uint32_t r = r0 + i;
+            if (r >= a.ring) r -= a.ring;
+            h[i] = s0 + i < s1 ? a.hist[(size_t)r * 256 + c] : 0;
+        }
         rows[c] = run;
 #pragma unroll
         for (uint32_t i = 0; i < kRankChunk; i++) {
             if (s0 + i < s1) {
+                uint32_t r = r0 + i + 1;
+                if (r >= a.ring) r -= a.ring;
                 run += h[i];
                 rows[(i + 1) * 256 + c] = run;
-                a.base[(size_t)((s0 + i + 1) % a.ring) * 256 + c] = run;
+                a.base[(size_t)r * 256 + c] = run;
             }
         }
     }
@@ -893,6 +906,7 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
     if (s0 < wend) {
         const uint32_t x0 = kPre + s0 * a.seg;
         const uint32_t npos = (s1 - s0) * a.seg;
+        const uint64_t segmagic = 0x100000000ull / a.seg + 1;
         // eight positions per thread a round, loads of a round in flight together
         for (uint32_t i0 = c; i0 < npos; i0 += 256 * 8) {
             uint32_t j[8], ml[8], lr[8], cx[8];
@@ -910,7 +924,8 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t i = i0 + (uint32_t)k * 256;
-                if (ok[k] && ml[k] != 255) a.srec[j[k]].ord = rows[(i / a.seg) * 256 + cx[k]] + lr[k];
+                const uint32_t sgi = (uint32_t)(((uint64_t)i * segmagic) >> 32);  // == i / seg for i < 2^16
+                if (ok[k] && ml[k] != 255) a.srec[j[k]].ord = rows[sgi * 256 + cx[k]] + lr[k];
             }
         }
     }
