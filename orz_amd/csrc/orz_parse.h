@@ -36,6 +36,7 @@ constexpr uint32_t kNoChange = 0xffffffffu;
 constexpr uint32_t kRankChunk = 32;         // segments per rank-kernel block
 constexpr uint32_t kLbPre = 8;              // bytes staged in LDS before the segment start
 constexpr uint32_t kLbLen = 336;            // kLbPre + 64 + 240 + 8 rounded up to dwords: x+240+8 readable
+constexpr uint32_t kRecBatch = 8;           // slot records in flight per lane (8 x 32 B: register budget)
 constexpr uint32_t kCntSlack = 64;          // own items a segment can add to one context (robustness margin)
 
 struct SlotRec {  // one candidate-list slot: 32 bytes, half a cache line, fetched as one request
@@ -185,7 +186,7 @@ ORZ_D void rebuild_summaries(const uint64_t* L0, uint64_t* L1, uint64_t* L2, uin
 // `word` is the already loaded level-0 word of slot hi-1.  Older words are reached through the
 // summaries: only non-empty ones are loaded, four in flight a round.
 ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint64_t* L2, uint64_t word, uint64_t l1word,
-                             uint32_t hi, uint32_t lo, uint32_t D, uint32_t* out, uint32_t& nwords) {
+                             uint32_t hi, uint32_t lo, uint32_t D, uint32_t* out, uint32_t ostride, uint32_t& nwords) {
     uint32_t found = 0;
     if (hi <= lo) return 0;
     const uint32_t w0 = (hi - 1) >> 6, wmin = lo >> 6;
@@ -193,7 +194,7 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
     if ((w0 << 6) < lo) word &= ~0ull << (lo - (w0 << 6));
     while (word && found < D) {
         int bit = 63 - clz64(word);
-        out[found++] = (w0 << 6) + (uint32_t)bit;
+        out[ostride * found++] = (w0 << 6) + (uint32_t)bit;
         word &= ~(1ull << bit);
     }
     uint32_t u = w0 >> 6;
@@ -225,7 +226,7 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
                 if (i < nw && (ww[i] << 6) < lo) v &= ~0ull << (lo - (ww[i] << 6));
                 while (v && found < D) {
                     int bit = 63 - clz64(v);
-                    out[found++] = (ww[i] << 6) + (uint32_t)bit;
+                    out[ostride * found++] = (ww[i] << 6) + (uint32_t)bit;
                     v &= ~(1ull << bit);
                 }
             }
@@ -255,14 +256,14 @@ ORZ_D uint32_t dec_len(uint64_t d) { return (uint32_t)(d >> 25) & 0xff; }
 
 // byte offsets of the per-wave LDS arrays
 struct ParseLds {
-    uint32_t lb, cdat, dec, idxL, keyL, kkL, ownord, srcL, basec, cq, mlz;
+    uint32_t lb, cdat, dec, idxL, keyL, kkL, ownord, srcL, basec, mlz;
     uint32_t wg, ctxL, ncand, ownv, ownml, ownE, oldml, oldE, tyL, w0L, lrL, cnt, dbg, total;
-    ORZ_HD static ParseLds make(uint32_t dmax) {
+    ORZ_HD static ParseLds make(uint32_t dmax, bool prof = false) {
         ParseLds o;
         uint32_t at = 0;
         auto take = [&](uint32_t bytes) { uint32_t r = at; at += (bytes + 15) & ~15u; return r; };
         o.lb = take(kLbLen + 16);
-        o.cdat = take(kNPMax * dmax * 8);  // per candidate: ord | lcp << 32 | ml << 40
+        o.cdat = take(kNPMax * dmax * 8);  // per candidate: ro0 (16) | lcp << 16 | ml << 24 | pos << 32
         o.dec = take(kNPMax * 8);
         o.idxL = take(kNPMax * 4);
         o.keyL = take(kNPMax * 4);
@@ -270,7 +271,6 @@ struct ParseLds {
         o.ownord = take(kNPMax * 4);
         o.srcL = take(kNPMax * 4);
         o.basec = take(256 * 4);
-        o.cq = take(kNPMax * dmax * 4);    // candidate position (slot while the list is being built)
         o.mlz = take(kNPMax * 4);          // per position: what its list offers a lazy probe (see precompute)
         o.wg = take(kNPMax * 2);
         o.ctxL = take(kNPMax);
@@ -284,7 +284,7 @@ struct ParseLds {
         o.w0L = take(kNPMax);
         o.lrL = take(kNPMax);
         o.cnt = take(256);
-        o.dbg = take(64 * 8 * 4);          // profiling stamps of sampled waves
+        o.dbg = take(prof ? 64 * 8 * 4 : 0);  // profiling stamps of sampled waves
         o.total = at;
         return o;
     }
@@ -300,7 +300,7 @@ struct ParseWave {
         uint8_t* lb;
         uint64_t* cdat;
         uint64_t* dec;
-        uint32_t *idxL, *keyL, *kkL, *ownord, *srcL, *basec, *cq, *mlz;
+        uint32_t *idxL, *keyL, *kkL, *ownord, *srcL, *basec, *mlz;
         uint16_t* wg;
         uint8_t *ctxL, *ncand, *ownv, *ownml, *ownE, *oldml, *oldE, *tyL, *w0L, *lrL, *cnt;
     };
@@ -311,7 +311,7 @@ struct ParseWave {
         const uint32_t front = a.ctl->front[a.par];
         const uint32_t sg = front + w.block();
         if (sg >= a.nseg) return;
-        const ParseLds L = ParseLds::make(a.dmax);
+        const ParseLds L = ParseLds::make(a.dmax, a.prof & 1);
         uint8_t* lds = w.lds();
         Sh s;
         s.lb = lds + L.lb;  // lb[kLbPre + i] = win[seg_start + i]
@@ -323,7 +323,6 @@ struct ParseWave {
         s.ownord = (uint32_t*)(lds + L.ownord);
         s.srcL = (uint32_t*)(lds + L.srcL);
         s.basec = (uint32_t*)(lds + L.basec);
-        s.cq = (uint32_t*)(lds + L.cq);
         s.mlz = (uint32_t*)(lds + L.mlz);
         s.wg = (uint16_t*)(lds + L.wg);
         s.ctxL = lds + L.ctxL; s.ncand = lds + L.ncand; s.ownv = lds + L.ownv; s.ownml = lds + L.ownml;
@@ -427,26 +426,27 @@ struct ParseWave {
             uint32_t wsn = wantw ? (uint32_t)a.wsnap[kk * 2] | ((uint32_t)a.wsnap[kk * 2 + 1] << 8) : 0;
 
             uint32_t found = 0, nwords = 0;
-            uint32_t* mycq = s.cq + x * D;
+            uint64_t* mydat = s.cdat + x * D;
+            uint32_t* mycq = (uint32_t*)mydat;  // slot k waits in the low half of entry k until its record arrives
             if (prof) dbg[1] = (uint32_t)(w.clock() - tk1) + (uint32_t)(word & 0) + (uint32_t)(kword & 0) + (uint32_t)(l1word & 0) + (uint32_t)(kl1word & 0) + (lo & 0) + (klo & 0) + (wsn & 0);
-            found = collect_slots(a.vbits, a.v1, a.v2, word, l1word, hi, lo, D, mycq, nwords);
+            found = collect_slots(a.vbits, a.v1, a.v2, word, l1word, hi, lo, D, mycq, 2, nwords);
             if (prof) dbg[2] = (uint32_t)(w.clock() - tk1);
             uint32_t kslot = 0xffffffffu;
-            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, kl1word, khi, klo, 1, &kslot, nwords) == 0) kslot = 0xffffffffu;
+            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, kl1word, khi, klo, 1, &kslot, 1, nwords) == 0) kslot = 0xffffffffu;
             if (prof) { dbg[3] = (uint32_t)(w.clock() - tk1); dbg[7] = nwords; }
             // second round trip: the slot records (32 B each, text included), sixteen in flight
             const uint32_t ku = kslot != 0xffffffffu ? a.kpos[kslot] : 0;
             const uint8_t* px = s.lb + kLbPre + x;
             const uint64_t x0 = ldu64(px), x1 = ldu64(px + 8);
-            uint64_t* mydat = s.cdat + x * D;
-            for (uint32_t k0 = 0; k0 < found; k0 += 16) {
-                SlotRec r[16];
-                uint32_t l[16];
+            const uint32_t hc0 = s.basec[s.ctxL[x]];  // ring ordinal of an item starting here, before own items
+            for (uint32_t k0 = 0; k0 < found; k0 += kRecBatch) {
+                SlotRec r[kRecBatch];
+                uint32_t l[kRecBatch];
                 uint32_t act = 0;  // candidates whose common prefix is still growing
 #pragma unroll
-                for (int i = 0; i < 16; i++) r[i] = ld_rec(&a.srec[mycq[k0 + i < found ? k0 + i : k0]]);
+                for (int i = 0; i < (int)kRecBatch; i++) r[i] = ld_rec(&a.srec[mycq[2 * (k0 + i < found ? k0 + i : k0)]]);
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
+                for (int i = 0; i < (int)kRecBatch; i++) {
                     const uint64_t d0 = r[i].t0 ^ x0, d1 = r[i].t1 ^ x1;
                     if (d0) l[i] = (uint32_t)ctz64(d0) >> 3;
                     else if (d1) l[i] = 8 + ((uint32_t)ctz64(d1) >> 3);
@@ -459,7 +459,7 @@ struct ParseWave {
 #pragma unroll
                     for (int k = 0; k < 8; k++) xb[k] = ldu64(px + off + 8 * k);
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
+                    for (int i = 0; i < (int)kRecBatch; i++) {
                         if (act & (1u << i)) {
                             const uint8_t* qa = b + r[i].pos + off;
                             uint64_t d[8];
@@ -475,11 +475,13 @@ struct ParseWave {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
+                for (int i = 0; i < (int)kRecBatch; i++) {
                     if (k0 + i < found) {
                         const uint32_t ll = r[i].ml == 255 ? 0 : l[i];
-                        mycq[k0 + i] = r[i].pos;
-                        mydat[k0 + i] = (uint64_t)r[i].ord | ((uint64_t)ll << 32) | ((uint64_t)(r[i].ml & 0xff) << 40);
+                        const uint32_t ro = hc0 - 1 - r[i].ord;  // reduced offset if no own item intervenes
+                        const uint32_t ro16 = ro < 0xffffu ? ro : 0xffffu;  // saturated: far outside the 4094-ring
+                        mydat[k0 + i] = (uint64_t)ro16 | ((uint64_t)ll << 16) | ((uint64_t)(r[i].ml & 0xff) << 24) |
+                                        ((uint64_t)r[i].pos << 32);
                     }
                 }
             }
@@ -675,36 +677,36 @@ struct ParseWave {
         const uint8_t* px = s.lb + kLbPre + x;
         const uint32_t p = seg_start + x;
         const uint32_t c = s.ctxL[x];
-        const uint32_t hcnt = s.basec[c] + s.cnt[c];
-        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0, nmain = 0, n1 = 0, n2 = 0, M1 = 0, M2 = 0;
+        const uint32_t cnt0 = s.cnt[c];  // 0 while the lanes precompute
+        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, bestro = 0, nmain = 0, n1 = 0, n2 = 0, M1 = 0, M2 = 0;
         bool rmain = true, r1 = true, r2 = true, stop_main = false, stop_all = false;
         const uint32_t nc = s.ncand[x];
         const uint64_t* dat = s.cdat + x * D;
         for (uint32_t k0 = 0; k0 < nc && !stop_all; k0 += 16) {
             uint64_t cdv[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 24);
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const uint64_t cd = cdv[i];
-                const uint32_t ml = (uint32_t)(cd >> 40) & 0xff;
+                const uint32_t ml = (uint32_t)(cd >> 24) & 0xff;
                 if (stop_all || ml == 255) continue;
-                const uint32_t oq = (uint32_t)cd;
-                const uint32_t ro = hcnt - 1 - oq;
+                const uint32_t ro0 = (uint32_t)cd & 0xffff;
+                const uint32_t ro = ro0 == 0xffff ? 0x7fffffffu : ro0 + cnt0;
                 const bool near = ro <= kRing - 1 && ro + kCntSlack > kRing - 1;
                 const bool want_main = !stop_main && nmain < a.depth, want1 = n1 < a.lazy1, want2 = n2 < a.lazy2;
                 if (near) { if (want_main) rmain = false; if (want1) r1 = false; if (want2) r2 = false; }
                 if (ro > kRing - 1) { stop_all = true; continue; }
-                const uint32_t l = (uint32_t)(cd >> 32) & 0xff;
+                const uint32_t l = (uint32_t)(cd >> 16) & 0xff;
                 if (want1) { n1++; if (l > M1) M1 = l; }
                 if (want2) { n2++; if (l > M2) M2 = l; }
                 if (want_main) {
                     nmain++;
                     if (l > max_len) {
-                        mlexp = ml; max_len = l; bestq = s.cq[x * D + k0 + i]; besto = oq;
+                        mlexp = ml; max_len = l; bestq = (uint32_t)(cd >> 32); bestro = ro;
                         if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop_main = true;
                     } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
-                        if (ldu32(b + s.cq[x * D + k0 + i] + max_len - 3) == ldu32(px + max_len - 3)) stop_main = true;
+                        if (ldu32(b + (uint32_t)(cd >> 32) + max_len - 3) == ldu32(px + max_len - 3)) stop_main = true;
                     }
                 } else {
                     stop_main = true;
@@ -718,9 +720,8 @@ struct ParseWave {
         uint64_t d = (uint64_t)bestq | ((uint64_t)max_len << 25);
         if (is_match) {
             d |= kDecMatch;
-            const uint32_t ro = hcnt - 1 - besto;
-            const bool bl = roid_bitlen(ro) < 8;
-            if (bl != (roid_bitlen(ro + kCntSlack) < 8)) rmain = false;
+            const bool bl = roid_bitlen(bestro) < 8;
+            if (bl != (roid_bitlen(bestro + kCntSlack) < 8)) rmain = false;
             if (bl) d |= kDecBl;
         }
         if (rmain) d |= kDecRobust;
@@ -741,7 +742,8 @@ struct ParseWave {
         const uint32_t hcnt = s.basec[c] + s.cnt[c];
         bool robust = true;
         // find_match, src/matcher.rs:135-192
-        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, besto = 0, cntv = 0;
+        const uint32_t cntc = s.cnt[c];
+        uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, bestro = 0, cntv = 0;
         bool stop = false;
         for (uint64_t m = m0; m && !stop;) {
             const uint32_t y = 63 - (uint32_t)clz64(m);
@@ -751,7 +753,7 @@ struct ParseWave {
             cntv++;
             const uint32_t l = lcp240u(s.lb + kLbPre + y, px);
             if (l > max_len) {
-                mlexp = s.ownml[y]; max_len = l; bestq = seg_start + y; besto = oq;
+                mlexp = s.ownml[y]; max_len = l; bestq = seg_start + y; bestro = hcnt - 1 - oq;
                 if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop = true;
             } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
                 if (ldu32(s.lb + kLbPre + y + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
@@ -762,25 +764,25 @@ struct ParseWave {
         for (uint32_t k0 = 0; k0 < nc && !stop; k0 += 16) {
             uint64_t cdv[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 24);
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const uint64_t cd = cdv[i];
-                const uint32_t ml = (uint32_t)(cd >> 40) & 0xff;
+                const uint32_t ml = (uint32_t)(cd >> 24) & 0xff;
                 if (stop || ml == 255) continue;
-                const uint32_t oq = (uint32_t)cd;
-                const uint32_t ro = hcnt - 1 - oq;
+                const uint32_t ro0 = (uint32_t)cd & 0xffff;
+                const uint32_t ro = ro0 == 0xffff ? 0x7fffffffu : ro0 + cntc;
                 if (check && ro <= kRing - 1 && ro + kCntSlack > kRing - 1) robust = false;
                 if (ro > kRing - 1 || cntv >= a.depth) { stop = true; continue; }
                 cntv++;
-                const uint32_t l = (uint32_t)(cd >> 32) & 0xff;
+                const uint32_t l = (uint32_t)(cd >> 16) & 0xff;
                 if (l > max_len) {
-                    mlexp = ml; max_len = l; bestq = s.cq[x * D + k0 + i]; besto = oq;
+                    mlexp = ml; max_len = l; bestq = (uint32_t)(cd >> 32); bestro = ro;
                     if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop = true;
                 } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
                     // the reference's 4-byte prefilter can pass by chance past the mismatch; it then
                     // leaves the walk without a better match (src/matcher.rs:150-168)
-                    if (ldu32(b + s.cq[x * D + k0 + i] + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
+                    if (ldu32(b + (uint32_t)(cd >> 32) + max_len - 3) == ldu32(px + max_len - 3)) stop = true;
                 }
             }
         }
@@ -788,9 +790,8 @@ struct ParseWave {
         uint64_t d = (uint64_t)bestq | ((uint64_t)max_len << 25);
         if (is_match) d |= kDecMatch;
         if (is_match && max_len < kMaxLen / 2) {  // src/lz.rs:151-170
-            const uint32_t ro = hcnt - 1 - besto;
-            if (check && (roid_bitlen(ro) < 8) != (roid_bitlen(ro + kCntSlack) < 8)) robust = false;
-            const uint32_t l1 = max_len + 1 + (roid_bitlen(ro) < 8);
+            if (check && (roid_bitlen(bestro) < 8) != (roid_bitlen(bestro + kCntSlack) < 8)) robust = false;
+            const uint32_t l1 = max_len + 1 + (roid_bitlen(bestro) < 8);
             if (has_lazy(s, m1, x + 1, l1, a.lazy1, check, robust)) {
                 d |= kDecLazy1;
             } else if (lwm == 2) {
@@ -825,17 +826,18 @@ struct ParseWave {
         for (uint32_t k0 = 0; k0 < nc; k0 += 16) {
             uint64_t cdv[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 40);
+            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 24);
             int res = -1;  // -1 undecided, 0 false, 1 true
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const uint64_t cd = cdv[i];
-                if (res >= 0 || ((uint32_t)(cd >> 40) & 0xff) == 255) continue;
-                const uint32_t ro = hx - 1 - (uint32_t)cd;
+                if (res >= 0 || ((uint32_t)(cd >> 24) & 0xff) == 255) continue;
+                const uint32_t ro0 = (uint32_t)cd & 0xffff;
+                const uint32_t ro = ro0 == 0xffff ? 0x7fffffffu : ro0 + s.cnt[cx];
                 if (check && ro <= kRing - 1 && ro + kCntSlack > kRing - 1) robust = false;
                 if (ro > kRing - 1 || cntv >= depth) { res = 0; continue; }
                 cntv++;
-                if (((uint32_t)(cd >> 32) & 0xff) >= min_len) res = 1;
+                if (((uint32_t)(cd >> 16) & 0xff) >= min_len) res = 1;
             }
             if (res >= 0) return res == 1;
         }

@@ -367,7 +367,7 @@ class StreamEncoder {
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
-        const size_t lds_bytes = ParseLds::make(dmax_).total;
+        const size_t lds_bytes = ParseLds::make(dmax_, pa.prof & 1).total;
         const uint32_t grid = std::min(wsegs_, nseg);
         uint32_t par = 0, front = 0, batch = 8;
         uint64_t sweeps = 0;
