@@ -875,15 +875,24 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
     const uint32_t s0 = f + chunk * kRankChunk;
     const uint32_t s1 = s0 + kRankChunk < wend ? s0 + kRankChunk : wend;
     const uint32_t* part = a.partial + (size_t)a.par * nchunk * 256;
-    if (s0 < wend) {
+    const bool live = s0 < wend;
+    // everything below is arranged as three rounds of independent loads: (1) ordinal inputs and the
+    // chunk's positions, (2) their slot records, then the barrier, then only stores
+    const uint32_t x0 = kPre + s0 * a.seg;
+    const uint32_t npos = live ? (s1 - s0) * a.seg : 0;  // <= 32 * 62 = 1984 <= 8 positions per thread
+    const uint64_t segmagic = 0x100000000ull / a.seg + 1;
+    uint32_t j[8], ml[8], lr[8], cx[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t i = c + (uint32_t)k * 256, x = x0 + i;
+        ok[k] = i < npos && x < a.len;
+        j[k] = ok[k] ? a.idx[x] : 0;
+        lr[k] = ok[k] ? a.LR[x] : 0;
+        cx[k] = ok[k] ? hash1(a.win, x - 1) : 0;
+    }
+    if (live) {
         uint32_t run = a.base[(size_t)(f % a.ring) * 256 + c];
-        for (uint32_t i0 = 0; i0 < chunk; i0 += 16) {  // sixteen loads in flight a round
-            uint32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = i0 + k < chunk ? part[(i0 + k) * 256 + c] : 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) run += v[k];
-        }
         uint32_t h[kRankChunk];
         const uint32_t r0 = s0 % a.ring;  // ring rows of the chunk: r0, r0+1, ... wrapping once at most
 #pragma unroll
@@ -892,6 +901,15 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
             if (r >= a.ring) r -= a.ring;
             h[i] = s0 + i < s1 ? a.hist[(size_t)r * 256 + c] : 0;
         }
+        for (uint32_t i0 = 0; i0 < chunk; i0 += 64) {  // sums of the chunks before mine, 64 loads in flight
+            uint32_t v[64];
+#pragma unroll
+            for (int k = 0; k < 64; k++) v[k] = i0 + k < chunk ? part[(i0 + k) * 256 + c] : 0;
+#pragma unroll
+            for (int k = 0; k < 64; k++) run += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) ml[k] = ok[k] ? a.srec[j[k]].ml : 255u;
         rows[c] = run;
 #pragma unroll
         for (uint32_t i = 0; i < kRankChunk; i++) {
@@ -905,30 +923,12 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
         }
     }
     sync();
-    if (s0 < wend) {
-        const uint32_t x0 = kPre + s0 * a.seg;
-        const uint32_t npos = (s1 - s0) * a.seg;
-        const uint64_t segmagic = 0x100000000ull / a.seg + 1;
-        // eight positions per thread a round, loads of a round in flight together
-        for (uint32_t i0 = c; i0 < npos; i0 += 256 * 8) {
-            uint32_t j[8], ml[8], lr[8], cx[8];
-            bool ok[8];
+    if (live) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t i = i0 + (uint32_t)k * 256, x = x0 + i;
-                ok[k] = i < npos && x < a.len;
-                j[k] = ok[k] ? a.idx[x] : 0;
-                lr[k] = ok[k] ? a.LR[x] : 0;
-                cx[k] = ok[k] ? hash1(a.win, x - 1) : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) ml[k] = ok[k] ? a.srec[j[k]].ml : 255u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t i = i0 + (uint32_t)k * 256;
-                const uint32_t sgi = (uint32_t)(((uint64_t)i * segmagic) >> 32);  // == i / seg for i < 2^16
-                if (ok[k] && ml[k] != 255) a.srec[j[k]].ord = rows[sgi * 256 + cx[k]] + lr[k];
-            }
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = c + (uint32_t)k * 256;
+            const uint32_t sgi = (uint32_t)(((uint64_t)i * segmagic) >> 32);  // == i / seg for i < 2^16
+            if (ok[k] && ml[k] != 255) a.srec[j[k]].ord = rows[sgi * 256 + cx[k]] + lr[k];
         }
     }
     // re-arm the other parity's accumulators for the next sweep (nobody reads them in this launch)
