@@ -32,9 +32,9 @@ def test_sweep_order_does_not_matter(emu, oracle, order):
     assert out == oracle.encode(data, 1)
 
 
-@pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (33, 128), (8, 4096)])
+@pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (33, 128), (8, 600)])
 def test_segment_and_window_sizes(emu, oracle, seg, win):
-    data = _data.mixed(25_000, seed=seg)
+    data = _data.mixed(25_000 if seg > 16 else 8_000, seed=seg)
     out, _ = emu(data, seg=seg, win=win)
     assert out == oracle.encode(data, 1)
 
