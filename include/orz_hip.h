@@ -123,6 +123,20 @@ int orz_stream_set_item_trace(orz_stream*, int on);
 /* copies up to cap items to out, returns the total number traced (or a negative error) */
 long orz_stream_get_item_trace(orz_stream*, orz_item* out, size_t cap);
 
+/* ---- many members per GPU (independent chunks, each a complete orz stream) ------------
+ * A stream does not shard (its model state is one adaptive chain), so throughput beyond one stream
+ * comes from encoding independent members concurrently: `jobs` stream encoders on one device, each fed
+ * members of `member_bytes` input bytes by its own host thread.  The output is the members' streams
+ * concatenated in input order; every member ends with its own EOF chunk, so the reference decoder reads
+ * each piece (orz_decode_members_mem / `orz decode --members` loop over them). */
+typedef struct orz_members orz_members;
+orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs);
+void orz_members_free(orz_members*);
+int orz_members_encode(orz_members*, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
+                       size_t* dst_len, size_t* n_members_out);
+/* decodes every stream of a concatenation (a plain single stream is the 1-member case) */
+int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* n_members_out);
+
 int orz_device_count(void);
 const char* orz_last_error(void);
 const char* orz_version(void);

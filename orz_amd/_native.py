@@ -96,6 +96,20 @@ SYMBOLS = [
          ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(EncodeStats)],
     ),
     ("orz_free", None, [ctypes.c_void_p]),
+    ("orz_members_new", ctypes.c_void_p, [ctypes.c_int, ctypes.POINTER(LZCfg), ctypes.c_int]),
+    ("orz_members_free", None, [ctypes.c_void_p]),
+    (
+        "orz_members_encode",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
+         ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
+    ),
+    (
+        "orz_decode_members_mem",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t),
+         ctypes.POINTER(ctypes.c_size_t)],
+    ),
     ("orz_stream_set_item_trace", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("orz_stream_get_item_trace", ctypes.c_long, [ctypes.c_void_p, ctypes.POINTER(Item), ctypes.c_size_t]),
     ("orz_device_count", ctypes.c_int, []),

@@ -139,6 +139,65 @@ def encode(src, dst, cfg, progress=None, device=0):
     return tuple(counts)
 
 
+class MemberEncoder:
+    """`jobs` stream encoders on one GPU; encode() cuts the input into members of `member_bytes`, encodes
+    them concurrently (one host thread per encoder inside the library) and returns the members' streams
+    concatenated in order -- each a complete orz stream the reference decoder reads."""
+
+    def __init__(self, device=0, level=1, jobs=4):
+        self._lib = _native.load()
+        self.cfg = cfg_for_level(level)
+        self._h = self._lib.orz_members_new(int(device), ctypes.byref(self.cfg), int(jobs))
+        if not self._h:
+            raise OrzError("orz_members_new failed: " + _native.last_error())
+
+    def _run(self, ptr, n, on_device, member_bytes):
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        dlen, nm = ctypes.c_size_t(), ctypes.c_size_t()
+        rc = self._lib.orz_members_encode(self._h, ptr, n, 1 if on_device else 0, int(member_bytes), ctypes.byref(dst),
+                                          ctypes.byref(dlen), ctypes.byref(nm))
+        _check(rc, "orz_members_encode")
+        try:
+            return ctypes.string_at(dst, dlen.value), nm.value
+        finally:
+            self._lib.orz_free(dst)
+
+    def encode(self, data, member_bytes=1 << 24):
+        data = bytes(data)
+        buf = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
+        return self._run(ctypes.cast(buf, ctypes.c_void_p), len(data), False, member_bytes)
+
+    def encode_device(self, dev_ptr, nbytes, member_bytes=1 << 24):
+        return self._run(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, member_bytes)
+
+    def close(self):
+        if self._h:
+            self._lib.orz_members_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_members(container):
+    """decode every stream of a concatenation of orz streams -> (bytes, n_members)"""
+    lib = _native.load()
+    container = bytes(container)
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n, nm = ctypes.c_size_t(), ctypes.c_size_t()
+    buf = ctypes.create_string_buffer(container, len(container)) if container else ctypes.create_string_buffer(1)
+    rc = lib.orz_decode_members_mem(ctypes.cast(buf, ctypes.c_void_p), len(container), ctypes.byref(dst), ctypes.byref(n),
+                                    ctypes.byref(nm))
+    _check(rc, "orz_decode_members_mem")
+    try:
+        return ctypes.string_at(dst, n.value), nm.value
+    finally:
+        lib.orz_free(dst)
+
+
 def decode_bytes(stream):
     """orz stream -> (bytes, consumed).  Host decoder of the library (orz::decode, src/lib.rs:94-129);
     stops after the first stream's EOF chunk like the reference."""

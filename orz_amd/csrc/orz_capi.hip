@@ -8,6 +8,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/orz_hip.h"
@@ -185,6 +187,95 @@ long orz_stream_get_item_trace(orz_stream* s, orz_item* out, size_t cap) {
         out[i] = it;
     }
     return (long)n;
+}
+
+// ------------------------------------------------------------------------------ members
+struct orz_members {
+    std::vector<orz_stream*> workers;
+};
+orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs) {
+    if (!cfg_ok(cfg) || jobs < 1 || jobs > 64) { fail(ORZ_EINVAL, "bad argument"); return nullptr; }
+    std::unique_ptr<orz_members> m(new orz_members);
+    for (int i = 0; i < jobs; i++) {
+        orz_stream* s = orz_stream_new(device, cfg);
+        if (!s) { for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
+        if (jobs > 1) {  // several streams share the GPU: a smaller speculative window each (same bytes out)
+            s->win = env_u("ORZ_MEMBER_WIN", 1024);
+            try { s->rebuild(); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
+        }
+        m->workers.push_back(s);
+    }
+    return m.release();
+}
+void orz_members_free(orz_members* m) {
+    if (!m) return;
+    for (orz_stream* w : m->workers) orz_stream_free(w);
+    delete m;
+}
+int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
+                       size_t* dst_len, size_t* n_members_out) {
+    if (!m || !dst || !dst_len || (!src && n) || member_bytes == 0) return fail(ORZ_EINVAL, "bad argument");
+    const size_t nm = n == 0 ? 1 : (n + member_bytes - 1) / member_bytes;
+    std::vector<std::vector<uint8_t>> outs(nm);
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc{ORZ_OK};
+    std::string err;
+    auto work = [&](orz_stream* s) {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nm || rc.load() != ORZ_OK) return;
+            const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
+            try {
+                orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
+            } catch (const std::exception& e) {
+                int expect = ORZ_OK;
+                if (rc.compare_exchange_strong(expect, ORZ_ENODEV)) err = e.what();
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < m->workers.size(); i++) th.emplace_back(work, m->workers[i]);
+    work(m->workers[0]);
+    for (auto& t : th) t.join();
+    if (rc.load() != ORZ_OK) return fail(rc.load(), err);
+    size_t total = 0;
+    for (auto& o : outs) total += o.size();
+    uint8_t* p = (uint8_t*)std::malloc(total ? total : 1);
+    if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+    size_t at = 0;
+    for (auto& o : outs) { std::memcpy(p + at, o.data(), o.size()); at += o.size(); }
+    *dst = p;
+    *dst_len = total;
+    if (n_members_out) *n_members_out = nm;
+    return ORZ_OK;
+}
+int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* n_members_out) {
+    if ((!src && n) || !dst || !dst_len) return fail(ORZ_EINVAL, "bad argument");
+    try {
+        std::vector<uint8_t> out;
+        size_t at = 0, members = 0;
+        while (at < n) {
+            orz::host::decode_stream(
+                [&](uint8_t* buf, size_t k) {
+                    if (at + k > n) return false;
+                    std::memcpy(buf, src + at, k);
+                    at += k;
+                    return true;
+                },
+                [&](const uint8_t* buf, size_t k) { out.insert(out.end(), buf, buf + k); }, [](bool, size_t, size_t) {});
+            members++;
+        }
+        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+        std::memcpy(p, out.data(), out.size());
+        *dst = p;
+        *dst_len = out.size();
+        if (n_members_out) *n_members_out = members;
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
 }
 
 // ------------------------------------------------------------------------------ orz_lz_encoder

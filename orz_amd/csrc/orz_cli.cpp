@@ -2,7 +2,10 @@
 // Same grammar as the reference binary (/root/reference/src/main.rs:21-52,97-113):
 //   orz encode [-s|--silent] [-l|--level 0..2 (default 2)] [source] [target]
 //   orz decode [-s|--silent] [source] [target]
-// source/target default to stdin/stdout.  Additive flag: --device N (HIP device of the encoder).
+// source/target default to stdin/stdout.  Additive flags: --device N (HIP device of the encoder);
+//   encode --member-size BYTES [--jobs J]: cut the input into independent members (complete orz streams,
+//   concatenated) and encode J of them concurrently on the GPU;  decode --members: decode every stream of
+//   such a concatenation (the reference, and the default here, stop after the first stream).
 // Progress lines mirror SimpleProgressLogger (src/progress.rs:48-98) on stderr.
 #include <cerrno>
 #include <chrono>
@@ -55,7 +58,9 @@ int main(int argc, char** argv) {
     const std::string cmd = argv[1];
     if (cmd != "encode" && cmd != "decode") return usage();
     bool silent = false;
-    long level = 2, device = 0;
+    long level = 2, device = 0, jobs = 4;
+    long long member_size = 0;
+    bool all_members = false;
     std::vector<std::string> pos;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -64,6 +69,9 @@ int main(int argc, char** argv) {
         else if (cmd == "encode" && a.rfind("--level=", 0) == 0) level = strtol(a.c_str() + 8, nullptr, 10);
         else if (cmd == "encode" && a.rfind("-l", 0) == 0 && a.size() > 2) level = strtol(a.c_str() + 2, nullptr, 10);
         else if (cmd == "encode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }
+        else if (cmd == "encode" && a == "--member-size") { if (++i >= argc) return usage(); member_size = strtoll(argv[i], nullptr, 10); }
+        else if (cmd == "encode" && a == "--jobs") { if (++i >= argc) return usage(); jobs = strtol(argv[i], nullptr, 10); }
+        else if (cmd == "decode" && a == "--members") all_members = true;
         else if (a.size() > 1 && a[0] == '-' ) return usage();
         else pos.push_back(a);
     }
@@ -79,10 +87,43 @@ int main(int argc, char** argv) {
             fprintf(stderr, "Error: \"invalid level: %ld\"\n", level);
             return 1;
         }
-        rc = orz_encode(rd, &io, wr, &io, &cfg, silent ? nullptr : progress, &pg, (int)device);
+        if (member_size > 0) {
+            orz_members* m = orz_members_new((int)device, &cfg, (int)jobs);
+            if (!m) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
+            std::vector<uint8_t> buf((size_t)member_size * (size_t)jobs);
+            size_t in_total = 0, out_total = 0;
+            bool any = false;
+            rc = ORZ_OK;
+            for (;;) {
+                size_t got = fread(buf.data(), 1, buf.size(), io.in);
+                if (got == 0 && any) break;
+                uint8_t* out = nullptr;
+                size_t out_len = 0;
+                rc = orz_members_encode(m, buf.data(), got, 0, (size_t)member_size, &out, &out_len, nullptr);
+                if (rc != ORZ_OK) break;
+                if (fwrite(out, 1, out_len, io.out) != out_len) rc = ORZ_EIO;
+                orz_free(out);
+                if (rc != ORZ_OK) break;
+                any = true;
+                in_total += got;
+                out_total += out_len;
+                if (!silent) progress(&pg, 0, in_total, out_total);
+                if (got < buf.size()) break;
+            }
+            orz_members_free(m);
+            if (rc == ORZ_OK && !silent) progress(&pg, 1, in_total, out_total);
+        } else {
+            rc = orz_encode(rd, &io, wr, &io, &cfg, silent ? nullptr : progress, &pg, (int)device);
+        }
         if (rc != ORZ_OK) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
     } else {
-        rc = orz_decode(rd, &io, wr, &io, silent ? nullptr : progress, &pg);
+        for (;;) {
+            rc = orz_decode(rd, &io, wr, &io, silent ? nullptr : progress, &pg);
+            if (rc != ORZ_OK || !all_members) break;
+            int c = fgetc(io.in);  // another member behind this stream's EOF chunk?
+            if (c == EOF) break;
+            ungetc(c, io.in);
+        }
         if (rc != ORZ_OK) { fprintf(stderr, "Error: \"decoding failed: %s\"\n", orz_last_error()); return 1; }
     }
     if (fflush(io.out) != 0) { fprintf(stderr, "Error: write failed\n"); return 1; }

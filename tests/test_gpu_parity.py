@@ -165,3 +165,32 @@ def test_gpu_stream_decodes_with_product_decoder(gpu_encoder_factory):
     data = _data.text(2_000_000, seed=91)
     out = gpu_encoder_factory(2).encode(data)
     assert orz_amd.decode_bytes(out)[0] == data
+
+
+def test_members_concurrent_on_one_gpu(oracle, tmp_path):
+    """independent members encoded concurrently (3 encoders, one GPU): every member is exactly the stream the
+    oracle produces for that slice, and the container decodes back to the input"""
+    import subprocess
+
+    import orz_amd
+    from orz_amd import dist as od
+
+    data = _data.mixed(22_000_000, seed=111)
+    member = 6_000_000
+    enc = orz_amd.MemberEncoder(device=0, level=1, jobs=3)
+    try:
+        container, nm = enc.encode(data, member_bytes=member)
+    finally:
+        enc.close()
+    pieces = od.split_members(container)
+    assert nm == len(pieces) == 4
+    for i, p in enumerate(pieces):
+        assert p == oracle.encode(data[i * member:(i + 1) * member], 1)
+    assert orz_amd.decode_members(container) == (data, 4)
+    # the same through the command line
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "orz")
+    src, encf, decf = tmp_path / "in.bin", tmp_path / "in.orz", tmp_path / "out.bin"
+    src.write_bytes(data[:9_000_000])
+    subprocess.check_call([cli, "encode", "-s", "-l1", "--member-size", "4000000", "--jobs", "2", str(src), str(encf)])
+    subprocess.check_call([cli, "decode", "-s", "--members", str(encf), str(decf)])
+    assert decf.read_bytes() == data[:9_000_000]

@@ -97,3 +97,21 @@ def test_cli_decode_and_errors(oracle, tmp_path):
     assert r.returncode != 0 and b"invalid level" in r.stderr
     r = subprocess.run([CLI, "decode", str(dst), str(tmp_path / "y")], stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"decoding failed" in r.stderr
+
+
+def test_member_container_decode(oracle, tmp_path):
+    """concatenated complete streams: decode_members / `orz decode --members` read all of them, the plain
+    decoder stops after the first like the reference (src/lib.rs:108-110)"""
+    import orz_amd
+
+    parts = [_data.mixed(40_000, seed=100 + i) for i in range(3)] + [b""]
+    container = b"".join(oracle.encode(p, 1) for p in parts)
+    out, nm = orz_amd.decode_members(container)
+    assert nm == 4 and out == b"".join(parts)
+    assert orz_amd.decode_bytes(container)[0] == parts[0]
+    src, dst = tmp_path / "m.orz", tmp_path / "m.out"
+    src.write_bytes(container)
+    subprocess.check_call([CLI, "decode", "-s", "--members", str(src), str(dst)])
+    assert dst.read_bytes() == b"".join(parts)
+    subprocess.check_call([CLI, "decode", "-s", str(src), str(dst)])
+    assert dst.read_bytes() == parts[0]
