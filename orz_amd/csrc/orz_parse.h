@@ -439,6 +439,7 @@ struct ParseWave {
             const uint8_t* px = s.lb + kLbPre + x;
             const uint64_t x0 = ldu64(px), x1 = ldu64(px + 8);
             const uint32_t hc0 = s.basec[s.ctxL[x]];  // ring ordinal of an item starting here, before own items
+            Pre pre;
             for (uint32_t k0 = 0; k0 < found; k0 += kRecBatch) {
                 SlotRec r[kRecBatch];
                 uint32_t l[kRecBatch];
@@ -482,11 +483,13 @@ struct ParseWave {
                         const uint32_t ro16 = ro < 0xffffu ? ro : 0xffffu;  // saturated: far outside the 4094-ring
                         mydat[k0 + i] = (uint64_t)ro16 | ((uint64_t)ll << 16) | ((uint64_t)(r[i].ml & 0xff) << 24) |
                                         ((uint64_t)r[i].pos << 32);
+                        pre_feed(pre, b, px, ro16, ll, r[i].ml & 0xff, r[i].pos);
                     }
                 }
             }
             if (prof) dbg[4] = (uint32_t)(w.clock() - tk1);
             s.ncand[x] = (uint8_t)found;
+            pre_finish(pre, s, seg_start, x, x < npos);
             if (wantw) {
                 if (kslot != 0xffffffffu) wsn = (uint32_t)b[ku] | ((uint32_t)b[ku + 1] << 8);
                 s.wg[x] = (uint16_t)wsn;
@@ -498,7 +501,6 @@ struct ParseWave {
         // ---- phase 2a: every position decides, on its own lane, what the item starting there would be
         // if the segment's own earlier items do not interfere (no same-key item, no words[] update of
         // its key, ring ordinals within kCntSlack of no threshold): kDecRobust marks those decisions.
-        if (lane < nprobe && seg_start + lane < a.len) precompute(s, b, seg_start, lane, lane < npos);
         uint32_t p, lt;
         if (sg == 0) {
             p = kPre;
@@ -671,60 +673,48 @@ struct ParseWave {
     // own items interfere: (a) find_match for an item starting here -> dec[x]; (b) what the list offers a
     // lazy probe AT this position: the longest common prefix among its first lazy1 / lazy2 ring members
     // (has_lazy_match(min_len) <=> that maximum >= min_len) -> mlz[x].  Robust bits: the result does not
-    // change for any own-item count in [0, kCntSlack].
-    ORZ_D void precompute(const Sh& s, const uint8_t* b, uint32_t seg_start, uint32_t x, bool item_start) const {
-        const uint32_t D = a.dmax;
-        const uint8_t* px = s.lb + kLbPre + x;
-        const uint32_t p = seg_start + x;
-        const uint32_t c = s.ctxL[x];
-        const uint32_t cnt0 = s.cnt[c];  // 0 while the lanes precompute
+    // change for any own-item count in [0, kCntSlack].  Candidates are fed newest first, straight from
+    // the registers of phase 1.
+    struct Pre {
         uint32_t max_len = kMinLen - 1, mlexp = kMinLen, bestq = 0, bestro = 0, nmain = 0, n1 = 0, n2 = 0, M1 = 0, M2 = 0;
         bool rmain = true, r1 = true, r2 = true, stop_main = false, stop_all = false;
-        const uint32_t nc = s.ncand[x];
-        const uint64_t* dat = s.cdat + x * D;
-        for (uint32_t k0 = 0; k0 < nc && !stop_all; k0 += 16) {
-            uint64_t cdv[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) cdv[i] = k0 + i < nc ? dat[k0 + i] : (255ull << 24);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint64_t cd = cdv[i];
-                const uint32_t ml = (uint32_t)(cd >> 24) & 0xff;
-                if (stop_all || ml == 255) continue;
-                const uint32_t ro0 = (uint32_t)cd & 0xffff;
-                const uint32_t ro = ro0 == 0xffff ? 0x7fffffffu : ro0 + cnt0;
-                const bool near = ro <= kRing - 1 && ro + kCntSlack > kRing - 1;
-                const bool want_main = !stop_main && nmain < a.depth, want1 = n1 < a.lazy1, want2 = n2 < a.lazy2;
-                if (near) { if (want_main) rmain = false; if (want1) r1 = false; if (want2) r2 = false; }
-                if (ro > kRing - 1) { stop_all = true; continue; }
-                const uint32_t l = (uint32_t)(cd >> 16) & 0xff;
-                if (want1) { n1++; if (l > M1) M1 = l; }
-                if (want2) { n2++; if (l > M2) M2 = l; }
-                if (want_main) {
-                    nmain++;
-                    if (l > max_len) {
-                        mlexp = ml; max_len = l; bestq = (uint32_t)(cd >> 32); bestro = ro;
-                        if (l == kMaxLen || (mlexp > 0 && l > mlexp)) stop_main = true;
-                    } else if (l + 3 < max_len && mlexp > 0 && l > mlexp) {
-                        if (ldu32(b + (uint32_t)(cd >> 32) + max_len - 3) == ldu32(px + max_len - 3)) stop_main = true;
-                    }
-                } else {
-                    stop_main = true;
-                }
-                if (stop_main && !want1 && !want2) stop_all = true;
+    };
+    ORZ_D void pre_feed(Pre& q, const uint8_t* b, const uint8_t* px, uint32_t ro16, uint32_t l, uint32_t ml, uint32_t pos) const {
+        if (q.stop_all || ml == 255) return;
+        const uint32_t ro = ro16 == 0xffff ? 0x7fffffffu : ro16;
+        const bool near = ro <= kRing - 1 && ro + kCntSlack > kRing - 1;
+        const bool want_main = !q.stop_main && q.nmain < a.depth, want1 = q.n1 < a.lazy1, want2 = q.n2 < a.lazy2;
+        if (near) { if (want_main) q.rmain = false; if (want1) q.r1 = false; if (want2) q.r2 = false; }
+        if (ro > kRing - 1) { q.stop_all = true; return; }
+        if (want1) { q.n1++; if (l > q.M1) q.M1 = l; }
+        if (want2) { q.n2++; if (l > q.M2) q.M2 = l; }
+        if (want_main) {
+            q.nmain++;
+            if (l > q.max_len) {
+                q.mlexp = ml; q.max_len = l; q.bestq = pos; q.bestro = ro;
+                if (l == kMaxLen || (q.mlexp > 0 && l > q.mlexp)) q.stop_main = true;
+            } else if (l + 3 < q.max_len && q.mlexp > 0 && l > q.mlexp) {
+                // the reference's 4-byte prefilter can pass by chance past the mismatch; it then leaves the walk
+                // without a better match (src/matcher.rs:150-168)
+                if (ldu32(b + pos + q.max_len - 3) == ldu32(px + q.max_len - 3)) q.stop_main = true;
             }
+        } else {
+            q.stop_main = true;
         }
-        s.mlz[x] = M1 | (M2 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)r2 << 17);
+        if (q.stop_main && !want1 && !want2) q.stop_all = true;
+    }
+    ORZ_D void pre_finish(Pre& q, const Sh& s, uint32_t seg_start, uint32_t x, bool item_start) const {
+        s.mlz[x] = q.M1 | (q.M2 << 8) | ((uint32_t)q.r1 << 16) | ((uint32_t)q.r2 << 17);
         if (!item_start) return;
-        const bool is_match = max_len >= kMinLen && p + max_len < a.len;
-        uint64_t d = (uint64_t)bestq | ((uint64_t)max_len << 25);
+        const bool is_match = q.max_len >= kMinLen && seg_start + x + q.max_len < a.len;
+        uint64_t d = (uint64_t)q.bestq | ((uint64_t)q.max_len << 25);
         if (is_match) {
             d |= kDecMatch;
-            const bool bl = roid_bitlen(bestro) < 8;
-            if (bl != (roid_bitlen(bestro + kCntSlack) < 8)) rmain = false;
+            const bool bl = roid_bitlen(q.bestro) < 8;
+            if (bl != (roid_bitlen(q.bestro + kCntSlack) < 8)) q.rmain = false;
             if (bl) d |= kDecBl;
         }
-        if (rmain) d |= kDecRobust;
+        if (q.rmain) d |= kDecRobust;
         s.dec[x] = d;
     }
 
