@@ -164,7 +164,8 @@ def main():
                 "lzcfg": [15, 9, 6],
                 "members": world,
                 "segment_bytes": 62,
-                "window_segments": 2048,
+                "window_segments": 3072,
+                "handoff_group": 48,
                 "input": "resident in HBM",
             },
             "compressed_bytes": len(out),

@@ -33,7 +33,7 @@ bool cfg_ok(const orz_lzcfg* c) {
            c->lazy_match_depth2 <= 200;
 }
 
-constexpr unsigned kDefaultSeg = 62, kDefaultWin = 2048;
+constexpr unsigned kDefaultSeg = 62, kDefaultWin = 3072;
 
 unsigned env_u(const char* name, unsigned dflt) {
     const char* v = std::getenv(name);

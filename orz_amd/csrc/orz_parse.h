@@ -23,7 +23,8 @@
 //     srec[slot].ml   the item's match_len_expected (0 literal/word, 255 = not an item)
 //     srec[slot].ord  the item's ordinal in its ctx ring (recomputed per sweep by the rank kernel)
 //     kbits           1 bit per word-predictor slot: words[] was updated at that position + 2
-//     exitst[s]       where segment s-1 left the stream: (next item position << 2) | last type
+//     exitst[s]       where segment s-1 left the stream: (next item position << 2) | last type, stamped with
+//                     the sweep that wrote it (hand-off inside a sweep, see phase 2)
 //     hist[s][ctx]    items per context of segment s (ring of R segments) -> base[s][ctx] prefix
 #pragma once
 #include "orz_common.h"
@@ -57,6 +58,7 @@ struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t wend;          // end of the last sweep's window: segments >= wend were never evaluated
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
+    uint32_t adv_hist[16];       // histogram of the front's advance per sweep: bucket = floor(log2(segments + 1))
 };
 
 struct ParseArgs {
@@ -69,6 +71,9 @@ struct ParseArgs {
     uint32_t lt0;             // type of the last item of the previous block (after_literal carry)
     uint32_t par;             // sweep parity
     uint32_t prof;            // sample phase timings into ctl->prof (diagnostics)
+    uint32_t sweep;           // 1-based id of this launch within the block (stamps the exit states)
+    uint32_t chain;           // segments per hand-off group: all but a group's first wait for their predecessor's
+                              // exit state of THIS sweep before walking (1 = never wait)
     SlotRec* srec;
     const uint32_t* idx;
     const uint32_t* runstart;
@@ -82,7 +87,7 @@ struct ParseArgs {
     uint64_t* kbits;          // word-predictor slots, same three levels
     uint64_t* k1;
     uint64_t* k2;
-    uint32_t* exitst;         // [nseg + 1]
+    uint64_t* exitst;         // [nseg + 2]  (sweep id << 32) | (next item position << 2) | last type
     uint8_t* hist;            // [ring][256]
     uint32_t* base;           // [ring][256]
     uint8_t* TY;              // per position outputs of the owning segment
@@ -100,6 +105,10 @@ ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p,
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { return atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { return atomicOr((unsigned long long*)p, (unsigned long long)v); }
+ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
+ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+constexpr uint32_t kHandoffPolls = 400;  // bounded wait for the predecessor (about 30 us), then go with the old state
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
@@ -118,6 +127,10 @@ ORZ_D void atom_or64(uint64_t* p, uint64_t v) { *p |= v; }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { *p &= v; }
 ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p &= v; return o; }
 ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p |= v; return o; }
+ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
+ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
+ORZ_D void spin_pause() {}
+constexpr uint32_t kHandoffPolls = 1;   // the emulator runs blocks one after another: no point in waiting
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { *p += v; }
@@ -501,102 +514,140 @@ struct ParseWave {
         // ---- phase 2a: every position decides, on its own lane, what the item starting there would be
         // if the segment's own earlier items do not interfere (no same-key item, no words[] update of
         // its key, ring ordinals within kCntSlack of no threshold): kDecRobust marks those decisions.
-        uint32_t p, lt;
-        if (sg == 0) {
-            p = kPre;
-            lt = a.lt0;
-        } else {  // where the previous segment left the stream (look through skipped segments)
-            uint32_t v = a.exitst[sg];
-            for (uint32_t d = 1; d <= 4 && d < sg; d++) {
-                uint32_t v2 = a.exitst[sg - d];
-                if (v2 > v) v = v2;
+        // ---- phase 2: the segment's items.  Everything up to here did not depend on the entry state (where the
+        // previous segment left the stream).  The wave walks optimistically from the entry it knows, then --
+        // inside a hand-off group of `chain` segments -- waits a bounded time for its predecessor's exit of THIS
+        // sweep; only if that differs from what it assumed does it walk again.  Each wave stamps its exit once
+        // per sweep, after it is sure of its entry; a parse that shifts and re-synchronises a segment or two
+        // later thus settles within one sweep instead of costing one sweep per segment.
+        const bool leader = sg == 0 || a.chain <= 1 || w.block() % a.chain == 0;
+        auto read_entry = [&](bool wait) -> uint32_t {  // lane 0 only; `wait`: until the predecessor stamped this sweep
+            uint64_t e = atom_load64(&a.exitst[sg]);
+            for (uint32_t tries = 0; wait && (uint32_t)(e >> 32) != a.sweep && tries < kHandoffPolls; tries++) {
+                spin_pause();
+                e = atom_load64(&a.exitst[sg]);
             }
-            p = v >> 2;
-            lt = v & 3;
-        }
-        // each lane keeps its own position's flags in registers: item start / words[] update there
-        bool myv = false, myE = false;
-        if (sg != 0 && p < seg_end) {
-            if (lane == p - seg_start) myE = (lt != kTyWord);
-            if (lane == 0) s.ownE[p - seg_start] = (lt != kTyWord);
+            uint32_t v = (uint32_t)e, o[4];
+#pragma unroll
+            for (uint32_t d = 1; d <= 4; d++) o[d - 1] = d < sg ? (uint32_t)atom_load64(&a.exitst[sg - d]) : 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) if (o[d] > v) v = o[d];  // look through skipped segments
+            return v;
+        };
+        uint32_t ventry = 0;
+        if (sg == 0) ventry = (kPre << 2) | a.lt0;
+        else {
+            if (lane == 0) ventry = read_entry(false);
+            ventry = w.bcast(ventry, 0);
         }
         const uint32_t mykey = lane < npos ? s.keyL[lane] : 0xffffffffu;
         const uint32_t mykk = lane < npos ? s.kkL[lane] : 0xffffffffu;
-        w.sync();
+        uint32_t p = 0, lt = 0, nslow = 0;
+        bool exit_changed = false;
         if (prof) tk3 = w.clock();
-
-        // ---- phase 2b: walk the items.  Robust decisions are taken as they are; the others are
-        // evaluated on the spot with this sweep's own items as the most recent candidates.
-        uint32_t nslow = 0;
-        while (p < seg_end) {
-            const uint32_t x = p - seg_start;
-            const bool older = lane < x && myv;
-            const uint64_t m0 = w.ballot(older && mykey == s.keyL[x]);
-            const uint64_t m1 = w.ballot(older && mykey == s.keyL[x + 1]);
-            const uint64_t m2 = w.ballot(older && mykey == s.keyL[x + 2]);
-            const uint64_t mE = w.ballot(lane <= x && myE && mykk == s.kkL[x + 2]);
-            const uint8_t* px = s.lb + kLbPre + x;
-            uint32_t w0, w1;
-            if (mE) {  // words[hash2(p-1)] was last written by this segment: at position e = seg_start + y
-                const uint32_t y = 63 - (uint32_t)clz64(mE);
-                w0 = s.lb[kLbPre + y - 2];
-                w1 = s.lb[kLbPre + y - 1];
-            } else {
-                w0 = s.wg[x] & 0xff;
-                w1 = s.wg[x] >> 8;
+        for (uint32_t pass = 0;; pass++) {
+            if (pass) {  // walking again: forget the first attempt
+                for (uint32_t c = lane; c < 256; c += 64) s.cnt[c] = 0;
+                if (lane < npos) { s.ownv[lane] = 0; s.ownml[lane] = 0; s.ownE[lane] = 0; }
             }
-            const uint32_t lwm = (px[0] == w0 && px[1] == w1);
-            uint64_t d = s.dec[x];
-            bool is_match = (d & kDecMatch) != 0;
-            uint32_t max_len = dec_len(d), lazy = 0;
-            bool robust = (d & kDecRobust) != 0 && !m0;
-            if (is_match && max_len < kMaxLen / 2) {  // the lazy probes read what the lists of x+1 / x+2 offer
-                const uint32_t l1 = max_len + 1 + ((d & kDecBl) ? 1u : 0u);
-                const uint32_t z1 = s.mlz[x + 1], z2 = s.mlz[x + 2];
-                if ((z1 & 0xff) >= l1) lazy = 1;
-                else if (((z2 >> 8) & 0xff) >= l1 - lwm) lazy = 2;
-                robust = robust && ((z1 >> 16) & 1) && ((z2 >> 17) & 1) && !(m1 | m2);
+            p = ventry >> 2;
+            lt = ventry & 3;
+            // each lane keeps its own position's flags in registers: item start / words[] update there
+            bool myv = false, myE = false;
+            if (sg != 0 && p < seg_end) {
+                if (lane == p - seg_start) myE = (lt != kTyWord);
+                if (lane == 0) s.ownE[p - seg_start] = (lt != kTyWord);
             }
-#ifdef ORZ_FORCE_SLOW
-            robust = false;
-#endif
-            if (!robust) {  // this sweep's own items interfere (or a ring threshold is near): evaluate on the spot
-                if (lane == 0) s.dec[x] = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
-                w.sync();
-                d = s.dec[x];
-                nslow++;
-                is_match = (d & kDecMatch) != 0;
-                max_len = dec_len(d);
-                lazy = (d & kDecLazy1) ? 1 : ((d & kDecLazy2a) ? 2 : 0);
-            }
-            // commit, src/lz.rs:172-234
-            const uint32_t c = s.ctxL[x];
-            const uint32_t cc = s.cnt[c];
-            const uint8_t al = (lt == kTyLit) ? 4 : 0;
-            uint32_t np, ty, ml = 0;
-            if (is_match && !lazy) {
-                ty = kTyMatch; ml = max_len; np = p + max_len;
-            } else if (p + 1 < a.len && lazy != 1 && lwm) {
-                ty = kTyWord; np = p + 2;
-            } else {
-                ty = kTyLit; np = p + 1;
-            }
-            if (lane == 0) {
-                s.ownv[x] = 1;
-                s.ownord[x] = s.basec[c] + cc;
-                s.lrL[x] = (uint8_t)cc;
-                s.cnt[c] = (uint8_t)(cc + 1);
-                s.w0L[x] = (uint8_t)w0;
-                s.tyL[x] = (uint8_t)(ty | al);
-                s.ownml[x] = (uint8_t)ml;
-                s.srcL[x] = dec_src(d);
-                if (np < seg_end) s.ownE[np - seg_start] = (ty != kTyWord);
-            }
-            if (lane == x) myv = true;
-            if (np < seg_end && lane == np - seg_start) myE = (ty != kTyWord);
-            p = np;
-            lt = ty;
             w.sync();
+            // ---- phase 2b: walk the items.  Robust decisions are taken as they are; the others are
+            // evaluated on the spot with this sweep's own items as the most recent candidates.
+                while (p < seg_end) {
+                const uint32_t x = p - seg_start;
+                const bool older = lane < x && myv;
+                const uint64_t m0 = w.ballot(older && mykey == s.keyL[x]);
+                const uint64_t m1 = w.ballot(older && mykey == s.keyL[x + 1]);
+                const uint64_t m2 = w.ballot(older && mykey == s.keyL[x + 2]);
+                const uint64_t mE = w.ballot(lane <= x && myE && mykk == s.kkL[x + 2]);
+                const uint8_t* px = s.lb + kLbPre + x;
+                uint32_t w0, w1;
+                if (mE) {  // words[hash2(p-1)] was last written by this segment: at position e = seg_start + y
+                    const uint32_t y = 63 - (uint32_t)clz64(mE);
+                    w0 = s.lb[kLbPre + y - 2];
+                    w1 = s.lb[kLbPre + y - 1];
+                } else {
+                    w0 = s.wg[x] & 0xff;
+                    w1 = s.wg[x] >> 8;
+                }
+                const uint32_t lwm = (px[0] == w0 && px[1] == w1);
+                uint64_t d = s.dec[x];
+                bool is_match = (d & kDecMatch) != 0;
+                uint32_t max_len = dec_len(d), lazy = 0;
+                bool robust = (d & kDecRobust) != 0 && !m0;
+                if (is_match && max_len < kMaxLen / 2) {  // the lazy probes read what the lists of x+1 / x+2 offer
+                    const uint32_t l1 = max_len + 1 + ((d & kDecBl) ? 1u : 0u);
+                    const uint32_t z1 = s.mlz[x + 1], z2 = s.mlz[x + 2];
+                    if ((z1 & 0xff) >= l1) lazy = 1;
+                    else if (((z2 >> 8) & 0xff) >= l1 - lwm) lazy = 2;
+                    robust = robust && ((z1 >> 16) & 1) && ((z2 >> 17) & 1) && !(m1 | m2);
+                }
+    #ifdef ORZ_FORCE_SLOW
+                robust = false;
+    #endif
+                if (!robust) {  // this sweep's own items interfere (or a ring threshold is near): evaluate on the spot
+                    if (lane == 0) s.dec[x] = eval_item(s, b, seg_start, x, m0, m1, m2, lwm, false);
+                    w.sync();
+                    d = s.dec[x];
+                    nslow++;
+                    is_match = (d & kDecMatch) != 0;
+                    max_len = dec_len(d);
+                    lazy = (d & kDecLazy1) ? 1 : ((d & kDecLazy2a) ? 2 : 0);
+                }
+                // commit, src/lz.rs:172-234
+                const uint32_t c = s.ctxL[x];
+                const uint32_t cc = s.cnt[c];
+                const uint8_t al = (lt == kTyLit) ? 4 : 0;
+                uint32_t np, ty, ml = 0;
+                if (is_match && !lazy) {
+                    ty = kTyMatch; ml = max_len; np = p + max_len;
+                } else if (p + 1 < a.len && lazy != 1 && lwm) {
+                    ty = kTyWord; np = p + 2;
+                } else {
+                    ty = kTyLit; np = p + 1;
+                }
+                if (lane == 0) {
+                    s.ownv[x] = 1;
+                    s.ownord[x] = s.basec[c] + cc;
+                    s.lrL[x] = (uint8_t)cc;
+                    s.cnt[c] = (uint8_t)(cc + 1);
+                    s.w0L[x] = (uint8_t)w0;
+                    s.tyL[x] = (uint8_t)(ty | al);
+                    s.ownml[x] = (uint8_t)ml;
+                    s.srcL[x] = dec_src(d);
+                    if (np < seg_end) s.ownE[np - seg_start] = (ty != kTyWord);
+                }
+                if (lane == x) myv = true;
+                if (np < seg_end && lane == np - seg_start) myE = (ty != kTyWord);
+                p = np;
+                lt = ty;
+                w.sync();
+            }
+            // ---- is the entry this walk started from the predecessor's exit of this sweep?
+            uint32_t again = 0, vnew = ventry;
+            if (lane == 0) {
+                bool ok = leader || pass >= 2;
+                if (!ok) {
+                    vnew = read_entry(true);
+                    if (vnew != ventry) again = 1;  // it left the stream somewhere else: walk again from there
+                }
+                if (!again) {  // stamp the exit: the successor may be waiting for it
+                    const uint32_t v = (p << 2) | lt;
+                    const uint64_t old = atom_xchg64(&a.exitst[sg + 1], ((uint64_t)a.sweep << 32) | v);
+                    exit_changed = (uint32_t)old != v;
+                }
+            }
+            again = w.bcast(again, 0);
+            if (!again) break;
+            ventry = w.bcast(vnew, 0);
         }
         if (prof) tk4 = w.clock();
 
@@ -638,11 +689,7 @@ struct ParseWave {
             }
         }
         if (lane == 0) {
-            const uint32_t v = (p << 2) | lt;
-            if (a.exitst[sg + 1] != v) {
-                a.exitst[sg + 1] = v;
-                changed = true;
-            }
+            if (exit_changed) changed = true;
             atom_add32(&a.ctl->evals, 1);
             if (nslow) atom_add32(&a.ctl->slow, nslow);
         }
@@ -931,6 +978,11 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
         a.ctl->front[a.par ^ 1] = nf;
         a.ctl->fchg[a.par ^ 1] = kNoChange;
         if (wend > a.ctl->wend) a.ctl->wend = wend;
+        {
+            uint32_t adv = nf - f, bk = 0;
+            while ((2u << bk) <= adv + 1 && bk < 15) bk++;
+            if (f < a.nseg) a.ctl->adv_hist[bk]++;
+        }
     }
 }
 

@@ -126,10 +126,10 @@ struct SlotInit {  // history slots carry their final item state, new slots star
     }
 };
 struct FillExit {
-    uint32_t* exitst;
+    uint64_t* exitst;
     uint32_t nseg, seg;
     ORZ_HD void operator()(size_t tid) const {
-        if (tid <= nseg) exitst[tid] = ((kPre + (uint32_t)tid * seg) << 2) | kTyLit;
+        if (tid <= nseg) exitst[tid] = ((kPre + (uint32_t)tid * seg) << 2) | kTyLit;  // sweep stamp 0
     }
 };
 struct ParseCtlInit {
@@ -143,6 +143,7 @@ struct ParseCtlInit {
         ctl->slow = 0;
         ctl->wend = 0;
         for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; }
+        for (int i = 0; i < 16; i++) ctl->adv_hist[i] = 0;
     }
 };
 struct FinalizeBlock {  // slot state -> per-position arrays of the new region
@@ -190,7 +191,7 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
 
-    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 2048)
+    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs) {
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
@@ -228,7 +229,7 @@ class StreamEncoder {
         k1_ = be_.template alloc<uint64_t>(kNewMax / 4096 + 2);
         k2_ = be_.template alloc<uint64_t>(kNewMax / 262144 + 2);
         srec_ = be_.template alloc<SlotRec>(kWLen);
-        exitst_ = be_.template alloc<uint32_t>((size_t)nseg_max_ + 2);
+        exitst_ = be_.template alloc<uint64_t>((size_t)nseg_max_ + 2);
         hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
         base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
         ctl_ = be_.template alloc<ParseCtl>(1);
@@ -364,6 +365,8 @@ class StreamEncoder {
         pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
         pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
         pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
+        pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 48;
+        if (pa.chain < 1) pa.chain = 1;
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
@@ -374,6 +377,7 @@ class StreamEncoder {
         while (front < nseg) {
             for (uint32_t i = 0; i < batch; i++) {
                 pa.par = par;
+                pa.sweep = (uint32_t)sweeps + 1;
                 be_.timed_begin();
                 be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
                 be_.timed_end();
@@ -398,6 +402,11 @@ class StreamEncoder {
             ParseCtl h;
             be_.d2h(&h, ctl_, sizeof h);
             stats.seg_evals += h.evals;
+            if (getenv("ORZ_PROF")) {
+                fprintf(stderr, "front advance per sweep (segments): ");
+                for (int i = 0; i < 16; i++) fprintf(stderr, "[%d..%d]:%u ", (1 << i) - 1, (2 << i) - 2, h.adv_hist[i]);
+                fprintf(stderr, "\n");
+            }
             if (getenv("ORZ_PROF") && h.nprof)
                 fprintf(stderr, "parse phases (avg shader cycles / sampled wave, %u waves): load %llu  candidates %llu  decide %llu  walk %llu  publish %llu ; slow items %u ; phase-1 slowest-lane stamps: own-count %llu  first-loads %llu  slot-walk %llu  word-walk %llu  records+lcp %llu ; max-lane bitmap words %llu\n",
                         h.nprof, h.prof[0] / h.nprof, h.prof[1] / h.nprof, h.prof[2] / h.nprof, h.prof[3] / h.nprof, h.prof[4] / h.nprof, h.slow, h.prof2[0] / h.nprof, h.prof2[1] / h.nprof, h.prof2[2] / h.nprof, h.prof2[3] / h.nprof, h.prof2[4] / h.nprof, h.prof2[7] / h.nprof);
@@ -456,8 +465,8 @@ class StreamEncoder {
         }
         // ---- model state carried to the next block (still on the main stream)
         be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
-        uint32_t ex;
-        be_.d2h(&ex, exitst_ + nseg, 4);
+        uint64_t ex;
+        be_.d2h(&ex, exitst_ + nseg, 8);
         const uint8_t ltf = (uint8_t)(ex & 3);
         be_.memset(wlast_, 0, 32768 * 4);
         be_.launch((size_t)n + 1, WordsLast{win, E_, len, wlast_});
@@ -574,7 +583,7 @@ class StreamEncoder {
     uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_;
     uint64_t *entA_, *entB_, *vbits_, *v1_, *v2_, *kbits_, *k1_, *k2_;
     SlotRec* srec_;
-    uint32_t* exitst_;
+    uint64_t* exitst_;
     uint8_t* hist_;
     uint32_t* base_;
     ParseCtl* ctl_;

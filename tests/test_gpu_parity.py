@@ -44,7 +44,7 @@ def test_tuning_does_not_change_the_stream(gpu_encoder_factory, oracle, seg, win
     try:
         assert enc.encode(data) == oracle.encode(data, 1)
     finally:
-        enc.set_tuning(62, 2048)
+        enc.set_tuning(62, 3072)
 
 
 def test_more_than_one_chunk_per_block(gpu_encoder_factory, oracle):
