@@ -107,9 +107,8 @@ ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { return atomicAnd((uns
 ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { return atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-ORZ_D void atom_store64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(1); }
-constexpr uint32_t kHandoffPolls = 600;  // bounded wait for the predecessor (about 30 us), then go with the old state
+ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+constexpr uint32_t kHandoffPolls = 400;  // bounded wait for the predecessor (about 30 us), then go with the old state
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
@@ -130,7 +129,6 @@ ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p &
 ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p |= v; return o; }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
-ORZ_D void atom_store64(uint64_t* p, uint64_t v) { *p = v; }
 ORZ_D void spin_pause() {}
 constexpr uint32_t kHandoffPolls = 1;   // the emulator runs blocks one after another: no point in waiting
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
@@ -546,7 +544,6 @@ struct ParseWave {
         const uint32_t mykk = lane < npos ? s.kkL[lane] : 0xffffffffu;
         uint32_t p = 0, lt = 0, nslow = 0;
         bool exit_changed = false;
-        const uint32_t old_exit = lane == 0 ? (uint32_t)atom_load64(&a.exitst[sg + 1]) : 0;  // what the last sweep left
         if (prof) tk3 = w.clock();
         for (uint32_t pass = 0;; pass++) {
             if (pass) {  // walking again: forget the first attempt
@@ -644,8 +641,8 @@ struct ParseWave {
                 }
                 if (!again) {  // stamp the exit: the successor may be waiting for it
                     const uint32_t v = (p << 2) | lt;
-                    atom_store64(&a.exitst[sg + 1], ((uint64_t)a.sweep << 32) | v);
-                    exit_changed = old_exit != v;
+                    const uint64_t old = atom_xchg64(&a.exitst[sg + 1], ((uint64_t)a.sweep << 32) | v);
+                    exit_changed = (uint32_t)old != v;
                 }
             }
             again = w.bcast(again, 0);
