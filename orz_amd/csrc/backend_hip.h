@@ -75,11 +75,13 @@ __global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchu
 __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank,
                                                          const uint32_t* rstart) {
     __shared__ uint16_t tab[2 * kSyms + 4];
+    __shared__ uint32_t magic[392];  // reciprocals for the rank update's division by the (small) item count
     const uint32_t c = blockIdx.x;
     const uint32_t a = rstart[c], e = rstart[c + 1];
     if (a >= e) return;
     uint16_t* state = srstate + (size_t)c * kSrWords;
     for (uint32_t i = threadIdx.x; i < kSrWords; i += 64) tab[i] = state[i];
+    for (uint32_t d = threadIdx.x; d < 392; d += 64) magic[d] = d >= 2 ? (uint32_t)(0x100000000ull / d) + 1 : 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint16_t* value = tab;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         uint32_t g = gsym[a];
         for (uint32_t j = a; j < e; j++) {
             uint32_t gn = j + 1 < e ? gsym[j + 1] : 0;  // prefetch the next item behind the table update
-            grank[j] = symrank_encode(value, index, cnt, sum, (uint16_t)(g & 0xffff), (uint16_t)(g >> 16));
+            grank[j] = symrank_encode(value, index, cnt, sum, (uint16_t)(g & 0xffff), (uint16_t)(g >> 16), magic);
             g = gn;
         }
         tab[2 * kSyms] = (uint16_t)cnt;

@@ -186,8 +186,10 @@ struct CensusFill {
 };
 
 // SymRankCoder::encode + update on tables held in fast memory (LDS on the GPU)
+// `magic` (optional): magic[d] = floor(2^32 / d) + 1 for d in [2, 391]; then floor(n / d) == mulhi(n, magic[d])
+// for every n < 2^32 / d -- here n = sum / 16 < 2^17 and d = cnt <= 390 (checked exhaustively in tests/).
 ORZ_HD uint16_t symrank_encode(uint16_t* value, uint16_t* index, uint32_t& cnt, uint32_t& sum, uint16_t v,
-                               uint16_t vun) {
+                               uint16_t vun, const uint32_t* magic = nullptr) {
     uint16_t i = index[v];
     uint16_t iu = index[vun];
     if (cnt > kSyms) {  // src/symrank.rs:63-66
@@ -196,7 +198,9 @@ ORZ_HD uint16_t symrank_encode(uint16_t* value, uint16_t* index, uint32_t& cnt, 
     }
     cnt += 1;
     sum += i;
-    uint16_t dec = (uint16_t)(i / 16 + (uint16_t)(sum / 16 / cnt));
+    const uint32_t n16 = sum / 16;
+    const uint32_t q = (magic && cnt > 1) ? (uint32_t)(((uint64_t)n16 * magic[cnt]) >> 32) : n16 / cnt;
+    uint16_t dec = (uint16_t)(i / 16 + (uint16_t)q);
     uint16_t next_i = i > dec ? (uint16_t)(i - dec) : 0;
     if (next_i < i / 2) next_i = i / 2;
     uint16_t n = i - next_i;

@@ -58,6 +58,7 @@ struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t wend;          // end of the last sweep's window: segments >= wend were never evaluated
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
+    uint32_t p1_hist[16];        // sampled waves: cycles until the end of phase 1, 16 K per bucket
     uint32_t adv_hist[16];       // histogram of the front's advance per sweep: bucket = floor(log2(segments + 1))
 };
 
@@ -72,6 +73,7 @@ struct ParseArgs {
     uint32_t par;             // sweep parity
     uint32_t prof;            // sample phase timings into ctl->prof (diagnostics)
     uint32_t sweep;           // 1-based id of this launch within the block (stamps the exit states)
+    uint32_t polls;           // hand-off: how often a wave polls for its predecessor's stamp before it gives up
     uint32_t chain;           // segments per hand-off group: all but a group's first wait for their predecessor's
                               // exit state of THIS sweep before walking (1 = never wait)
     SlotRec* srec;
@@ -523,7 +525,7 @@ struct ParseWave {
         const bool leader = sg == 0 || a.chain <= 1 || w.block() % a.chain == 0;
         auto read_entry = [&](bool wait) -> uint32_t {  // lane 0 only; `wait`: until the predecessor stamped this sweep
             uint64_t e = atom_load64(&a.exitst[sg]);
-            for (uint32_t tries = 0; wait && (uint32_t)(e >> 32) != a.sweep && tries < kHandoffPolls; tries++) {
+            for (uint32_t tries = 0; wait && (uint32_t)(e >> 32) != a.sweep && tries < a.polls; tries++) {
                 spin_pause();
                 e = atom_load64(&a.exitst[sg]);
             }
@@ -702,6 +704,12 @@ struct ParseWave {
             atom_add64(&a.ctl->prof[3], tk4 - tk3);
             atom_add64(&a.ctl->prof[4], tk5 - tk4);
             atom_add32(&a.ctl->nprof, 1);
+            {   // distribution of the wave's time up to the end of phase 1 (shader cycles): buckets of 16 K
+                const unsigned long long t1 = tk2 - tk0;
+                uint32_t bk = (uint32_t)(t1 >> 14);
+                if (bk > 15) bk = 15;
+                atom_add32(&a.ctl->p1_hist[bk], 1);
+            }
             {
                 const uint32_t* dg = (const uint32_t*)(lds + L.dbg);
                 for (int k = 0; k < 5; k++) {

@@ -100,10 +100,12 @@ struct ScatterSlots {  // idx[pos[j]] = j ; run starts
     uint32_t n;
     uint32_t* idx;
     uint32_t* runstart;
+    uint32_t* runend;  // optional
     ORZ_HD void operator()(size_t tid) const {
         if (tid >= n) return;
         idx[pos[tid]] = (uint32_t)tid;
         if (tid == 0 || keys[tid] != keys[tid - 1]) runstart[keys[tid]] = (uint32_t)tid;
+        if (runend && (tid + 1 == n || keys[tid + 1] != keys[tid])) runend[keys[tid]] = (uint32_t)tid + 1;
     }
 };
 struct SlotInit {  // history slots carry their final item state, new slots start empty
@@ -143,7 +145,7 @@ struct ParseCtlInit {
         ctl->slow = 0;
         ctl->wend = 0;
         for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; }
-        for (int i = 0; i < 16; i++) ctl->adv_hist[i] = 0;
+        for (int i = 0; i < 16; i++) { ctl->adv_hist[i] = 0; ctl->p1_hist[i] = 0; }
     }
 };
 struct FinalizeBlock {  // slot state -> per-position arrays of the new region
@@ -168,6 +170,20 @@ struct FinalizeBlock {  // slot state -> per-position arrays of the new region
             e = (uint32_t)((kbits[ks >> 6] >> (ks & 63)) & 1);
         }
         E[x] = (uint8_t)e;
+    }
+};
+// words[] carried to the next block: per hash2 key the last position of the block whose update stuck
+// (src/lz.rs:203,233) = the last set bit of the key's run in the word-predictor bitmap.
+struct WordsLastRun {
+    const uint64_t *kbits, *k1, *k2;
+    const uint32_t *kpos, *krun, *krunend;
+    uint32_t* wlast;  // [32768] out: position u, 0 = no update in this block
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid >= 32768) return;
+        const uint32_t lo = krun[tid], hi = krunend[tid];
+        uint32_t slot = 0, found = 0, nwords = 0;
+        if (hi > lo) found = collect_slots(kbits, k1, k2, kbits[(hi - 1) >> 6], k1[(hi - 1) >> 12], hi, lo, 1, &slot, 1, nwords);
+        wlast[tid] = found ? kpos[slot] : 0;
     }
 };
 struct ChunkTotals {  // total payload bits of each chunk = header + items
@@ -222,6 +238,7 @@ class StreamEncoder {
         kpos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 8);
         runstart_ = be_.template alloc<uint32_t>(kNumKeys + 1);
         krun_ = be_.template alloc<uint32_t>(32768 + 1);
+        krunend_ = be_.template alloc<uint32_t>(32768 + 1);
         vbits_ = be_.template alloc<uint64_t>(kWLen / 64 + 2);
         v1_ = be_.template alloc<uint64_t>(kWLen / 4096 + 2);
         v2_ = be_.template alloc<uint64_t>(kWLen / 262144 + 2);
@@ -276,7 +293,7 @@ class StreamEncoder {
     }
     ~StreamEncoder() {
         void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, symA_, symB_, epos_,
-                        kpos_, runstart_, krun_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
+                        kpos_, runstart_, krun_, krunend_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_};
@@ -338,9 +355,11 @@ class StreamEncoder {
         uint32_t* kkeysB = keysB + kWLen;
         be_.launch(std::max<size_t>(nent, (size_t)n + 1), BuildKeys{win, hpos_, tailkey_, nhist, n, keysA, valsA, kkeysA, kvalsA});
         be_.sort_pairs_u32(keysA, keysB, valsA, epos_, nent, 21);
-        be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_});
+        be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_, nullptr});
         be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
-        be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_});
+        be_.memset(krun_, 0, 32769 * 4);
+        be_.memset(krunend_, 0, 32769 * 4);
+        be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_, krunend_});
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 1) * 8);
         be_.memset(v1_, 0, ((size_t)kWLen / 4096 + 2) * 8);
         be_.memset(v2_, 0, ((size_t)kWLen / 262144 + 2) * 8);
@@ -367,6 +386,7 @@ class StreamEncoder {
         pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
         pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 48;
         if (pa.chain < 1) pa.chain = 1;
+        pa.polls = getenv("ORZ_POLLS") ? (uint32_t)atoi(getenv("ORZ_POLLS")) : kHandoffPolls;
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
@@ -403,7 +423,9 @@ class StreamEncoder {
             be_.d2h(&h, ctl_, sizeof h);
             stats.seg_evals += h.evals;
             if (getenv("ORZ_PROF")) {
-                fprintf(stderr, "front advance per sweep (segments): ");
+                fprintf(stderr, "phase-1 end, cycles/16K histogram: ");
+                for (int i = 0; i < 16; i++) fprintf(stderr, "%u ", h.p1_hist[i]);
+                fprintf(stderr, "\nfront advance per sweep (segments): ");
                 for (int i = 0; i < 16; i++) fprintf(stderr, "[%d..%d]:%u ", (1 << i) - 1, (2 << i) - 2, h.adv_hist[i]);
                 fprintf(stderr, "\n");
             }
@@ -468,8 +490,7 @@ class StreamEncoder {
         uint64_t ex;
         be_.d2h(&ex, exitst_ + nseg, 8);
         const uint8_t ltf = (uint8_t)(ex & 3);
-        be_.memset(wlast_, 0, 32768 * 4);
-        be_.launch((size_t)n + 1, WordsLast{win, E_, len, wlast_});
+        be_.launch(32768, WordsLastRun{kbits_, k1_, k2_, kpos_, krun_, krunend_, wlast_});
         be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
         lt_carry_ = ltf;
 
@@ -580,7 +601,7 @@ class StreamEncoder {
     uint8_t* winbuf_;
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
     uint32_t *ORD_, *SRC_;
-    uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_;
+    uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_, *krunend_;
     uint64_t *entA_, *entB_, *vbits_, *v1_, *v2_, *kbits_, *k1_, *k2_;
     SlotRec* srec_;
     uint64_t* exitst_;

@@ -65,3 +65,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(d, f), errors="replace").read()
                 assert "orz_oracle" not in src and "_oracle" not in src, f
+
+
+def test_symrank_reciprocal_division_is_exact():
+    """orz_symrank_kernel replaces sum/16/cnt by a multiply-high with floor(2^32/cnt)+1 (orz_kernels.h):
+    exact on the whole reachable domain (sum < 2^21 => n < 2^17, cnt <= 390)."""
+    import numpy as np
+
+    n = np.arange(0, 1 << 17, dtype=np.uint64)
+    for d in range(2, 392):
+        m = np.uint64((1 << 32) // d + 1)
+        assert (((n * m) >> np.uint64(32)) == n // np.uint64(d)).all()
