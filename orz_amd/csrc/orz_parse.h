@@ -110,7 +110,6 @@ ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { return atomicOr((unsig
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
-constexpr uint32_t kHandoffPolls = 400;  // bounded wait for the predecessor (about 30 us), then go with the old state
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
@@ -132,7 +131,6 @@ ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p |=
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
 ORZ_D void spin_pause() {}
-constexpr uint32_t kHandoffPolls = 1;   // the emulator runs blocks one after another: no point in waiting
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { *p += v; }

@@ -386,7 +386,7 @@ class StreamEncoder {
         pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
         pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 48;
         if (pa.chain < 1) pa.chain = 1;
-        pa.polls = getenv("ORZ_POLLS") ? (uint32_t)atoi(getenv("ORZ_POLLS")) : kHandoffPolls;
+        pa.polls = getenv("ORZ_POLLS") ? (uint32_t)atoi(getenv("ORZ_POLLS")) : be_.handoff_polls();
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;

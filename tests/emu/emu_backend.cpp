@@ -24,6 +24,7 @@ struct EmuBackend {
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
+    uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
     void select(int) {}
     void record(int) {}
     void wait(int) {}
