@@ -141,7 +141,7 @@ class HipBackend {
 
     hipStream_t stream() const { return streams_[0]; }
     // hand-off inside a sweep: polls a wave spends waiting for its predecessor's exit stamp before giving up
-    uint32_t handoff_polls() const { return 400; }
+    uint32_t handoff_polls() const { return 250; }
     // second stream: the tail stage of a block overlaps the next block's parse (orz_stream.h)
     void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
