@@ -541,17 +541,6 @@ struct Pack {  // src/lz.rs:320-342
 
 // ---------------------------------------------------------------------------------------------
 // block end: word-predictor snapshot (the table is byte values, it never expires: src/lz.rs:52,203,233)
-struct WordsLast {  // wlast[key] = max u with an update (E bit at u+2)
-    const uint8_t* win;
-    const uint8_t* E;
-    uint32_t len;
-    uint32_t* wlast;  // [32768], zeroed
-    ORZ_HD void operator()(size_t tid) const {
-        uint32_t u = kPre - 1 + (uint32_t)tid;
-        if (u + 2 >= len) return;  // the update at e == len is applied by WordsApply (it is the newest)
-        if (E[u + 2]) ORZ_ATOMIC_MAX(&wlast[hash2(win, u - 1)], u);
-    }
-};
 struct WordsApply {
     const uint8_t* win;
     const uint32_t* wlast;

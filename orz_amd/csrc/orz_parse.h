@@ -105,15 +105,12 @@ ORZ_D uint32_t ldu32(const uint8_t* p) { return *reinterpret_cast<const __attrib
 ORZ_D uint64_t ldu64(const uint8_t* p) { return *reinterpret_cast<const __attribute__((aligned(1))) uint64_t*>(p); }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
-ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { return atomicAnd((unsigned long long*)p, (unsigned long long)v); }
-ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { return atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
-ORZ_D void fence_agent() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
 ORZ_D int clz64(uint64_t v) { return __clzll((long long)v); }
 ORZ_D int ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }
 ORZ_D SlotRec ld_rec(const SlotRec* p) {
@@ -126,15 +123,12 @@ ORZ_D uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4);
 ORZ_D uint64_t ldu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { *p |= v; }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { *p &= v; }
-ORZ_D uint64_t atom_fetch_and64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p &= v; return o; }
-ORZ_D uint64_t atom_fetch_or64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p |= v; return o; }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
 ORZ_D void spin_pause() {}
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { *p += v; }
-ORZ_D void fence_agent() {}
 ORZ_D int clz64(uint64_t v) { return __builtin_clzll(v); }
 ORZ_D int ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ORZ_D SlotRec ld_rec(const SlotRec* p) { return *p; }
@@ -511,9 +505,6 @@ struct ParseWave {
         w.sync();
         if (prof) tk2 = w.clock();
 
-        // ---- phase 2a: every position decides, on its own lane, what the item starting there would be
-        // if the segment's own earlier items do not interfere (no same-key item, no words[] update of
-        // its key, ring ordinals within kCntSlack of no threshold): kDecRobust marks those decisions.
         // ---- phase 2: the segment's items.  Everything up to here did not depend on the entry state (where the
         // previous segment left the stream).  The wave walks optimistically from the entry it knows, then --
         // inside a hand-off group of `chain` segments -- waits a bounded time for its predecessor's exit of THIS
