@@ -58,6 +58,7 @@ struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t wend;          // end of the last sweep's window: segments >= wend were never evaluated
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
+    unsigned long long prof3[8]; // the same for the slowest waves (phase 1 > 140 K cycles); [6] = their number
     uint32_t p1_hist[16];        // sampled waves: cycles until the end of phase 1, 16 K per bucket
     uint32_t adv_hist[16];       // histogram of the front's advance per sweep: bucket = floor(log2(segments + 1))
 };
@@ -210,14 +211,17 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
     if (w0 & 63) m1 &= (1ull << (w0 & 63)) - 1; else m1 = 0;
     while (more) {
         if ((u << 6) < wmin) m1 &= ~0ull << (wmin - (u << 6));
+        uint32_t round = 0;
         while (m1 && found < D) {
-            uint32_t ww[4];
-            uint64_t wd[4];
+            // four words in flight in the first round, eight from then on (sparse runs: fewer round trips)
+            uint32_t ww[8];
+            uint64_t wd[8];
+            const int cap = round++ ? 8 : 4;
             int nw = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 8; i++) {
                 ww[i] = 0;
-                if (m1) {
+                if (i < cap && m1) {
                     const int bit = 63 - clz64(m1);
                     m1 &= ~(1ull << bit);
                     ww[i] = (u << 6) + (uint32_t)bit;
@@ -225,10 +229,10 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) wd[i] = i < nw ? L0[ww[i]] : 0;
+            for (int i = 0; i < 8; i++) wd[i] = i < nw ? L0[ww[i]] : 0;
             nwords += (uint32_t)nw;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 8; i++) {
                 uint64_t v = wd[i];
                 if (i < nw && (ww[i] << 6) < lo) v &= ~0ull << (lo - (ww[i] << 6));
                 while (v && found < D) {
@@ -701,11 +705,13 @@ struct ParseWave {
             }
             {
                 const uint32_t* dg = (const uint32_t*)(lds + L.dbg);
+                const bool slowwave = (tk2 - tk0) > 140000;  // tail waves are accounted separately (prof3)
                 for (int k = 0; k < 5; k++) {
                     uint32_t mx = 0;
                     for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + k] > mx) mx = dg[i * 8 + k];
-                    atom_add64(&a.ctl->prof2[k], mx);
+                    atom_add64(slowwave ? &a.ctl->prof3[k] : &a.ctl->prof2[k], mx);
                 }
+                if (slowwave) atom_add64(&a.ctl->prof3[6], 1);
                 uint32_t mw = 0;
                 for (uint32_t i = 0; i < nprobe && seg_start + i < a.len; i++) if (dg[i * 8 + 7] > mw) mw = dg[i * 8 + 7];
                 atom_add64(&a.ctl->prof2[7], mw);

@@ -144,7 +144,7 @@ struct ParseCtlInit {
         ctl->nprof = 0;
         ctl->slow = 0;
         ctl->wend = 0;
-        for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; }
+        for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; ctl->prof3[i] = 0; }
         for (int i = 0; i < 16; i++) { ctl->adv_hist[i] = 0; ctl->p1_hist[i] = 0; }
     }
 };
@@ -423,6 +423,7 @@ class StreamEncoder {
             be_.d2h(&h, ctl_, sizeof h);
             stats.seg_evals += h.evals;
             if (getenv("ORZ_PROF")) {
+                if (h.prof3[6]) fprintf(stderr, "slow waves (%llu): own-count %llu first-loads %llu slot-walk %llu word-walk %llu records+lcp %llu\n", h.prof3[6], h.prof3[0] / h.prof3[6], h.prof3[1] / h.prof3[6], h.prof3[2] / h.prof3[6], h.prof3[3] / h.prof3[6], h.prof3[4] / h.prof3[6]);
                 fprintf(stderr, "phase-1 end, cycles/16K histogram: ");
                 for (int i = 0; i < 16; i++) fprintf(stderr, "%u ", h.p1_hist[i]);
                 fprintf(stderr, "\nfront advance per sweep (segments): ");

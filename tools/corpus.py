@@ -70,8 +70,10 @@ def text_corpus(nbytes):
     if len(buf) < nbytes:  # not enough text on this image: pad with synthetic text
         buf += synth_text(nbytes - len(buf))
     data = bytes(buf[:nbytes])
-    with open(path, "wb") as f:
+    tmp = "%s.%d.tmp" % (path, os.getpid())  # several ranks may build the cache at once: publish atomically
+    with open(tmp, "wb") as f:
         f.write(data)
+    os.replace(tmp, path)
     return data
 
 
