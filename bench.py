@@ -80,10 +80,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # test hook: ORZ_BENCH_BACKEND=gloo + ORZ_BENCH_DEVICE=0 runs several ranks on ONE GPU (RCCL refuses that)
+    backend = os.environ.get("ORZ_BENCH_BACKEND", "nccl")
+    if "ORZ_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ORZ_BENCH_DEVICE"])
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and distributed:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -106,7 +113,7 @@ def main():
     def step():
         out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True)
         if distributed:  # the job's only exchange: gather the finished bitstreams on rank 0
-            got = odist.gather_members({rank: out}, world, rank, world, device=dev)
+            got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None)
             if rank == 0:
                 assert all(g is not None for g in got)
         return out, st
@@ -124,7 +131,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
