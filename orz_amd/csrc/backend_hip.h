@@ -44,6 +44,8 @@ struct DevWave {
     __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) const {
         return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
     }
+    // value of lane `src` (any per-lane index): ds_bpermute
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)src, 64); }
     __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t src) const {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);

@@ -59,6 +59,9 @@ struct ParseCtl {           // device-resident sweep control of one stream
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
     unsigned long long prof3[8]; // the same for the slowest waves (phase 1 > 140 K cycles); [6] = their number
+    uint32_t stop_cause[32];     // per sweep: input-change bits of the first changed segment (2 entry, 4 words, 8 candidates, 16 first evaluation)
+    uint32_t cause[8];           // changed segments near the front: [0] all, [1] entry moved, [2] words answers moved,
+                                 // [3] candidate lists moved, [4] none of these
     uint32_t p1_hist[16];        // sampled waves: cycles until the end of phase 1, 16 K per bucket
     uint32_t adv_hist[16];       // histogram of the front's advance per sweep: bucket = floor(log2(segments + 1))
 };
@@ -97,6 +100,7 @@ struct ParseArgs {
     uint32_t* SRC;
     uint8_t* W0;
     uint8_t* LR;
+    uint32_t* sig;            // [nseg][4] diagnostics (ORZ_PROF): input signatures of each segment's last evaluation
     uint32_t* partial;        // [2][chunks][256] per-chunk ctx item counts of the sweep, by parity
     ParseCtl* ctl;
 };
@@ -508,6 +512,18 @@ struct ParseWave {
         }
         w.sync();
         if (prof) tk2 = w.clock();
+        uint32_t sigW = 0, sigC = 0;
+        if ((a.prof & 1) && a.sig) {  // diagnostics: what did this evaluation read? (compared with the last one at the end)
+            uint32_t hw = 0, hc = 0;
+            if (lane < npos) hw = (uint32_t)s.wg[lane] * 2654435761u + lane;
+            if (lane < nprobe && seg_start + lane < a.len)
+                for (uint32_t k = 0; k < s.ncand[lane]; k++) {
+                    const uint64_t cd = s.cdat[lane * D + k];
+                    hc = hc * 31u + (uint32_t)(cd >> 32) + (uint32_t)((cd >> 16) & 0xffff) * 977u;  // pos, lcp, ml (not the ring offset)
+                }
+            for (int off = 32; off; off >>= 1) { hw ^= w.shfl(hw, lane ^ off); hc += w.shfl(hc, lane ^ off); }
+            sigW = hw; sigC = hc;
+        }
 
         // ---- phase 2: the segment's items.  Everything up to here did not depend on the entry state (where the
         // previous segment left the stream).  The wave walks optimistically from the entry it knows, then --
@@ -688,7 +704,21 @@ struct ParseWave {
             atom_add32(&a.ctl->evals, 1);
             if (nslow) atom_add32(&a.ctl->slow, nslow);
         }
-        if (w.ballot(changed) && lane == 0) atom_min32(&a.ctl->fchg[a.par], sg);
+        const bool anych = w.ballot(changed) != 0;
+        if ((a.prof & 1) && a.sig && lane == 0) {
+            uint32_t* sg4 = a.sig + (size_t)sg * 4;
+            if (anych && w.block() < 256 && (sg4[3] & 1)) {
+                const bool e = sg4[0] != ventry, ww = sg4[1] != sigW, c = sg4[2] != sigC;
+                atom_add32(&a.ctl->cause[0], 1);
+                if (e) atom_add32(&a.ctl->cause[1], 1);
+                if (ww) atom_add32(&a.ctl->cause[2], 1);
+                if (c) atom_add32(&a.ctl->cause[3], 1);
+                if (!e && !ww && !c) atom_add32(&a.ctl->cause[4], 1);
+            }
+            const uint32_t bits = sg4[3] ? ((sg4[0] != ventry ? 2u : 0u) | (sg4[1] != sigW ? 4u : 0u) | (sg4[2] != sigC ? 8u : 0u)) : 16u;
+            sg4[0] = ventry; sg4[1] = sigW; sg4[2] = sigC; sg4[3] = 1 | (bits << 8);
+        }
+        if (anych && lane == 0) atom_min32(&a.ctl->fchg[a.par], sg);
         if (prof && lane == 0) {
             const unsigned long long tk5 = w.clock();
             atom_add64(&a.ctl->prof[0], tk1 - tk0);
@@ -905,6 +935,7 @@ struct RankArgs {
     const uint64_t *vbits, *kbits;  // level-0 bitmaps ...
     uint64_t *v1, *v2, *k1, *k2;     // ... and their summaries, rebuilt here after every sweep
     uint32_t nvwords, nkwords;       // level-0 words in use
+    const uint32_t* sig;             // diagnostics (may be null)
 };
 // `rows` = LDS [kRankChunk + 1][256] u32 ; sync() = block barrier ; c = thread id (0..255)
 template <class SYNC>
@@ -981,6 +1012,10 @@ ORZ_D void rank_chunk(const RankArgs& a, uint32_t chunk, uint32_t c, uint32_t* r
         a.ctl->front[a.par ^ 1] = nf;
         a.ctl->fchg[a.par ^ 1] = kNoChange;
         if (wend > a.ctl->wend) a.ctl->wend = wend;
+        if (a.sig && fc != kNoChange) {  // diagnostics: what had moved for the segment that stopped the front
+            const uint32_t bits = (a.sig[(size_t)fc * 4 + 3] >> 8) & 31;
+            a.ctl->stop_cause[bits & 31]++;
+        }
         {
             uint32_t adv = nf - f, bk = 0;
             while ((2u << bk) <= adv + 1 && bk < 15) bk++;

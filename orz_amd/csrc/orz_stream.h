@@ -146,6 +146,8 @@ struct ParseCtlInit {
         ctl->wend = 0;
         for (int i = 0; i < 8; i++) { ctl->prof[i] = 0; ctl->prof2[i] = 0; ctl->prof3[i] = 0; }
         for (int i = 0; i < 16; i++) { ctl->adv_hist[i] = 0; ctl->p1_hist[i] = 0; }
+        for (int i = 0; i < 8; i++) ctl->cause[i] = 0;
+        for (int i = 0; i < 32; i++) ctl->stop_cause[i] = 0;
     }
 };
 struct FinalizeBlock {  // slot state -> per-position arrays of the new region
@@ -368,7 +370,7 @@ class StreamEncoder {
         be_.memset(k2_, 0, ((size_t)kNewMax / 262144 + 2) * 8);
         be_.launch(nent, SlotInit{win, epos_, nent, ML_, ORD_, srec_, vbits_});
         // summary levels of both bitmaps, exact before the first sweep (0 rank chunks = rebuild only)
-        be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, 0, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2}, 0);
+        be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, 0, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2, nullptr}, 0);
         be_.launch((size_t)nseg + 1, FillExit{exitst_, nseg, seg_});
         be_.memset(hist_, 0, (size_t)ring_ * 256);
         be_.d2d(base_, ctxcount_, 256 * 4);
@@ -390,6 +392,11 @@ class StreamEncoder {
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
+        pa.sig = nullptr;
+        if (getenv("ORZ_PROF")) {  // diagnostics only: borrow the (idle during the parse) scan buffer
+            pa.sig = sc32_;
+            be_.memset(sc32_, 0, (size_t)(nseg + 1) * 16);
+        }
         const size_t lds_bytes = ParseLds::make(dmax_, pa.prof & 1).total;
         const uint32_t grid = std::min(wsegs_, nseg);
         uint32_t par = 0, front = 0, batch = 8;
@@ -401,7 +408,7 @@ class StreamEncoder {
                 be_.timed_begin();
                 be_.launch_waves(grid, ParseWave{pa}, lds_bytes);
                 be_.timed_end();
-                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, par, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2},
+                be_.rank(RankArgs{win, ctl_, hist_, base_, partial_, idx_, srec_, LR_, nseg, seg_, wsegs_, ring_, len, par, vbits_, kbits_, v1_, v2_, k1_, k2_, nent / 64 + 1, n / 64 + 2, pa.sig},
                          wsegs_ / kRankChunk + 1);
                 par ^= 1;
                 sweeps++;
@@ -423,6 +430,10 @@ class StreamEncoder {
             be_.d2h(&h, ctl_, sizeof h);
             stats.seg_evals += h.evals;
             if (getenv("ORZ_PROF")) {
+                fprintf(stderr, "changed segments within 256 of the front: %u ; entry moved %u, words answers moved %u, candidate lists moved %u, none of these %u\n", h.cause[0], h.cause[1], h.cause[2], h.cause[3], h.cause[4]);
+                fprintf(stderr, "front stoppers by what had moved (E entry, W words, C candidates): ");
+                for (int i = 0; i < 32; i++) if (h.stop_cause[i]) fprintf(stderr, "%s%s%s%s:%u ", (i & 2) ? "E" : "", (i & 4) ? "W" : "", (i & 8) ? "C" : "", (i & 16) ? "first" : ((i & 14) ? "" : "none"), h.stop_cause[i]);
+                fprintf(stderr, "\n");
                 if (h.prof3[6]) fprintf(stderr, "slow waves (%llu): own-count %llu first-loads %llu slot-walk %llu word-walk %llu records+lcp %llu\n", h.prof3[6], h.prof3[0] / h.prof3[6], h.prof3[1] / h.prof3[6], h.prof3[2] / h.prof3[6], h.prof3[3] / h.prof3[6], h.prof3[4] / h.prof3[6]);
                 fprintf(stderr, "phase-1 end, cycles/16K histogram: ");
                 for (int i = 0; i < 16; i++) fprintf(stderr, "%u ", h.p1_hist[i]);

@@ -116,6 +116,7 @@ struct WaveCtx {
         uint32_t g = deposit(v);
         return w->tag[g & 1][src] == g ? (uint32_t)w->val[g & 1][src] : 0;
     }
+    uint32_t shfl(uint32_t v, uint32_t src) { return bcast(v, src); }
     uint64_t bcast64(uint64_t v, uint32_t src) {
         uint32_t g = deposit(v);
         return w->tag[g & 1][src] == g ? w->val[g & 1][src] : 0;
