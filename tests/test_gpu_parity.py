@@ -194,3 +194,15 @@ def test_members_concurrent_on_one_gpu(oracle, tmp_path):
     subprocess.check_call([cli, "encode", "-s", "-l1", "--member-size", "4000000", "--jobs", "2", str(src), str(encf)])
     subprocess.check_call([cli, "decode", "-s", "--members", str(encf), str(decf)])
     assert decf.read_bytes() == data[:9_000_000]
+
+
+def test_randomised_settings_do_not_change_the_stream():
+    """short run of tools/gpu_fuzz.py: random shapes / sizes / levels / speculation settings vs the oracle"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "12", "7"], capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout
