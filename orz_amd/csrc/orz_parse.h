@@ -408,16 +408,27 @@ struct ParseWave {
         // how many of this segment's earlier positions share my (ctx, hash) key / my words[] key:
         // their slots sit right below mine in the run and are this sweep's business, not older segments'
         uint32_t same = 0, samek = 0;
-        {   // keys travel lane to lane through v_readlane (an LDS scan of the 64 keys measured 2x slower)
-            const uint32_t kmine = lane < nprobe ? s.keyL[lane] : 0xfffffffeu;
-            const uint32_t kkmine = s.kkL[lane];                      // key of entry u = seg_start - 2 + lane
-            const uint32_t kkq = lane < nprobe ? s.kkL[lane + 2] : 0xfffffffeu;  // my words[] lookup key
-            for (uint32_t y = 0; y < 64; y++) {
-                const uint64_t both = w.bcast64((uint64_t)kmine | ((uint64_t)kkmine << 32), y);
-                const uint32_t ky = (uint32_t)both, kky = (uint32_t)(both >> 32);
-                same += (y < lane && ky == kmine) ? 1u : 0u;
-                samek += (y < lane + 2 && seg_start - 2 + y >= kPre - 1 && kky == kkq) ? 1u : 0u;
+        {   // which lanes hold the same key as mine?  one ballot per key bit (21 + 15) instead of 64 broadcasts
+            const uint32_t kmine = lane < nprobe ? s.keyL[lane] : 0x1fffffu;  // probe lanes beyond the segment: no real key
+            const uint32_t kkmine = s.kkL[lane];                               // key of entry u = seg_start - 2 + lane
+            uint64_t mk = ~0ull, mkk = ~0ull;
+            for (uint32_t bit = 0; bit < 21; bit++) {
+                const uint64_t bal = w.ballot((kmine >> bit) & 1);
+                mk &= ((kmine >> bit) & 1) ? bal : ~bal;
             }
+            for (uint32_t bit = 0; bit < 15; bit++) {
+                const uint64_t bal = w.ballot((kkmine >> bit) & 1);
+                mkk &= ((kkmine >> bit) & 1) ? bal : ~bal;
+            }
+            const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;          // lanes < mine
+            const uint64_t real = nprobe >= 64 ? ~0ull : ((1ull << nprobe) - 1);  // lanes that hold a position
+            same = (uint32_t)__builtin_popcountll(mk & below & real);
+            // my words[] lookup key is the entry key of lane + 2: take that lane's match mask
+            const uint32_t src = lane + 2 < 64 ? lane + 2 : lane;
+            const uint64_t mq = (uint64_t)w.shfl((uint32_t)mkk, src) | ((uint64_t)w.shfl((uint32_t)(mkk >> 32), src) << 32);
+            const uint32_t ulo = seg_start - 2 >= kPre - 1 ? 0 : (kPre - 1) - (seg_start - 2);  // entries u >= P-1 only
+            const uint64_t upto = lane + 2 >= 64 ? ~0ull : ((1ull << (lane + 2)) - 1);          // entries i < lane + 2
+            samek = (uint32_t)__builtin_popcountll(mq & upto & (~0ull << ulo));
         }
         if (lane < nprobe && seg_start + lane < a.len) {
             const uint32_t x = lane;
