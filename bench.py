@@ -172,7 +172,8 @@ def main():
                 "members": world,
                 "segment_bytes": 62,
                 "window_segments": 3072,
-                "handoff_group": 48,
+                "handoff_lookback_segments": 63,
+                "handoff_deadline_us": 110,
                 "input": "resident in HBM",
             },
             "compressed_bytes": len(out),

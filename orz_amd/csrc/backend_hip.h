@@ -52,6 +52,7 @@ struct DevWave {
         return (uint64_t)lo | ((uint64_t)hi << 32);
     }
     __device__ __forceinline__ unsigned long long clock() const { return __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ unsigned long long wallclock() const { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz, chip-wide
 };
 template <class K>
 __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {
@@ -143,7 +144,14 @@ class HipBackend {
 
     hipStream_t stream() const { return streams_[0]; }
     // hand-off inside a sweep: polls a wave spends waiting for its predecessor's exit stamp before giving up
-    uint32_t handoff_polls() const { return 250; }
+    uint32_t handoff_polls() const { return 1000; }
+    uint32_t handoff_deadline() const { return 11000; }  // 110 us in ticks of the 100 MHz wall clock
+    // far-from-the-front limits: measured counter-productive on MI355X (every evaluation of a far segment
+    // pre-converges state the front later flies through), so off by default; ORZ_NEAR / ORZ_FAR_DEADLINE_US /
+    // ORZ_SKIP_US turn them on for experiments
+    uint32_t near_blocks() const { return 0; }
+    uint32_t far_deadline() const { return 0; }
+    uint32_t skip_after() const { return 0; }
     // second stream: the tail stage of a block overlaps the next block's parse (orz_stream.h)
     void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }

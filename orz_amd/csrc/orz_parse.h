@@ -23,8 +23,9 @@
 //     srec[slot].ml   the item's match_len_expected (0 literal/word, 255 = not an item)
 //     srec[slot].ord  the item's ordinal in its ctx ring (recomputed per sweep by the rank kernel)
 //     kbits           1 bit per word-predictor slot: words[] was updated at that position + 2
-//     exitst[s]       where segment s-1 left the stream: (next item position << 2) | last type, stamped with
-//                     the sweep that wrote it (hand-off inside a sweep, see phase 2)
+//     exitst[s]       how segment s-1 passed the stream on: the entry it walked from and the exit it reached
+//                     ((next item position << 2) | last type, each), a `settled` flag and the sweep that wrote
+//                     it -- see ExitPair and the hand-off inside a sweep in phase 2
 //     hist[s][ctx]    items per context of segment s (ring of R segments) -> base[s][ctx] prefix
 #pragma once
 #include "orz_common.h"
@@ -49,6 +50,23 @@ struct SlotRec {  // one candidate-list slot: 32 bytes, half a cache line, fetch
                       // touching the window
 };
 
+// How a segment passed the stream on, packed into one 64-bit word that is stored and loaded atomically:
+//   [26:0] entry = (position of the first item at or after the segment start << 2) | type of the item before
+//   [35:27] exit position - entry position (< 512: a segment is <= 62 bytes, an item <= 240)
+//   [37:36] type of the last item   [38] settled (will not change any more in this sweep)   [63:39] sweep
+struct ExitPair {
+    ORZ_HD static uint64_t make(uint32_t sweep, bool settled, uint32_t entry, uint32_t exit) {
+        return ((uint64_t)sweep << 39) | ((uint64_t)(settled ? 1 : 0) << 38) | ((uint64_t)(exit & 3) << 36) |
+               ((uint64_t)(((exit >> 2) - (entry >> 2)) & 0x1ff) << 27) | (entry & 0x7ffffffu);
+    }
+    ORZ_HD static uint32_t entry(uint64_t e) { return (uint32_t)e & 0x7ffffffu; }
+    ORZ_HD static uint32_t exit(uint64_t e) {
+        return ((((uint32_t)e & 0x7ffffffu) >> 2) + (uint32_t)((e >> 27) & 0x1ff)) << 2 | (uint32_t)((e >> 36) & 3);
+    }
+    ORZ_HD static bool settled(uint64_t e) { return (e >> 38) & 1; }
+    ORZ_HD static uint32_t sweep(uint64_t e) { return (uint32_t)(e >> 39); }
+};
+
 struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t front[2];      // first non-final segment, by sweep parity
     uint32_t fchg[2];       // lowest segment whose result changed in the sweep, by parity
@@ -56,6 +74,8 @@ struct ParseCtl {           // device-resident sweep control of one stream
     uint32_t nprof;         // waves sampled into prof[]
     uint32_t slow;          // items that needed the serial evaluation (statistics)
     uint32_t wend;          // end of the last sweep's window: segments >= wend were never evaluated
+    uint32_t skipped;       // evaluations given up because the wave ran late (statistics)
+    uint32_t pad0;
     unsigned long long prof[8];  // shader cycles per phase, summed over the sampled waves
     unsigned long long prof2[8]; // phase 1 detail: max-over-lanes stamps
     unsigned long long prof3[8]; // the same for the slowest waves (phase 1 > 140 K cycles); [6] = their number
@@ -93,7 +113,14 @@ struct ParseArgs {
     uint64_t* kbits;          // word-predictor slots, same three levels
     uint64_t* k1;
     uint64_t* k2;
-    uint64_t* exitst;         // [nseg + 2]  (sweep id << 32) | (next item position << 2) | last type
+    uint64_t* exitst;         // [nseg + 2]  ExitPair of segment s-1 at [s]
+    uint32_t maxpass = 2;     // walks again at most this many times per sweep
+    uint32_t deadline = 0;    // stop waiting for hand-offs this long after the wave started (10 ns ticks; 0 = polls only)
+    uint32_t near = 0;        // blocks >= near (far from the front) use the two limits below instead
+    uint32_t far_deadline = 0;
+    uint32_t skip_after = 0;  // a far wave still collecting candidates this long after its start keeps its previous
+                              // evaluation instead (0 = never)
+    uint32_t skip_rand = 0;   // test hook: skip pseudo-randomly, about one evaluation in skip_rand
     uint8_t* hist;            // [ring][256]
     uint32_t* base;           // [ring][256]
     uint8_t* TY;              // per position outputs of the owning segment
@@ -101,6 +128,8 @@ struct ParseArgs {
     uint8_t* W0;
     uint8_t* LR;
     uint32_t* sig;            // [nseg][4] diagnostics (ORZ_PROF): input signatures of each segment's last evaluation
+    unsigned long long* tim = nullptr;  // [wsegs][8] diagnostics (ORZ_TIMELINE): wall-clock stamps of one sweep's waves
+    uint32_t timsweep = 0;    // the sweep `tim` records
     uint32_t* partial;        // [2][chunks][256] per-chunk ctx item counts of the sweep, by parity
     ParseCtl* ctl;
 };
@@ -112,6 +141,7 @@ ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p,
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+ORZ_D void atom_store64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
@@ -130,6 +160,7 @@ ORZ_D void atom_or64(uint64_t* p, uint64_t v) { *p |= v; }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { *p &= v; }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
 ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
+ORZ_D void atom_store64(uint64_t* p, uint64_t v) { *p = v; }
 ORZ_D void spin_pause() {}
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
@@ -197,8 +228,10 @@ ORZ_D void rebuild_summaries(const uint64_t* L0, uint64_t* L1, uint64_t* L2, uin
 // Newest-first list of the set slots in [lo, hi) of a three-level bitmap, at most D of them.
 // `word` is the already loaded level-0 word of slot hi-1.  Older words are reached through the
 // summaries: only non-empty ones are loaded, four in flight a round.
+template <class Late>
 ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint64_t* L2, uint64_t word, uint64_t l1word,
-                             uint32_t hi, uint32_t lo, uint32_t D, uint32_t* out, uint32_t ostride, uint32_t& nwords) {
+                             uint32_t hi, uint32_t lo, uint32_t D, uint32_t* out, uint32_t ostride, uint32_t& nwords,
+                             const Late& late) {
     uint32_t found = 0;
     if (hi <= lo) return 0;
     const uint32_t w0 = (hi - 1) >> 6, wmin = lo >> 6;
@@ -246,7 +279,7 @@ ORZ_D uint32_t collect_slots(const uint64_t* L0, const uint64_t* L1, const uint6
                 }
             }
         }
-        if (found >= D || (u << 6) <= wmin || u == 0) break;
+        if (found >= D || (u << 6) <= wmin || u == 0 || late()) break;
         uint32_t u2 = (u - 1) >> 6;  // next non-empty level-1 word below u, through level 2
         uint64_t m2 = L2[u2];
         if (u & 63) m2 &= (1ull << (u & 63)) - 1;
@@ -352,8 +385,22 @@ struct ParseWave {
         const uint32_t D = a.dmax;
         const bool prof = (a.prof & 1) && (w.block() & 63) == 5;
         unsigned long long tk0 = prof ? w.clock() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+        const bool tl = a.tim && a.sweep == a.timsweep;  // timeline of this sweep (diagnostics)
+        const unsigned long long tl0 = w.wallclock();
+        unsigned long long tl1 = 0, tl2 = 0, tl3 = 0;
+        uint32_t tlpolls = 0, tlpass = 0;
 
         // ---- phase 0: stage the segment's bytes, slots, old state and the ctx ordinals in LDS
+        const uint64_t oldpair = w.bcast64(lane == 0 ? atom_load64(&a.exitst[sg + 1]) : 0, 0);  // my last evaluation's hand-off
+        // a wave far from the front that runs late may keep its previous evaluation (if it has one)
+        const bool far = a.near && w.block() >= a.near;
+        const bool may_skip = far && ExitPair::sweep(oldpair) != 0;
+        const bool skip_now = may_skip && a.skip_rand && ((sg * 2654435761u) ^ (a.sweep * 40503u)) % a.skip_rand == 0;
+        bool gave_up = false;
+        auto late = [&]() -> bool {
+            if (skip_now || (may_skip && a.skip_after && w.wallclock() - tl0 > a.skip_after)) gave_up = true;
+            return gave_up;
+        };
         {
             const uint8_t* src = b + (int64_t)seg_start - kLbPre;
             for (uint32_t i = lane * 4; i < kLbLen; i += 256) {
@@ -455,10 +502,11 @@ struct ParseWave {
             uint64_t* mydat = s.cdat + x * D;
             uint32_t* mycq = (uint32_t*)mydat;  // slot k waits in the low half of entry k until its record arrives
             if (prof) dbg[1] = (uint32_t)(w.clock() - tk1) + (uint32_t)(word & 0) + (uint32_t)(kword & 0) + (uint32_t)(l1word & 0) + (uint32_t)(kl1word & 0) + (lo & 0) + (klo & 0) + (wsn & 0);
-            found = collect_slots(a.vbits, a.v1, a.v2, word, l1word, hi, lo, D, mycq, 2, nwords);
+            if (late()) found = 0;
+            else found = collect_slots(a.vbits, a.v1, a.v2, word, l1word, hi, lo, D, mycq, 2, nwords, late);
             if (prof) dbg[2] = (uint32_t)(w.clock() - tk1);
             uint32_t kslot = 0xffffffffu;
-            if (wantw && collect_slots(a.kbits, a.k1, a.k2, kword, kl1word, khi, klo, 1, &kslot, 1, nwords) == 0) kslot = 0xffffffffu;
+            if (wantw && !gave_up && collect_slots(a.kbits, a.k1, a.k2, kword, kl1word, khi, klo, 1, &kslot, 1, nwords, late) == 0) kslot = 0xffffffffu;
             if (prof) { dbg[3] = (uint32_t)(w.clock() - tk1); dbg[7] = nwords; }
             // second round trip: the slot records (32 B each, text included), sixteen in flight
             const uint32_t ku = kslot != 0xffffffffu ? a.kpos[kslot] : 0;
@@ -466,7 +514,7 @@ struct ParseWave {
             const uint64_t x0 = ldu64(px), x1 = ldu64(px + 8);
             const uint32_t hc0 = s.basec[s.ctxL[x]];  // ring ordinal of an item starting here, before own items
             Pre pre;
-            for (uint32_t k0 = 0; k0 < found; k0 += kRecBatch) {
+            for (uint32_t k0 = 0; k0 < found && !late(); k0 += kRecBatch) {
                 SlotRec r[kRecBatch];
                 uint32_t l[kRecBatch];
                 uint32_t act = 0;  // candidates whose common prefix is still growing
@@ -522,6 +570,22 @@ struct ParseWave {
             }
         }
         w.sync();
+        // running late, far from the front: the segment keeps its previous evaluation.  Hand the old exit on under
+        // this sweep's stamp, count the old items into the ordinal prefix (the hist row is still ours), and hold
+        // the front back (the segment was not evaluated against this sweep's state).
+        auto keep_previous = [&]() {
+            if (lane == 0) {
+                atom_store64(&a.exitst[sg + 1], ExitPair::make(a.sweep, true, ExitPair::entry(oldpair), ExitPair::exit(oldpair)));
+                atom_add32(&a.ctl->skipped, 1);
+                atom_min32(&a.ctl->fchg[a.par], sg - 1);
+            }
+            uint32_t* part = a.partial + ((size_t)a.par * (a.wsegs / kRankChunk + 1) + w.block() / kRankChunk) * 256;
+            for (uint32_t c = lane; c < 256; c += 64) {
+                const uint32_t v = a.hist[(size_t)(sg % a.ring) * 256 + c];
+                if (v) atom_add32(&part[c], v);
+            }
+        };
+        if (w.ballot(gave_up)) { keep_previous(); return; }
         if (prof) tk2 = w.clock();
         uint32_t sigW = 0, sigC = 0;
         if ((a.prof & 1) && a.sig) {  // diagnostics: what did this evaluation read? (compared with the last one at the end)
@@ -542,32 +606,27 @@ struct ParseWave {
         // sweep; only if that differs from what it assumed does it walk again.  Each wave stamps its exit once
         // per sweep, after it is sure of its entry; a parse that shifts and re-synchronises a segment or two
         // later thus settles within one sweep instead of costing one sweep per segment.
-        const bool leader = sg == 0 || a.chain <= 1 || w.block() % a.chain == 0;
-        auto read_entry = [&](bool wait) -> uint32_t {  // lane 0 only; `wait`: until the predecessor stamped this sweep
-            uint64_t e = atom_load64(&a.exitst[sg]);
-            for (uint32_t tries = 0; wait && (uint32_t)(e >> 32) != a.sweep && tries < a.polls; tries++) {
-                spin_pause();
-                e = atom_load64(&a.exitst[sg]);
-            }
-            uint32_t v = (uint32_t)e, o[4];
-#pragma unroll
-            for (uint32_t d = 1; d <= 4; d++) o[d - 1] = d < sg ? (uint32_t)atom_load64(&a.exitst[sg - d]) : 0;
-#pragma unroll
-            for (uint32_t d = 0; d < 4; d++) if (o[d] > v) v = o[d];  // look through skipped segments
-            return v;
-        };
-        uint32_t ventry = 0;
+        const bool anchor = sg == 0 || a.chain <= 1 || w.block() == 0;  // the front segment's entry is exact
+        const uint32_t dl = far ? a.far_deadline : a.deadline;
+        const uint32_t look = anchor ? 0 : (w.block() < a.chain ? w.block() : (a.chain < 63 ? a.chain : 63));
+        uint32_t ventry = 0, vold = 0;
         if (sg == 0) ventry = (kPre << 2) | a.lt0;
-        else {
-            if (lane == 0) ventry = read_entry(false);
-            ventry = w.bcast(ventry, 0);
+        {   // lanes 1..5: what the up to five segments before this one last reported (a long match may have
+            // skipped some of them)
+            uint32_t v = 0;
+            if (lane >= 1 && lane <= 5 && lane <= sg) v = ExitPair::exit(atom_load64(&a.exitst[sg + 1 - lane]));
+            vold = ExitPair::exit(oldpair);
+            for (int off = 4; off; off >>= 1) { const uint32_t o = w.shfl(v, lane ^ off); if (o > v) v = o; }
+            if (sg != 0) ventry = w.bcast(v, 0);
         }
         const uint32_t mykey = lane < npos ? s.keyL[lane] : 0xffffffffu;
         const uint32_t mykk = lane < npos ? s.kkL[lane] : 0xffffffffu;
         uint32_t p = 0, lt = 0, nslow = 0;
         bool exit_changed = false;
         if (prof) tk3 = w.clock();
+        if (tl) tl1 = w.wallclock();
         for (uint32_t pass = 0;; pass++) {
+            tlpass = pass;
             if (pass) {  // walking again: forget the first attempt
                 for (uint32_t c = lane; c < 256; c += 64) s.cnt[c] = 0;
                 if (lane < npos) { s.ownv[lane] = 0; s.ownml[lane] = 0; s.ownE[lane] = 0; }
@@ -653,25 +712,48 @@ struct ParseWave {
                 lt = ty;
                 w.sync();
             }
-            // ---- is the entry this walk started from the predecessor's exit of this sweep?
-            uint32_t again = 0, vnew = ventry;
-            if (lane == 0) {
-                bool ok = leader || pass >= 2;
-                if (!ok) {
-                    vnew = read_entry(true);
-                    if (vnew != ventry) again = 1;  // it left the stream somewhere else: walk again from there
-                }
-                if (!again) {  // stamp the exit: the successor may be waiting for it
-                    const uint32_t v = (p << 2) | lt;
-                    const uint64_t old = atom_xchg64(&a.exitst[sg + 1], ((uint64_t)a.sweep << 32) | v);
-                    exit_changed = (uint32_t)old != v;
-                }
+            // ---- hand-off: publish (entry, exit) of this walk, then look at what the `look` segments before
+            // this one published in THIS sweep.  The predecessor left the stream somewhere else: walk again
+            // from there.  Every link back to a settled segment (or all `look` links) agrees: settled.
+            if (pass == 0 && may_skip && !skip_now && a.skip_after && w.wallclock() - tl0 > a.skip_after + a.skip_after / 4) {
+                keep_previous();  // a slow walk on top of it all: nothing of this evaluation is out yet
+                return;
             }
-            again = w.bcast(again, 0);
-            if (!again) break;
-            ventry = w.bcast(vnew, 0);
+            const uint32_t vexit = (p << 2) | lt;
+            bool fin = anchor || pass >= a.maxpass;
+            if (lane == 0) atom_store64(&a.exitst[sg + 1], ExitPair::make(a.sweep, fin, ventry, vexit));
+            if (tl && pass == 0) tl2 = w.wallclock();
+            uint32_t again = 0, vnew = ventry;
+            for (uint32_t tries = 0; !fin; tries++) {
+                // lane i (1..look) holds the pair of segment sg - i; lane 0 stands for this segment
+                uint64_t q = 0;
+                if (lane >= 1 && lane <= look) q = atom_load64(&a.exitst[sg + 1 - lane]);
+                const bool pub = lane >= 1 && lane <= look && ExitPair::sweep(q) == a.sweep;
+                const uint32_t myE = lane == 0 ? ventry : ExitPair::entry(q);
+                const uint32_t succE = w.shfl(myE, lane ? lane - 1 : 0);     // entry of the segment after mine
+                const uint64_t P = w.ballot(pub) | 1;                         // bit 0: this segment
+                const bool succ_pub = lane >= 1 && ((P >> (lane - 1)) & 1);
+                const uint64_t C = w.ballot(pub && succ_pub && ExitPair::exit(q) == succE);
+                const uint64_t F = w.ballot(pub && ExitPair::settled(q));
+                const uint32_t x1 = w.bcast(ExitPair::exit(q), 1);
+                const bool overdue = dl && w.wallclock() - tl0 > dl;
+                if (!overdue && (P & 2) && !(C & 2) && ((F & 2) || (C & 4) || look == 1)) {  // predecessor moved (and is not about to move again)
+                    again = 1; vnew = x1;
+                    break;
+                }
+                const uint64_t upto = F ? ((2ull << ctz64(F)) - 2) : ((2ull << look) - 2);  // links 1 .. nearest settled
+                if ((C & upto) == upto) break;                                // settled
+                if (tries >= a.polls || overdue) break;  // give up: later sweeps sort it out
+                spin_pause();
+                tlpolls++;
+            }
+            if (again) { ventry = vnew; continue; }
+            if (!fin && lane == 0) atom_store64(&a.exitst[sg + 1], ExitPair::make(a.sweep, true, ventry, vexit));
+            exit_changed = vexit != vold;
+            break;
         }
         if (prof) tk4 = w.clock();
+        if (tl) tl3 = w.wallclock();
 
         // ---- phase 3: publish what changed, the per-ctx item counts and the exit state
         bool changed = false;
@@ -730,6 +812,11 @@ struct ParseWave {
             sg4[0] = ventry; sg4[1] = sigW; sg4[2] = sigC; sg4[3] = 1 | (bits << 8);
         }
         if (anych && lane == 0) atom_min32(&a.ctl->fchg[a.par], sg);
+        if (tl && lane == 0) {
+            unsigned long long* t = a.tim + (size_t)w.block() * 8;
+            t[0] = tl0; t[1] = tl1; t[2] = tl2; t[3] = tl3; t[4] = w.wallclock();
+            t[5] = ((unsigned long long)tlpass << 32) | tlpolls; t[6] = sg; t[7] = anych;
+        }
         if (prof && lane == 0) {
             const unsigned long long tk5 = w.clock();
             atom_add64(&a.ctl->prof[0], tk1 - tk0);

@@ -131,7 +131,10 @@ struct FillExit {
     uint64_t* exitst;
     uint32_t nseg, seg;
     ORZ_HD void operator()(size_t tid) const {
-        if (tid <= nseg) exitst[tid] = ((kPre + (uint32_t)tid * seg) << 2) | kTyLit;  // sweep stamp 0
+        if (tid <= nseg) {  // "nothing crosses the segment boundary", sweep stamp 0
+            const uint32_t v = ((kPre + (uint32_t)tid * seg) << 2) | kTyLit;
+            exitst[tid] = ExitPair::make(0, false, v, v);
+        }
     }
 };
 struct ParseCtlInit {
@@ -141,6 +144,7 @@ struct ParseCtlInit {
         ctl->front[0] = 0; ctl->front[1] = 0;
         ctl->fchg[0] = kNoChange; ctl->fchg[1] = kNoChange;
         ctl->evals = 0;
+        ctl->skipped = 0;
         ctl->nprof = 0;
         ctl->slow = 0;
         ctl->wend = 0;
@@ -184,7 +188,7 @@ struct WordsLastRun {
         if (tid >= 32768) return;
         const uint32_t lo = krun[tid], hi = krunend[tid];
         uint32_t slot = 0, found = 0, nwords = 0;
-        if (hi > lo) found = collect_slots(kbits, k1, k2, kbits[(hi - 1) >> 6], k1[(hi - 1) >> 12], hi, lo, 1, &slot, 1, nwords);
+        if (hi > lo) found = collect_slots(kbits, k1, k2, kbits[(hi - 1) >> 6], k1[(hi - 1) >> 12], hi, lo, 1, &slot, 1, nwords, [] { return false; });
         wlast[tid] = found ? kpos[slot] : 0;
     }
 };
@@ -386,9 +390,15 @@ class StreamEncoder {
         pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
         pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
         pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
-        pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 48;
+        pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 63;
         if (pa.chain < 1) pa.chain = 1;
         pa.polls = getenv("ORZ_POLLS") ? (uint32_t)atoi(getenv("ORZ_POLLS")) : be_.handoff_polls();
+        if (getenv("ORZ_MAXPASS")) pa.maxpass = (uint32_t)atoi(getenv("ORZ_MAXPASS"));
+        pa.deadline = getenv("ORZ_DEADLINE_US") ? (uint32_t)atoi(getenv("ORZ_DEADLINE_US")) * 100 : be_.handoff_deadline();
+        pa.near = getenv("ORZ_NEAR") ? (uint32_t)atoi(getenv("ORZ_NEAR")) : be_.near_blocks();
+        pa.far_deadline = getenv("ORZ_FAR_DEADLINE_US") ? (uint32_t)atoi(getenv("ORZ_FAR_DEADLINE_US")) * 100 : be_.far_deadline();
+        pa.skip_after = getenv("ORZ_SKIP_US") ? (uint32_t)atoi(getenv("ORZ_SKIP_US")) * 100 : be_.skip_after();
+        pa.skip_rand = getenv("ORZ_SKIP_RAND") ? (uint32_t)atoi(getenv("ORZ_SKIP_RAND")) : 0;
         pa.srec = srec_; pa.idx = idx_; pa.runstart = runstart_; pa.kpos = kpos_; pa.kidx = kidx_; pa.krun = krun_;
         pa.wsnap = wsnap_; pa.vbits = vbits_; pa.v1 = v1_; pa.v2 = v2_; pa.kbits = kbits_; pa.k1 = k1_; pa.k2 = k2_; pa.exitst = exitst_;
         pa.hist = hist_; pa.base = base_; pa.TY = TY_; pa.SRC = SRC_; pa.W0 = W0_; pa.LR = LR_; pa.partial = partial_; pa.ctl = ctl_;
@@ -396,6 +406,12 @@ class StreamEncoder {
         if (getenv("ORZ_PROF")) {  // diagnostics only: borrow the (idle during the parse) scan buffer
             pa.sig = sc32_;
             be_.memset(sc32_, 0, (size_t)(nseg + 1) * 16);
+        }
+        unsigned long long* tim = nullptr;
+        if (getenv("ORZ_TIMELINE")) {  // diagnostics only: wall-clock stamps of every wave of one sweep -> stderr
+            tim = be_.template alloc<unsigned long long>((size_t)wsegs_ * 8);
+            be_.memset(tim, 0, (size_t)wsegs_ * 64);
+            pa.tim = tim; pa.timsweep = (uint32_t)atoi(getenv("ORZ_TIMELINE"));
         }
         const size_t lds_bytes = ParseLds::make(dmax_, pa.prof & 1).total;
         const uint32_t grid = std::min(wsegs_, nseg);
@@ -444,6 +460,21 @@ class StreamEncoder {
             if (getenv("ORZ_PROF") && h.nprof)
                 fprintf(stderr, "parse phases (avg shader cycles / sampled wave, %u waves): load %llu  candidates %llu  decide %llu  walk %llu  publish %llu ; slow items %u ; phase-1 slowest-lane stamps: own-count %llu  first-loads %llu  slot-walk %llu  word-walk %llu  records+lcp %llu ; max-lane bitmap words %llu\n",
                         h.nprof, h.prof[0] / h.nprof, h.prof[1] / h.nprof, h.prof[2] / h.nprof, h.prof[3] / h.nprof, h.prof[4] / h.nprof, h.slow, h.prof2[0] / h.nprof, h.prof2[1] / h.nprof, h.prof2[2] / h.nprof, h.prof2[3] / h.nprof, h.prof2[4] / h.nprof, h.prof2[7] / h.nprof);
+        }
+        if (tim) {
+            std::vector<unsigned long long> h((size_t)wsegs_ * 8);
+            be_.d2h(h.data(), tim, h.size() * 8);
+            unsigned long long t0 = ~0ull;
+            for (uint32_t i = 0; i < wsegs_; i++) if (h[i * 8] && h[i * 8] < t0) t0 = h[i * 8];
+            if (t0 != ~0ull) {
+                fprintf(stderr, "timeline of sweep %u (10 ns ticks from the first wave's start): block seg start p1end walk1 walkend end passes polls changed\n", pa.timsweep);
+                for (uint32_t i = 0; i < wsegs_; i++) {
+                    const unsigned long long* t = &h[i * 8];
+                    if (!t[0]) continue;
+                    fprintf(stderr, "TL %u %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, t[6], t[0] - t0, t[1] - t0, t[2] ? t[2] - t0 : 0, t[3] - t0, t[4] - t0, t[5] >> 32, t[5] & 0xffffffffu, t[7]);
+                }
+            }
+            be_.free(tim);
         }
         stats.sweeps += sweeps;
         be_.launch(n, FinalizeBlock{idx_, kidx_, srec_, kbits_, len, S_, ML_, E_, ORD_});
@@ -501,7 +532,7 @@ class StreamEncoder {
         be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
         uint64_t ex;
         be_.d2h(&ex, exitst_ + nseg, 8);
-        const uint8_t ltf = (uint8_t)(ex & 3);
+        const uint8_t ltf = (uint8_t)(ExitPair::exit(ex) & 3);
         be_.launch(32768, WordsLastRun{kbits_, k1_, k2_, kpos_, krun_, krunend_, wlast_});
         be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
         lt_carry_ = ltf;

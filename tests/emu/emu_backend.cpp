@@ -25,6 +25,10 @@ struct EmuBackend {
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
     uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
+    uint32_t handoff_deadline() const { return 0; }
+    uint32_t near_blocks() const { return 16; }  // small windows here: exercise the far-wave paths too
+    uint32_t far_deadline() const { return 0; }
+    uint32_t skip_after() const { return 0; }
     void select(int) {}
     void record(int) {}
     void wait(int) {}

@@ -123,6 +123,7 @@ struct WaveCtx {
     }
     void sync() { deposit(0); }
     unsigned long long clock() const { return 0; }
+    unsigned long long wallclock() const { return 0; }
 };
 
 enum Order { kAscending = 0, kDescending = 1, kShuffled = 2 };
