@@ -76,3 +76,20 @@ def test_symrank_reciprocal_division_is_exact():
     for d in range(2, 392):
         m = np.uint64((1 << 32) // d + 1)
         assert (((n * m) >> np.uint64(32)) == n // np.uint64(d)).all()
+
+
+def test_parse_kernel_keeps_three_waves_per_simd():
+    """the sweep window (3072 segments = 256 CUs x 4 SIMDs x 3) assumes every wave of a launch is resident at once:
+    the build records each kernel's registers / occupancy next to the library"""
+    import __graft_entry__ as ge
+
+    ge.build()
+    path = ge.LIB + ".resources.txt"
+    if not os.path.exists(path):
+        pytest.skip("library was built without the resource remarks")
+    blocks = open(path).read().split("Function Name: ")
+    parse = [b for b in blocks if b.strip() and "ParseWave" in b.splitlines()[0]]
+    assert parse, "no resource record for the parse kernel"
+    fields = dict(ln.split(": ", 1) for ln in parse[0].splitlines()[1:] if ": " in ln)
+    assert int(fields["Occupancy [waves/SIMD]"]) >= 3, fields
+    assert int(fields["ScratchSize [bytes/lane]"]) == 0 and int(fields["VGPRs Spill"]) == 0, fields
