@@ -157,6 +157,19 @@ class HipBackend {
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
     void wait(int ev) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, sev_[ev], 0)); }
     int device() const { return device_; }
+    // wave slots the parse kernel can fill at once: its LDS per wave against 160 KB per CU, at most 3 per SIMD
+    // (142 VGPRs).  The sweep window is sized to this: waves of one launch hand their exits on to each other,
+    // so a launch that does not fit the chip runs in several rounds and takes that many times longer.
+    uint32_t resident_parse_waves(size_t lds_bytes) const {
+        int cus = 0;
+        ORZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
+        const size_t gran = 1280;  // LDS allocation granule
+        const size_t per_wave = (lds_bytes + gran - 1) / gran * gran;
+        size_t per_cu = per_wave ? (160 * 1024) / per_wave : 12;
+        if (per_cu > 12) per_cu = 12;
+        if (per_cu < 1) per_cu = 1;
+        return (uint32_t)(per_cu * (size_t)(cus > 0 ? cus : 256));
+    }
 
     template <class T>
     T* alloc(size_t n) {

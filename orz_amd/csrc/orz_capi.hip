@@ -33,7 +33,7 @@ bool cfg_ok(const orz_lzcfg* c) {
            c->lazy_match_depth2 <= 200;
 }
 
-constexpr unsigned kDefaultSeg = 62, kDefaultWin = 3072;
+constexpr unsigned kDefaultSeg = 62;  // window: 0 = as many segments as parse waves fit the device at once
 
 unsigned env_u(const char* name, unsigned dflt) {
     const char* v = std::getenv(name);
@@ -41,6 +41,12 @@ unsigned env_u(const char* name, unsigned dflt) {
 }
 
 using Enc = orz::StreamEncoder<orz::HipBackend>;
+
+unsigned window_for(const orz::HipBackend& be, const orz_lzcfg& c, unsigned asked) {
+    if (asked) return asked;
+    const size_t dmax = std::max(c.match_depth, std::max(c.lazy_match_depth1, c.lazy_match_depth2));
+    return be.resident_parse_waves(orz::ParseLds::make((uint32_t)dmax, false).total);
+}
 
 }  // namespace
 
@@ -53,7 +59,7 @@ struct orz_stream {
     bool tracing = false;
     void rebuild() {
         enc.reset();
-        enc.reset(new Enc(*be, to_cfg(&cfg), seg, win));
+        enc.reset(new Enc(*be, to_cfg(&cfg), seg, window_for(*be, cfg, win)));
         enc->trace = tracing ? &trace : nullptr;
     }
 };
@@ -104,7 +110,7 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         s->be.reset(new orz::HipBackend(device));
         s->cfg = *cfg;
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
-        s->win = env_u("ORZ_WIN", kDefaultWin);
+        s->win = env_u("ORZ_WIN", 0);
         s->rebuild();
         return s.release();
     } catch (const std::exception& e) {
@@ -200,7 +206,7 @@ orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs) {
         orz_stream* s = orz_stream_new(device, cfg);
         if (!s) { for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
         if (jobs > 1) {  // several streams share the GPU: a smaller speculative window each (same bytes out)
-            s->win = env_u("ORZ_MEMBER_WIN", 1024);
+            s->win = env_u("ORZ_MEMBER_WIN", std::max(256u, window_for(*s->be, *cfg, 0) / (unsigned)jobs));
             try { s->rebuild(); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
         }
         m->workers.push_back(s);
@@ -285,7 +291,7 @@ orz_lz_encoder* orz_lz_encoder_new(int device) {
         std::unique_ptr<orz_lz_encoder> e(new orz_lz_encoder);
         e->be.reset(new orz::HipBackend(device));
         e->seg = env_u("ORZ_SEG", kDefaultSeg);
-        e->win = env_u("ORZ_WIN", kDefaultWin);
+        e->win = env_u("ORZ_WIN", 0);
         return e.release();
     } catch (const std::exception& ex) {
         fail(ORZ_ENODEV, ex.what());
@@ -307,7 +313,7 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
         const bool same_cfg = e->enc && std::memcmp(&e->cfg, cfg, sizeof *cfg) == 0;
         if (!e->enc) {
             e->cfg = *cfg;
-            e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, e->win));
+            e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, window_for(*e->be, *cfg, e->win)));
         } else if (!same_cfg) {
             return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
         }
