@@ -137,6 +137,22 @@ int orz_members_encode(orz_members*, const void* src, size_t n, int src_on_devic
 /* decodes every stream of a concatenation (a plain single stream is the 1-member case) */
 int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* n_members_out);
 
+/* ---- members decoded on the device (decoder on GPU, one member per wavefront) --------
+ * Replaces orz::decode (/root/reference/src/lib.rs:94-129) + LZDecoder::decode (src/lz.rs:366-478) for a
+ * concatenation of members: decoding one stream is a serial chain, so each member is decoded by one lane of
+ * its own wavefront and the parallelism is the number of members (up to 2048 in flight).  Members must fit
+ * one block (<= 16,777,216 decoded bytes -- what orz_members_encode / `orz encode --member-size` produce);
+ * a larger member fails with ORZ_EINVAL and a message naming the host decoder.  Same bytes out as
+ * orz_decode_members_mem; ORZ_EINVAL for what the reference reports as InvalidData. */
+typedef struct {
+    uint64_t members, in_bytes, out_bytes;
+    uint64_t launches;     /* kernel launches (members / 2048, rounded up) */
+    double kernel_ms;      /* HIP-event time of the decode kernel launches (sum) */
+    double total_s;        /* wall time incl. framing scan, uploads and the download of the result */
+} orz_decode_stats;
+int orz_decode_members_device(int device, const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len,
+                              size_t* n_members_out, orz_decode_stats* stats);
+
 int orz_device_count(void);
 const char* orz_last_error(void);
 const char* orz_version(void);

@@ -54,6 +54,20 @@ WRITE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t)
 
 # every symbol include/orz_hip.h declares: (name, restype, argtypes)
+class DecodeStats(ctypes.Structure):  # orz_decode_stats
+    _fields_ = [
+        ("members", ctypes.c_uint64),
+        ("in_bytes", ctypes.c_uint64),
+        ("out_bytes", ctypes.c_uint64),
+        ("launches", ctypes.c_uint64),
+        ("kernel_ms", ctypes.c_double),
+        ("total_s", ctypes.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 SYMBOLS = [
     ("orz_lzcfg_from_level", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LZCfg)]),
     ("orz_lz_encoder_new", ctypes.c_void_p, [ctypes.c_int]),
@@ -109,6 +123,12 @@ SYMBOLS = [
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t),
          ctypes.POINTER(ctypes.c_size_t)],
+    ),
+    (
+        "orz_decode_members_device",
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(DecodeStats)],
     ),
     ("orz_stream_set_item_trace", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("orz_stream_get_item_trace", ctypes.c_long, [ctypes.c_void_p, ctypes.POINTER(Item), ctypes.c_size_t]),

@@ -198,6 +198,25 @@ def decode_members(container):
         lib.orz_free(dst)
 
 
+def decode_members_device(container, device=0, stats=False):
+    """decode every member of a concatenation of orz streams ON THE GPU (one member per wavefront; members of at
+    most one block) -> (bytes, n_members[, stats dict]).  Same bytes as `decode_members`."""
+    lib = _native.load()
+    container = bytes(container)
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n, nm = ctypes.c_size_t(), ctypes.c_size_t()
+    st = _native.DecodeStats()
+    buf = ctypes.create_string_buffer(container, len(container)) if container else ctypes.create_string_buffer(1)
+    rc = lib.orz_decode_members_device(device, ctypes.cast(buf, ctypes.c_void_p), len(container), ctypes.byref(dst),
+                                       ctypes.byref(n), ctypes.byref(nm), ctypes.byref(st))
+    _check(rc, "orz_decode_members_device")
+    try:
+        out = ctypes.string_at(dst, n.value)
+    finally:
+        lib.orz_free(dst)
+    return (out, nm.value, st.as_dict()) if stats else (out, nm.value)
+
+
 def decode_bytes(stream):
     """orz stream -> (bytes, consumed).  Host decoder of the library (orz::decode, src/lib.rs:94-129);
     stops after the first stream's EOF chunk like the reference."""

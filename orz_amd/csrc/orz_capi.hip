@@ -14,6 +14,7 @@
 
 #include "../../include/orz_hip.h"
 #include "backend_hip.h"
+#include "orz_decode_device.h"
 #include "orz_host_decode.h"
 #include "orz_stream.h"
 
@@ -261,8 +262,10 @@ int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* 
     try {
         std::vector<uint8_t> out;
         size_t at = 0, members = 0;
+        orz::host::DecodeWorkspace ws;  // one window / model allocation for all members
         while (at < n) {
             orz::host::decode_stream(
+                ws,
                 [&](uint8_t* buf, size_t k) {
                     if (at + k > n) return false;
                     std::memcpy(buf, src + at, k);
@@ -278,6 +281,31 @@ int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* 
         *dst = p;
         *dst_len = out.size();
         if (n_members_out) *n_members_out = members;
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
+}
+
+int orz_decode_members_device(int device, const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len,
+                              size_t* n_members_out, orz_decode_stats* stats) {
+    if ((!src && n) || !dst || !dst_len) return fail(ORZ_EINVAL, "bad argument");
+    if (device < 0 || device >= orz_device_count()) return fail(ORZ_ENODEV, "no such HIP device");
+    try {
+        orz::HipBackend be(device);
+        std::vector<uint8_t> out;
+        orz::DecodeStats st;
+        orz::decode_members_device(be, src, n, out, st, env_u("ORZ_DECODE_SLOTS", 2048));
+        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+        std::memcpy(p, out.data(), out.size());
+        *dst = p;
+        *dst_len = out.size();
+        if (n_members_out) *n_members_out = (size_t)st.members;
+        if (stats) {
+            stats->members = st.members; stats->in_bytes = st.in_bytes; stats->out_bytes = st.out_bytes;
+            stats->launches = st.launches; stats->kernel_ms = st.kernel_ms; stats->total_s = st.total_s;
+        }
         return ORZ_OK;
     } catch (const std::exception& e) {
         return fail(ORZ_EINVAL, e.what());

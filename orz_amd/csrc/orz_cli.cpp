@@ -5,7 +5,8 @@
 // source/target default to stdin/stdout.  Additive flags: --device N (HIP device of the encoder);
 //   encode --member-size BYTES [--jobs J]: cut the input into independent members (complete orz streams,
 //   concatenated) and encode J of them concurrently on the GPU;  decode --members: decode every stream of
-//   such a concatenation (the reference, and the default here, stop after the first stream).
+//   such a concatenation (the reference, and the default here, stop after the first stream);
+//   decode --members --gpu [--device N]: decode the members on the GPU, one member per wavefront.
 // Progress lines mirror SimpleProgressLogger (src/progress.rs:48-98) on stderr.
 #include <cerrno>
 #include <chrono>
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
     bool silent = false;
     long level = 2, device = 0, jobs = 4;
     long long member_size = 0;
-    bool all_members = false;
+    bool all_members = false, gpu_decode = false;
     std::vector<std::string> pos;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -72,6 +73,8 @@ int main(int argc, char** argv) {
         else if (cmd == "encode" && a == "--member-size") { if (++i >= argc) return usage(); member_size = strtoll(argv[i], nullptr, 10); }
         else if (cmd == "encode" && a == "--jobs") { if (++i >= argc) return usage(); jobs = strtol(argv[i], nullptr, 10); }
         else if (cmd == "decode" && a == "--members") all_members = true;
+        else if (cmd == "decode" && a == "--gpu") gpu_decode = true;
+        else if (cmd == "decode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }
         else if (a.size() > 1 && a[0] == '-' ) return usage();
         else pos.push_back(a);
     }
@@ -116,6 +119,17 @@ int main(int argc, char** argv) {
             rc = orz_encode(rd, &io, wr, &io, &cfg, silent ? nullptr : progress, &pg, (int)device);
         }
         if (rc != ORZ_OK) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
+    } else if (gpu_decode) {
+        std::vector<uint8_t> in;
+        uint8_t tmp[1 << 16];
+        for (size_t got; (got = fread(tmp, 1, sizeof tmp, io.in)) > 0;) in.insert(in.end(), tmp, tmp + got);
+        uint8_t* out = nullptr;
+        size_t out_len = 0, nm = 0;
+        rc = orz_decode_members_device((int)device, in.data(), in.size(), &out, &out_len, &nm, nullptr);
+        if (rc == ORZ_OK && fwrite(out, 1, out_len, io.out) != out_len) rc = ORZ_EIO;
+        if (out) orz_free(out);
+        if (rc != ORZ_OK) { fprintf(stderr, "Error: \"decoding failed: %s\"\n", orz_last_error()); return 1; }
+        if (!silent) progress(&pg, 1, in.size(), out_len);
     } else {
         for (;;) {
             rc = orz_decode(rd, &io, wr, &io, silent ? nullptr : progress, &pg);

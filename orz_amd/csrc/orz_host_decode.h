@@ -109,6 +109,19 @@ class Decoder {  // LZDecoder, src/lz.rs:348-479
                 rank_val_(512 * kSyms), rank_idx_(512 * kSyms), rank_cnt_(512, 0), rank_sum_(512, 1000000),
                 words_(32768 * 2, 0) {}
 
+    // back to the state of a new LZDecoder (src/lz.rs:352-357) without giving the arrays back
+    void reset() {
+        std::fill(ring_pos_.begin(), ring_pos_.end(), 0u);
+        std::fill(ring_min_.begin(), ring_min_.end(), (uint8_t)0);
+        std::fill(ring_exp_.begin(), ring_exp_.end(), (uint8_t)0);
+        std::fill(head_.begin(), head_.end(), 0u);
+        std::fill(rank_cnt_.begin(), rank_cnt_.end(), 0u);
+        std::fill(rank_sum_.begin(), rank_sum_.end(), 1000000u);
+        std::fill(words_.begin(), words_.end(), (uint8_t)0);
+        first_ = true;
+        after_literal_ = true;
+    }
+
     // Bucket::forward for all contexts, src/lz.rs:359-364, src/matcher.rs:82-87
     void forward(size_t forward_len) {
         for (auto& p : ring_pos_) p = p > forward_len ? (uint32_t)(p - forward_len) : 0;
@@ -243,12 +256,29 @@ class Decoder {  // LZDecoder, src/lz.rs:348-479
     bool first_ = true, after_literal_ = true;
 };
 
+// the buffers of one orz::decode call (src/lib.rs:99-101), reusable across the members of a container
+struct DecodeWorkspace {
+    Decoder dec;
+    std::vector<uint8_t> win, tbuf;
+    bool used = false, slid = false;
+    DecodeWorkspace() : win((size_t)kBlock * 2 + 2 * kSent, 0), tbuf((size_t)kPre * 3) {}
+    void begin_stream() {
+        if (!used) { used = true; return; }
+        dec.reset();
+        // bytes at and after SBVEC_PREMATCH_LEN are always written before they are read; the history below it
+        // is zero unless the previous stream slid its window there
+        if (slid) std::fill(win.begin(), win.begin() + kSent + kPre, (uint8_t)0);
+        slid = false;
+    }
+};
+
 // orz::decode over callbacks (src/lib.rs:94-129).  read(buf, n) must fill exactly n bytes or return false.
 template <class ReadExact, class WriteAll, class Progress>
-void decode_stream(ReadExact&& rd, WriteAll&& wr, Progress&& progress) {
-    Decoder dec;
-    std::vector<uint8_t> win((size_t)kBlock * 2 + 2 * kSent, 0), tbuf((size_t)kPre * 3);
-    uint8_t* sbuf = win.data() + kSent;
+void decode_stream(DecodeWorkspace& ws, ReadExact&& rd, WriteAll&& wr, Progress&& progress) {
+    ws.begin_stream();
+    Decoder& dec = ws.dec;
+    std::vector<uint8_t>& tbuf = ws.tbuf;
+    uint8_t* sbuf = ws.win.data() + kSent;
     size_t spos = kPre, in_total = 0, out_total = 0;
     for (;;) {
         size_t t = 0;
@@ -272,11 +302,17 @@ void decode_stream(ReadExact&& rd, WriteAll&& wr, Progress&& progress) {
         if (spos >= kBlock) {  // src/lib.rs:120-125
             std::memmove(sbuf, sbuf + (kBlock - kPre), kPre);
             dec.forward(kBlock - kPre);
+            ws.slid = true;
             progress(false, in_total, out_total);
             spos = kPre;
         }
     }
     progress(true, in_total, out_total);
+}
+template <class ReadExact, class WriteAll, class Progress>
+void decode_stream(ReadExact&& rd, WriteAll&& wr, Progress&& progress) {
+    DecodeWorkspace ws;
+    decode_stream(ws, rd, wr, progress);
 }
 
 }  // namespace host

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <numeric>
 
+#include "../../orz_amd/csrc/orz_decode_device.h"
 #include "../../orz_amd/csrc/orz_stream.h"
 #include "simt.h"
 
@@ -34,6 +35,8 @@ struct EmuBackend {
     void wait(int) {}
     void timed_begin() {}
     void timed_end() {}
+    void set_timing(bool) {}
+    double collect_timed(uint64_t* n) { if (n) *n = 0; return 0.0; }
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     template <class F> void launch(size_t n, const F& f) {
         for (size_t i = 0; i < n; i++) f(i);
@@ -129,3 +132,22 @@ extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, in
     }
 }
 extern "C" void emu_free(void* p) { std::free(p); }
+
+// the device decoder's kernel body and host driver on the CPU: members container -> bytes
+// returns 0, or 1 with a message in err (cap bytes)
+extern "C" int emu_decode_members(const uint8_t* src, size_t n, unsigned slots, uint8_t** dst, size_t* dst_len, size_t* members,
+                                  char* err, size_t cap) {
+    try {
+        EmuBackend be;
+        std::vector<uint8_t> out;
+        orz::DecodeStats st;
+        orz::decode_members_device(be, src, n, out, st, slots ? slots : 4);
+        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(p, out.data(), out.size());
+        *dst = p; *dst_len = out.size(); *members = (size_t)st.members;
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && cap) { std::strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
+        return 1;
+    }
+}

@@ -115,3 +115,14 @@ def test_member_container_decode(oracle, tmp_path):
     assert dst.read_bytes() == b"".join(parts)
     subprocess.check_call([CLI, "decode", "-s", str(src), str(dst)])
     assert dst.read_bytes() == parts[0]
+
+
+def test_members_share_one_workspace(oracle):
+    """orz_decode_members_mem reuses one window / model allocation for all members: a member that slid the
+    window (> one block) must not leak history into the next one"""
+    import orz_amd
+
+    parts = [bytes(17_000_000), b"abc" * 1000, _data.mixed(50_000, seed=8), b"", _data.mixed(20_000, seed=9)]
+    blob = b"".join(oracle.encode(p, i % 3) for i, p in enumerate(parts))
+    out, m = orz_amd.decode_members(blob)
+    assert m == len(parts) and out == b"".join(parts)
