@@ -146,7 +146,7 @@ def main():
         # WRITE_SIZE collected in separate rocprofv3 runs on one 16 MiB block, profiles/): not live
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01e_pmc_hbm_traffic_16MiB_l1.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic_16MiB_l1.json")) as f:
                 traffic = json.load(f).get("parse_wave_hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -172,7 +172,7 @@ def main():
                 "members": world,
                 "segment_bytes": 62,
                 "window_segments": 3072,
-                "handoff_lookback_segments": 63,
+                "handoff_lookback_segments": 24,
                 "handoff_deadline_us": 110,
                 "input": "resident in HBM",
             },

@@ -114,7 +114,7 @@ struct ParseArgs {
     uint64_t* k1;
     uint64_t* k2;
     uint64_t* exitst;         // [nseg + 2]  ExitPair of segment s-1 at [s]
-    uint32_t maxpass = 2;     // walks again at most this many times per sweep
+    uint32_t maxpass = 3;     // walks again at most this many times per sweep
     uint32_t deadline = 0;    // stop waiting for hand-offs this long after the wave started (10 ns ticks; 0 = polls only)
     uint32_t near = 0;        // blocks >= near (far from the front) use the two limits below instead
     uint32_t far_deadline = 0;
@@ -737,7 +737,8 @@ struct ParseWave {
                 const uint64_t F = w.ballot(pub && ExitPair::settled(q));
                 const uint32_t x1 = w.bcast(ExitPair::exit(q), 1);
                 const bool overdue = dl && w.wallclock() - tl0 > dl;
-                if (!overdue && (P & 2) && !(C & 2) && ((F & 2) || (C & 4) || look == 1)) {  // predecessor moved (and is not about to move again)
+                if (!overdue && (P & 2) && !(C & 2)) {  // the predecessor left the stream elsewhere: follow at once, even if it
+                                                        // may move again (waiting for it to settle first measured 6 % slower)
                     again = 1; vnew = x1;
                     break;
                 }

@@ -390,7 +390,7 @@ class StreamEncoder {
         pa.win = win; pa.len = len; pa.nseg = nseg; pa.seg = seg_; pa.wsegs = wsegs_; pa.ring = ring_;
         pa.depth = (uint32_t)cfg_.depth; pa.lazy1 = (uint32_t)cfg_.lazy1; pa.lazy2 = (uint32_t)cfg_.lazy2; pa.dmax = dmax_;
         pa.lt0 = lt_carry_; pa.par = 0; pa.prof = (getenv("ORZ_PROF") ? 1 : 0) | (getenv("ORZ_NO_E1") ? 2 : 0);
-        pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 63;
+        pa.chain = getenv("ORZ_CHAIN") ? (uint32_t)atoi(getenv("ORZ_CHAIN")) : 24;
         if (pa.chain < 1) pa.chain = 1;
         pa.polls = getenv("ORZ_POLLS") ? (uint32_t)atoi(getenv("ORZ_POLLS")) : be_.handoff_polls();
         if (getenv("ORZ_MAXPASS")) pa.maxpass = (uint32_t)atoi(getenv("ORZ_MAXPASS"));
