@@ -1,8 +1,9 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
 as MI355X_MICROARCH.md prescribes: TCC slots do not fit both).  Values are KiB per dispatch as rocprofv3
 reports them; FETCH_SIZE under-counts wide coalesced 16 B/lane streams by 2x on gfx950 (guide, section HBM) --
-the parse kernel's accesses are narrow and scattered, so no correction is applied and the figure is
-marked uncalibrated."""
+the parse kernel's accesses are narrow and scattered; tools/pmc_calibrate.py measures what the counter
+reports for that pattern on the box (128 B per scattered 32-byte row, 1.00 x for a streaming read), so the
+figure is the counter as is: line fetches x 128 B."""
 import json
 import sqlite3
 import sys
@@ -26,7 +27,7 @@ if __name__ == "__main__":
         rows.append({"kernel": name[:100], "dispatches": int(max(nf, nw)),
                      "fetch_KiB_per_dispatch": round(sf / nf, 1) if nf else None,
                      "write_KiB_per_dispatch": round(sw / nw, 1) if nw else None})
-    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes, uncalibrated)", "kernels": rows[:24]}
+    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes; scattered loads count 128 B per line, see pmc_calibrate.py)", "kernels": rows[:24]}
     for r in rows:
         if "ParseWave" in r["kernel"]:
             res["parse_wave_hbm_bytes_per_launch"] = int(((r["fetch_KiB_per_dispatch"] or 0) + (r["write_KiB_per_dispatch"] or 0)) * 1024)
