@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchu
         rebuild_summaries(a.kbits, a.k1, a.k2, a.nkwords, blockIdx.x - nchunks - nvblk, threadIdx.x, (uint64_t*)rows, sync);
 }
 
+// Huffman code lengths + canonical codes (src/huffman.rs:27-141): one wavefront per (chunk, table); the
+// weights and the heap / tree scratch live in LDS, lane 0 runs the (serial, tie-break exact) construction.
+__global__ __launch_bounds__(64) void orz_huff_kernel(HuffBuild f) {
+    __shared__ uint32_t sc[HuffBuild::kHuffScratch];
+    __shared__ uint32_t w0[kSyms];
+    const uint32_t tid = blockIdx.x, ch = tid / 3, t = tid % 3;
+    const uint32_t n = HuffBuild::table_syms(t);
+    const uint32_t* src = f.hw + (size_t)ch * kHwStride + HuffBuild::table_off(t);
+    for (uint32_t i = threadIdx.x; i < n; i += 64) w0[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) f.build(tid, w0, sc);
+}
+
 // SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context, the 389-entry value and
 // index tables live in LDS; lane 0 walks the context's item run (the chain is serial by
 // definition), all 64 lanes move the tables in and out of LDS.
@@ -223,6 +236,11 @@ class HipBackend {
     void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         if (!nblocks) return;
         hipLaunchKernelGGL(orz_wave_kernel<K>, dim3((unsigned)nblocks), dim3(64), lds_bytes, stream_, k);
+        ORZ_HIP_CHECK(hipGetLastError());
+    }
+    void huffbuild(const HuffBuild& f) {
+        if (!f.nchunks) return;
+        hipLaunchKernelGGL(orz_huff_kernel, dim3(f.nchunks * 3), dim3(64), 0, stream_, f);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void rank(const RankArgs& a, uint32_t nchunks) {

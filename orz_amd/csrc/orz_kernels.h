@@ -317,15 +317,21 @@ struct HuffBuild {
     ORZ_HD static bool less(uint32_t wa, uint32_t ia, uint32_t wb, uint32_t ib) {
         return wa < wb || (wa == wb && ia < ib);
     }
-    ORZ_HD void operator()(size_t tid) const {
+    ORZ_HD static uint32_t table_off(uint32_t t) { return t == 0 ? 0 : (t == 1 ? kSyms : 2 * kSyms); }
+    ORZ_HD static uint32_t table_syms(uint32_t t) { return t == 2 ? kLenSyms : kSyms; }
+    ORZ_HD void operator()(size_t tid) const {  // scratch in global memory (host emulation; any backend)
         if (tid >= (size_t)nchunks * 3) return;
+        const uint32_t ch = (uint32_t)(tid / 3), t = (uint32_t)(tid % 3);
+        build(tid, hw + (size_t)ch * kHwStride + table_off(t), scratch + tid * kHuffScratch);
+    }
+    // table `tid` = (chunk, table) from the weights at w0, with kHuffScratch words of scratch at sc: the HIP
+    // backend runs this with both in LDS (the heap is ~35 K dependent accesses: 16 ms from HBM, < 1 ms from LDS)
+    ORZ_HD void build(size_t tid, const uint32_t* w0, uint32_t* sc) const {
         uint32_t ch = (uint32_t)(tid / 3), t = (uint32_t)(tid % 3);
-        uint32_t off = t == 0 ? 0 : (t == 1 ? kSyms : 2 * kSyms);
-        uint32_t n = t == 2 ? kLenSyms : kSyms;
-        const uint32_t* w0 = hw + (size_t)ch * kHwStride + off;
+        uint32_t off = table_off(t);
+        uint32_t n = table_syms(t);
         uint8_t* lens = hl + (size_t)ch * kHwStride + off;
         uint16_t* codes = hc + (size_t)ch * kHwStride + off;
-        uint32_t* sc = scratch + tid * kHuffScratch;
         uint32_t* w = sc;                  // [2n] node weights
         uint32_t* c1 = sc + 2 * kSyms;     // [2n]
         uint32_t* c2 = sc + 4 * kSyms;     // [2n]

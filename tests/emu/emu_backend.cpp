@@ -44,6 +44,7 @@ struct EmuBackend {
     template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
     }
+    void huffbuild(const orz::HuffBuild& f) { launch((size_t)f.nchunks * 3, f); }
     void rank(const orz::RankArgs& a, uint32_t nchunks) {
         // one block per chunk, 256 threads around one barrier: run each block as two thread loops
         std::vector<uint32_t> rows((orz::kRankChunk + 1) * 256);
