@@ -196,6 +196,30 @@ def test_members_concurrent_on_one_gpu(oracle, tmp_path):
     assert decf.read_bytes() == data[:9_000_000]
 
 
+@pytest.mark.parametrize("kind", ["text", "zeros_noise"])
+def test_baseline_configs_2_and_4_members_at_l2(oracle, kind):
+    """BASELINE.json configs[2] / configs[4] in small: -l2, full 16 MiB members (the sweep window of -l2 is
+    sized from the kernel's LDS footprint), text and the degenerate zeros + 1 % noise regime; every member is the
+    oracle's stream for that slice.  tools/gpu_configs.py runs the same at 1 GB (round trip only)."""
+    import corpus
+    import orz_amd
+    from orz_amd import dist as od
+
+    member = 1 << 24
+    n = 2 * member + 3_000_000
+    data = corpus.text_corpus(100_000_000)[5_000_000:5_000_000 + n] if kind == "text" else corpus.zeros_noise(n)
+    enc = orz_amd.MemberEncoder(device=0, level=2, jobs=2)
+    try:
+        container, nm = enc.encode(data, member_bytes=member)
+    finally:
+        enc.close()
+    pieces = od.split_members(container)
+    assert nm == len(pieces) == 3
+    for i, p in enumerate(pieces):
+        assert p == oracle.encode(data[i * member:(i + 1) * member], 2), "member %d" % i
+    assert orz_amd.decode_members(container) == (data, 3)
+
+
 def test_randomised_settings_do_not_change_the_stream():
     """short run of tools/gpu_fuzz.py: random shapes / sizes / levels / speculation settings vs the oracle"""
     import subprocess

@@ -77,8 +77,9 @@ def text_corpus(nbytes):
     return data
 
 
-def _splitmix64(n, seed):
-    x = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)
+def _splitmix64(first, n, seed):
+    """splitmix64 outputs number first+1 .. first+n of the stream seeded with `seed`"""
+    x = (np.arange(first + 1, first + n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)
     x ^= x >> np.uint64(30)
     x *= np.uint64(0xBF58476D1CE4E5B9)
     x ^= x >> np.uint64(27)
@@ -88,11 +89,17 @@ def _splitmix64(n, seed):
 
 
 def zeros_noise(nbytes, seed=0x6F727A):
+    """byte i = 0, except with probability 0.01 uniform in 1..255; generated in
+    pieces so that a gigabyte does not need tens of gigabytes of temporaries"""
+    out = np.zeros(nbytes, dtype=np.uint8)
+    step = 1 << 24
     with np.errstate(over="ignore"):
-        r = _splitmix64(nbytes, seed)
-    noisy = (r % np.uint64(100)) == 0
-    vals = ((r >> np.uint64(32)) % np.uint64(255) + np.uint64(1)).astype(np.uint8)
-    out = np.where(noisy, vals, 0).astype(np.uint8)
+        for at in range(0, nbytes, step):
+            n = min(step, nbytes - at)
+            r = _splitmix64(at, n, seed)
+            quarter = np.nonzero((r & np.uint64(3)) == 0)[0]            # r % 100 == 0  <=>  r % 4 == 0 and r % 25 == 0
+            noisy = quarter[(r[quarter] % np.uint64(25)) == 0]
+            out[at + noisy] = ((r[noisy] >> np.uint64(32)) % np.uint64(255) + np.uint64(1)).astype(np.uint8)
     return out.tobytes()
 
 

@@ -1,0 +1,55 @@
+"""BASELINE.json configs[2] and configs[4] on one GPU, through the product path only:
+  C2  1 GB of text (the 100 MB bench workload repeated: no cross-copy matches, the window is 32 MiB), -l2,
+      independent members of 16 MiB
+  C4  1 GB of zeros with 1 % uniform noise (splitmix64, seed 0x6f727a), -l2 -- degenerate regime of the
+      symbol-ranking / Huffman path
+Reports encode MB/s, ratio, and the size-independent parity property available without the oracle: the
+container decodes (library host decoder, member by member) to the input, bit for bit.  The byte-for-byte
+comparison with the oracle at full size lives in tests/ (smaller sizes) -- tools never touch oracle/.
+
+  python tools/gpu_configs.py [total_bytes=1000000000] [jobs=2]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import corpus  # noqa: E402
+import orz_amd  # noqa: E402
+
+
+def run(name, data, level, jobs, member=1 << 24):
+    enc = orz_amd.MemberEncoder(device=0, level=level, jobs=jobs)
+    enc.encode(data[: 2 * member], member_bytes=member)  # warm-up: allocations, first launches
+    t0 = time.time()
+    blob, n = enc.encode(data, member_bytes=member)
+    t_enc = time.time() - t0
+    enc.close()
+    t0 = time.time()
+    back, m = orz_amd.decode_members(blob)
+    t_dec = time.time() - t0
+    ok = m == n and hashlib.sha256(back).digest() == hashlib.sha256(data).digest()
+    print(json.dumps({"config": name, "bytes": len(data), "level": level, "members": n, "member_bytes": member, "jobs": jobs,
+                      "compressed": len(blob), "ratio": round(len(blob) / len(data), 5),
+                      "encode_MBps": round(len(data) / t_enc / 1e6, 1), "encode_s": round(t_enc, 2),
+                      "host_decode_MBps": round(len(data) / t_dec / 1e6, 1), "round_trip_exact": bool(ok)}), flush=True)
+    return ok
+
+
+def main():
+    total = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
+    jobs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    base = corpus.text_corpus(100_000_000)
+    text = (base * (total // len(base) + 1))[:total]
+    ok = run("C2: text x%d, -l2, 16 MiB members" % (total // len(base)), text, 2, jobs)
+    del text
+    ok &= run("C4: zeros + 1% noise, -l2, 16 MiB members", corpus.zeros_noise(total), 2, jobs)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
