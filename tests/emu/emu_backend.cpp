@@ -134,6 +134,16 @@ extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, in
 }
 extern "C" void emu_free(void* p) { std::free(p); }
 
+// the hand-off word of the parse kernel (orz_parse.h, ExitPair): pack, then unpack into out[4] = entry, exit, settled, sweep
+extern "C" unsigned long long emu_exitpair(unsigned sweep, int settled, unsigned entry, unsigned exit, unsigned* out) {
+    const uint64_t e = orz::ExitPair::make(sweep, settled != 0, entry, exit);
+    out[0] = orz::ExitPair::entry(e);
+    out[1] = orz::ExitPair::exit(e);
+    out[2] = orz::ExitPair::settled(e) ? 1u : 0u;
+    out[3] = orz::ExitPair::sweep(e);
+    return e;
+}
+
 // the device decoder's kernel body and host driver on the CPU: members container -> bytes
 // returns 0, or 1 with a message in err (cap bytes)
 extern "C" int emu_decode_members(const uint8_t* src, size_t n, unsigned slots, uint8_t** dst, size_t* dst_len, size_t* members,

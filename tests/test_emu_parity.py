@@ -2,6 +2,8 @@
 emulation backend (tests/emu: thread kernels as loops, the wave-cooperative parse on a SIMT
 emulator), must reproduce the oracle's stream byte for byte.  Sizes are small because the emulator
 is slow; the GPU tier (test_gpu_parity.py) covers the full sizes through the C ABI."""
+import os
+
 import pytest
 
 import _data
@@ -63,3 +65,24 @@ def test_ring_wraps_within_a_context(emu, oracle):
     data = (b"ab " * 5000) + _data.text(12_000, seed=4) + (b"ab " * 1500)
     out, _ = emu(data)
     assert out == oracle.encode(data, 1)
+
+
+def test_handoff_word_packs_and_unpacks(emu):
+    """ExitPair (orz_parse.h): entry 27 bit, exit as a distance of < 512 positions + type, settled flag, sweep"""
+    import ctypes
+    import random
+
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libemu.so"))
+    lib.emu_exitpair.restype = ctypes.c_ulonglong
+    out = (ctypes.c_uint * 4)()
+    rnd = random.Random(5)
+    kpre, kblock = 16_777_215, 33_554_431
+    for _ in range(20_000):
+        p = rnd.choice([kpre, kblock - 1, rnd.randrange(kpre, kblock)])
+        d = rnd.choice([0, 1, 62, 240, 301, 511, rnd.randrange(0, 512)])
+        if p + d > kblock:
+            d = kblock - p
+        entry, exit_ = (p << 2) | rnd.randrange(3), ((p + d) << 2) | rnd.randrange(3)
+        sweep, settled = rnd.choice([0, 1, 4, (1 << 25) - 1, rnd.randrange(1 << 25)]), rnd.randrange(2)
+        lib.emu_exitpair(sweep, settled, entry, exit_, out)
+        assert list(out) == [entry, exit_, settled, sweep]
