@@ -146,7 +146,7 @@ def main():
         # WRITE_SIZE collected in separate rocprofv3 runs on one 16 MiB block, profiles/): not live
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic_16MiB_l1.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic_16MiB_l1.json")) as f:
                 traffic = json.load(f).get("parse_wave_hbm_bytes_per_launch")
         except Exception:
             traffic = None
