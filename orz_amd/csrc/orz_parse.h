@@ -97,9 +97,9 @@ struct ParseArgs {
     uint32_t par;             // sweep parity
     uint32_t prof;            // sample phase timings into ctl->prof (diagnostics)
     uint32_t sweep;           // 1-based id of this launch within the block (stamps the exit states)
-    uint32_t polls;           // hand-off: how often a wave polls for its predecessor's stamp before it gives up
-    uint32_t chain;           // segments per hand-off group: all but a group's first wait for their predecessor's
-                              // exit state of THIS sweep before walking (1 = never wait)
+    uint32_t polls;           // hand-off: poll cap per wait (the wall-clock deadline is what normally ends a wait)
+    uint32_t chain;           // hand-off look-back: a wave watches the pairs of this many predecessors (<= 63; 1 = no
+                              // hand-off inside a sweep)
     SlotRec* srec;
     const uint32_t* idx;
     const uint32_t* runstart;
@@ -601,11 +601,11 @@ struct ParseWave {
         }
 
         // ---- phase 2: the segment's items.  Everything up to here did not depend on the entry state (where the
-        // previous segment left the stream).  The wave walks optimistically from the entry it knows, then --
-        // inside a hand-off group of `chain` segments -- waits a bounded time for its predecessor's exit of THIS
-        // sweep; only if that differs from what it assumed does it walk again.  Each wave stamps its exit once
-        // per sweep, after it is sure of its entry; a parse that shifts and re-synchronises a segment or two
-        // later thus settles within one sweep instead of costing one sweep per segment.
+        // previous segment left the stream).  The wave walks optimistically from the entry it knows and publishes
+        // the pair (entry, exit); it then watches the pairs its `chain` predecessors publish in THIS sweep: the
+        // predecessor left the stream elsewhere -> walk again from there; every link back to a settled segment
+        // agrees -> settled.  A parse that shifts and re-synchronises a segment or two later thus settles within
+        // one sweep instead of costing one sweep per segment.
         const bool anchor = sg == 0 || a.chain <= 1 || w.block() == 0;  // the front segment's entry is exact
         const uint32_t dl = far ? a.far_deadline : a.deadline;
         const uint32_t look = anchor ? 0 : (w.block() < a.chain ? w.block() : (a.chain < 63 ? a.chain : 63));
