@@ -9,8 +9,10 @@
  * Parity pinning: the reference ships no golden vectors and cannot be built here (no Rust
  * toolchain, nightly-only crate).  The oracle is pinned by (a) the reference's only unit test
  * (src/coder.rs:224-265) restated in tests/, (b) the hand-derived known-answer vectors of
- * SURVEY.md A.8, (c) encoder->decoder round trips.  Byte-level parity with the Rust encoder on
- * large inputs is therefore "parity unpinned" beyond those vectors.
+ * SURVEY.md A.8, (c) encoder->decoder round trips, (d) agreement, stream for stream, with a second
+ * restatement written independently in Python from the same source (tests/pyref, tests/test_pyref.py).
+ * Byte-level parity with the Rust encoder itself is therefore "parity unpinned" beyond those
+ * (see DESIGN.md).
  */
 #ifndef ORZ_ORACLE_H
 #define ORZ_ORACLE_H
