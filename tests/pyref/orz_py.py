@@ -7,16 +7,16 @@ module by module, keeping the reference's control flow (not the oracle's); tests
 restatements to produce identical streams.  Agreement of two independent readings is the strongest pin available
 here; it is not an output of the reference binary, and DESIGN.md keeps saying "parity unpinned".
 
-Scope: `orz::encode` for inputs of at most one block (no window slide), any LZCfg.  Slow (pure Python loops): meant
-for inputs of a few tens of kilobytes.
+Scope: `orz::encode`, any LZCfg, any number of blocks (window slide and LZEncoder::forward included).  Slow (pure
+Python loops): meant for inputs of a few tens of kilobytes, or larger ones with few items (long runs).
 
 Source map (all /root/reference/src):
   lib.rs:31-34,54-92   constants, window layout, chunk loop, EOF chunk       -> encode()
   ioutil.rs:79-88      write_len                                            -> write_len()
   lz.rs:89-346         LZEncoder::encode                                    -> Encoder.encode_chunk()
   lz.rs:482-534        hash1, hash2, reduced-offset id table                -> hash1(), hash2(), ROID
-  matcher.rs:62-80     Bucket::update                                       -> Bucket.update()
-  matcher.rs:115-228   BucketMatcher::{update, find_match, has_lazy_match}  -> Matcher
+  matcher.rs:62-87     Bucket::{update, forward}                            -> Bucket.update(), Bucket.forward()
+  matcher.rs:115-228   BucketMatcher::{update, forward, find_match, has_lazy_match} -> Matcher, find_match(), ...
   matcher.rs:256-263   hash_dword                                           -> hash_dword()
   mem.rs:41-70         mem_fast_common_prefix, mem_fast_equal               -> common_prefix(), fast_equal()
   symrank.rs:22-97     SymRankCoder                                         -> SymRank
@@ -223,6 +223,9 @@ class Bucket:  # matcher.rs:28-100
         self.len_exp[new_head] = match_len
         self.head = new_head
 
+    def forward(self, forward_len):  # matcher.rs:82-87
+        self.pos = [p - forward_len if p > forward_len else 0 for p in self.pos]
+
 
 class Matcher:  # matcher.rs:102-228
     __slots__ = ("heads", "nexts")
@@ -231,14 +234,25 @@ class Matcher:  # matcher.rs:102-228
         self.heads = [-1] * HASHSIZE
         self.nexts = [-1] * RING
 
+    def forward(self, bucket):  # matcher.rs:123-133: entries that point at an out-of-date node
+        self.heads = [-1 if h != -1 and bucket.pos[h] == 0 else h for h in self.heads]
+        self.nexts = [-1 if x != -1 and bucket.pos[x] == 0 else x for x in self.nexts]
+
 
 class Window:
-    """sbuf with its sentinels: index i of the reference's sbuf is self.b[SENTINEL + i]; zeros everywhere else"""
+    """sbvec_buf of lib.rs:67-69: index i of the reference's sbvec is self.b[SENTINEL + i].  One allocation for the
+    whole stream: what a block leaves behind stays there (bytes past a short final block are the previous block's)."""
 
-    def __init__(self, data):
-        self.n = PREMATCH + len(data)               # sbuf.len() as LZEncoder::encode sees it (lib.rs:77)
-        self.b = bytearray(SENTINEL + self.n + MAX_LEN + 2 * SENTINEL)  # enough zero tail for every read past the end
+    def __init__(self):
+        self.b = bytearray(BLOCK + SENTINEL * 2)
+        self.n = PREMATCH
+
+    def load(self, data):  # read_repeatedly into sbvec[SBVEC_PREMATCH_LEN..]
         self.b[SENTINEL + PREMATCH:SENTINEL + PREMATCH + len(data)] = data
+        self.n = PREMATCH + len(data)  # sbuf.len() as LZEncoder::encode sees it (lib.rs:77)
+
+    def slide(self):  # sbvec.copy_within(sbvec.len() - SBVEC_PREMATCH_LEN.., 0) on the FULL block slice (lib.rs:83)
+        self.b[SENTINEL:SENTINEL + PREMATCH] = self.b[SENTINEL + BLOCK - PREMATCH:SENTINEL + BLOCK]
 
     def u8(self, i):
         return self.b[SENTINEL + i]
@@ -346,6 +360,11 @@ class Encoder:  # LZEncoder + LZContext, lz.rs:49-80
         self.first_block = True
         self.after_literal = True
 
+    def forward(self, forward_len):  # lz.rs:82-87
+        for i in range(256):
+            self.buckets[i].forward(forward_len)
+            self.matchers[i].forward(self.buckets[i])
+
     def _insert(self, w, ctx, spos, reduced_offset, match_len):
         b, m = self.buckets[ctx], self.matchers[ctx]
         b.update(spos, reduced_offset, match_len)      # lz.rs:191-195 / 209
@@ -446,18 +465,22 @@ def write_len(n):  # ioutil.rs:79-88
 
 
 def encode(data, cfg):
-    """orz::encode (lib.rs:58-92) for at most one block of input; cfg = (match_depth, lazy_depth1, lazy_depth2)"""
+    """orz::encode (lib.rs:58-92); cfg = (match_depth, lazy_depth1, lazy_depth2)"""
     data = bytes(data)
-    if len(data) > BLOCK - PREMATCH:
-        raise ValueError("pyref handles a single block only")
     out = bytearray()
-    if data:
-        enc = Encoder()
-        w = Window(data)
+    enc = Encoder()
+    w = Window()
+    at = 0
+    while at < len(data):
+        piece = data[at:at + BLOCK - PREMATCH]
+        at += len(piece)
+        w.load(piece)
         spos = PREMATCH
-        while spos < PREMATCH + len(data):
+        while spos < PREMATCH + len(piece):
             spos, chunk = enc.encode_chunk(cfg, w, spos)
             out += write_len(len(chunk))
             out += chunk
+        w.slide()
+        enc.forward(BLOCK - PREMATCH)
     out += write_len(0)
     return bytes(out)

@@ -75,3 +75,36 @@ def test_random_structures_agree(oracle, seed):
             out += b" the " * rnd.randrange(1, 5) + base[:rnd.randrange(3, 40)]
     level = rnd.randrange(3)
     assert orz_py.encode(bytes(out), LEVELS[level]) == oracle.encode(bytes(out), level)
+
+
+def test_two_blocks_agree(oracle):
+    """window slide + LZEncoder::forward: a full 16 MiB block and a short second one, made of long runs and short text
+    snippets so that pure Python gets through it; the second block matches into the history, and the last items of the
+    first block are hashed with whatever lies past the block end (the hazard DESIGN.md section 2 describes)"""
+    import random
+
+    rnd = random.Random(77)
+    base = _data.text(50_000, seed=5)
+    out = bytearray()
+    target = (1 << 24) + 300_000
+    while len(out) < target:
+        out += bytes([rnd.randrange(256)]) * rnd.randrange(400, 4000)
+        at = rnd.randrange(len(base) - 64)
+        out += base[at:at + rnd.randrange(8, 48)]
+    # dense text on both sides of the block boundary: many items whose candidates sit in the slid history
+    lo, hi = (1 << 24) - 120_000, (1 << 24) + 120_000
+    k = 0
+    while lo < hi:
+        piece = base[(k * 7919) % 40_000:][:rnd.randrange(20, 900)]
+        out[lo:lo + len(piece)] = piece
+        lo += len(piece)
+        k += 1
+    data = bytes(out[:target])
+    assert orz_py.encode(data, LEVELS[1]) == oracle.encode(data, 1)
+
+
+def test_two_chunks_agree(oracle):
+    """more than 2^20 items in one block: the second chunk starts without a census, with the running symbol ranks
+    and fresh Huffman tables (lz.rs:131,238-270)"""
+    data = _data.random_bytes(1_080_000)  # incompressible: one item per byte
+    assert orz_py.encode(data, LEVELS[0]) == oracle.encode(data, 0)
