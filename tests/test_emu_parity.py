@@ -46,14 +46,14 @@ def test_late_waves_may_keep_their_previous_evaluation(emu, oracle, order, monke
 
 @pytest.mark.parametrize("seg,win", [(62, 64), (62, 1024), (40, 256), (16, 512), (33, 128), (8, 600)])
 def test_segment_and_window_sizes(emu, oracle, seg, win):
-    data = _data.mixed(25_000 if seg > 16 else 8_000, seed=seg)
+    data = _data.mixed(25_000 if seg > 16 else (8_000 if seg > 8 else 4_000), seed=seg)
     out, _ = emu(data, seg=seg, win=win)
     assert out == oracle.encode(data, 1)
 
 
 @pytest.mark.parametrize("maker", ["zeros", "random", "p1", "p2", "p3", "p5"])
 def test_degenerate_inputs(emu, oracle, maker):
-    n = 20_000
+    n = 20_000 if maker in ("zeros", "random") else 12_000  # (periodic data is the emulator's slowest case)
     data = {"zeros": lambda: _data.zeros_noise(n), "random": lambda: _data.random_bytes(n), "p1": lambda: _data.periodic(n, 1),
             "p2": lambda: _data.periodic(n, 2), "p3": lambda: _data.periodic(n, 3), "p5": lambda: _data.periodic(n, 5)}[maker]()
     out, _ = emu(data)
