@@ -1,0 +1,25 @@
+"""Sanitizer run of the encoder's kernel bodies (parse, rank, tail stage) on the host emulation backend (TEST INFRASTRUCTURE; see run.sh)."""
+import ctypes
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _data  # noqa: E402
+import _oracle  # noqa: E402
+
+lib = ctypes.CDLL(os.environ.get("ORZ_EMU_ASAN", "/tmp/libemu_asan.so"))
+
+
+def enc(data, cfg=(15,9,6), seg=62, win=128, order=2):
+    dst = ctypes.POINTER(ctypes.c_uint8)(); n = ctypes.c_size_t(); st = (ctypes.c_ulonglong*5)()
+    rc = lib.emu_encode(bytes(data), ctypes.c_size_t(len(data)), cfg[0], cfg[1], cfg[2], seg, win, order, ctypes.byref(dst), ctypes.byref(n), st)
+    assert rc == 0
+    out = ctypes.string_at(dst, n.value); lib.emu_free(dst); return out
+for name, data, lv, seg, win in [("mixed", _data.mixed(30_000, seed=2), 1, 62, 128), ("zeros", _data.zeros_noise(20_000), 2, 62, 64), ("p3", _data.periodic(6_000, 3), 0, 17, 200), ("tiny", b"abc", 1, 62, 64), ("one", b"x", 2, 8, 300)]:
+    cfg = _oracle.LEVELS[lv]
+    out = enc(data, cfg, seg, win)
+    print(name, len(out), out == _oracle.encode(data, lv))
