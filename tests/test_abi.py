@@ -93,3 +93,16 @@ def test_parse_kernel_keeps_three_waves_per_simd():
     fields = dict(ln.split(": ", 1) for ln in parse[0].splitlines()[1:] if ": " in ln)
     assert int(fields["Occupancy [waves/SIMD]"]) >= 3, fields
     assert int(fields["ScratchSize [bytes/lane]"]) == 0 and int(fields["VGPRs Spill"]) == 0, fields
+
+
+def test_bench_traffic_artefact_is_committed():
+    """bench.py reports `roofline.traffic` from the committed PMC summary of the dominant kernel: the file it names
+    must exist and hold the parse kernel's per-launch bytes"""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    names = re.findall(r'"(r\d+\w*_pmc_hbm_traffic_\w+\.json)"', src)
+    assert len(names) == 1, names
+    data = json.load(open(os.path.join(root, "profiles", names[0])))
+    assert data["parse_wave_hbm_bytes_per_launch"] > 0
