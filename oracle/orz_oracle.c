@@ -591,6 +591,7 @@ struct orc_lz_encoder { /* LZEncoder, src/lz.rs:69-72 */
     bmatcher* matchers; /* 256 */
     mitem* items;       /* LZ_CHUNK_SIZE */
     orc_trace* trace;
+    uint16_t* nodeof;   /* plan-driven encoder only: ring node index of each window position */
 };
 
 orc_lz_encoder* orc_lz_encoder_new(void) { /* :75-80 */
@@ -608,6 +609,7 @@ void orc_lz_encoder_free(orc_lz_encoder* e) {
     lzctx_free(&e->ctx);
     free(e->matchers);
     free(e->items);
+    free(e->nodeof);
     free(e);
 }
 void orc_lz_encoder_set_trace(orc_lz_encoder* e, orc_trace* t) { e->trace = t; }
@@ -617,17 +619,95 @@ void orc_lz_encoder_forward(orc_lz_encoder* e, size_t forward_len) { /* :82-87 *
         bucket_forward(&e->ctx.buckets[i], forward_len);
         bm_forward(&e->matchers[i], &e->ctx.buckets[i]);
     }
+    if (e->nodeof) memmove(e->nodeof, e->nodeof + forward_len, ((size_t)ORC_LZ_BLOCK_SIZE + 1 - forward_len) * sizeof(uint16_t));
 }
 
-void orc_lz_encoder_encode(orc_lz_encoder* e, const orc_lzcfg* cfg, const uint8_t* sbuf,
-                           size_t sbuf_len, uint8_t* tbuf, size_t spos, size_t* spos_out,
-                           size_t* tlen_out) { /* :89-346 */
+/* Second half of LZEncoder::encode (src/lz.rs:236-346): census header on the first chunk, symbol ranking,
+ * Huffman tables, item emit.  Shared by the reference parse below and by the plan-driven encoder. */
+static size_t emit_items(orc_lz_encoder* e, mitem* items, size_t n_items, size_t spos, size_t sbuf_len,
+                         uint8_t* tbuf, size_t trace_base) {
     lzctx* c = &e->ctx;
     bitenc enc;
     enc.out = tbuf;
     enc.pos = 0;
     enc.b.value = 0;
     enc.b.len = 0;
+    if (c->first_block) { /* :238-265 */
+        uint32_t counts[ORC_NUM_SYMBOLS];
+        memset(counts, 0, sizeof counts);
+        for (size_t i = 0; i < n_items; i++) counts[items[i].symbol]++;
+        uint32_t num_counted = 0;
+        for (unsigned s = 0; s < ORC_NUM_SYMBOLS; s++) num_counted += counts[s] > 1;
+        /* stable sort by Reverse(max(count,1)): insertion sort is stable */
+        uint16_t vs[ORC_NUM_SYMBOLS];
+        for (unsigned s = 0; s < ORC_NUM_SYMBOLS; s++) {
+            uint32_t key = counts[s] > 1 ? counts[s] : 1;
+            unsigned j = s;
+            while (j > 0) {
+                uint32_t kprev = counts[vs[j - 1]] > 1 ? counts[vs[j - 1]] : 1;
+                if (kprev >= key) break;
+                vs[j] = vs[j - 1];
+                j--;
+            }
+            vs[j] = (uint16_t)s;
+        }
+        enc_varint(&enc, num_counted);
+        for (uint32_t i = 0; i < num_counted; i++) enc_raw(&enc, vs[i], 9);
+        orc_symrank init;
+        orc_symrank_new(&init);
+        orc_symrank_init(&init, vs);
+        for (int i = 0; i < 512; i++) c->symranks[i] = init;
+        c->first_block = 0;
+    }
+
+    enc_varint(&enc, (uint32_t)(spos < sbuf_len ? spos : sbuf_len)); /* :268-269 */
+    enc_varint(&enc, (uint32_t)n_items);
+
+    uint32_t w1[2][ORC_NUM_SYMBOLS]; /* :272-305 */
+    uint32_t w2[ORC_MATCH_MAX_LEN];
+    memset(w1, 0, sizeof w1);
+    memset(w2, 0, sizeof w2);
+    for (size_t i = 0; i < n_items; i++) {
+        mitem* p = &items[i];
+        uint16_t r = orc_symrank_encode(&c->symranks[p->symrank_context], p->symbol, p->symrank_unlikely);
+        w1[p->after_literal][r]++;
+        if (p->is_match && p->encoded_match_len >= LZ_LENID_SIZE - 1) w2[p->encoded_match_len]++;
+        p->symbol = r;
+        if (e->trace && trace_base + i < e->trace->n) e->trace->items[trace_base + i].rank = r;
+    }
+    uint8_t l0[ORC_NUM_SYMBOLS], l1[ORC_NUM_SYMBOLS], l2[ORC_MATCH_MAX_LEN]; /* :306-318 */
+    uint16_t k0[ORC_NUM_SYMBOLS], k1[ORC_NUM_SYMBOLS], k2[ORC_MATCH_MAX_LEN];
+    orc_huffman_lengths(w1[0], ORC_NUM_SYMBOLS, 15, l0);
+    orc_huffman_lengths(w1[1], ORC_NUM_SYMBOLS, 15, l1);
+    orc_huffman_lengths(w2, ORC_MATCH_MAX_LEN, 15, l2);
+    enc_huffman_table(&enc, l0, ORC_NUM_SYMBOLS);
+    enc_huffman_table(&enc, l1, ORC_NUM_SYMBOLS);
+    enc_huffman_table(&enc, l2, ORC_MATCH_MAX_LEN);
+    orc_huffman_codes(l0, ORC_NUM_SYMBOLS, k0);
+    orc_huffman_codes(l1, ORC_NUM_SYMBOLS, k1);
+    orc_huffman_codes(l2, ORC_MATCH_MAX_LEN, k2);
+
+    for (size_t i = 0; i < n_items; i++) { /* :320-342 */
+        const mitem* p = &items[i];
+        const uint16_t* kk = p->after_literal ? k1 : k0;
+        const uint8_t* ll = p->after_literal ? l1 : l0;
+        enc_reserve(&enc);
+        bb_put(&enc.b, ll[p->symbol], kk[p->symbol]);
+        if (p->is_match) {
+            enc_raw(&enc, p->robits, p->robitlen);
+            if (p->encoded_match_len >= LZ_LENID_SIZE - 1) {
+                enc_reserve(&enc);
+                bb_put(&enc.b, l2[p->encoded_match_len], k2[p->encoded_match_len]);
+            }
+        }
+    }
+    return enc_finish(&enc);
+}
+
+void orc_lz_encoder_encode(orc_lz_encoder* e, const orc_lzcfg* cfg, const uint8_t* sbuf,
+                           size_t sbuf_len, uint8_t* tbuf, size_t spos, size_t* spos_out,
+                           size_t* tlen_out) { /* :89-346 */
+    lzctx* c = &e->ctx;
     mitem* items = e->items;
     size_t n_items = 0;
     size_t trace_base = e->trace ? e->trace->n : 0;
@@ -733,77 +813,113 @@ void orc_lz_encoder_encode(orc_lz_encoder* e, const orc_lzcfg* cfg, const uint8_
         }
     }
 
-    if (c->first_block) { /* :238-265 */
-        uint32_t counts[ORC_NUM_SYMBOLS];
-        memset(counts, 0, sizeof counts);
-        for (size_t i = 0; i < n_items; i++) counts[items[i].symbol]++;
-        uint32_t num_counted = 0;
-        for (unsigned s = 0; s < ORC_NUM_SYMBOLS; s++) num_counted += counts[s] > 1;
-        /* stable sort by Reverse(max(count,1)): insertion sort is stable */
-        uint16_t vs[ORC_NUM_SYMBOLS];
-        for (unsigned s = 0; s < ORC_NUM_SYMBOLS; s++) {
-            uint32_t key = counts[s] > 1 ? counts[s] : 1;
-            unsigned j = s;
-            while (j > 0) {
-                uint32_t kprev = counts[vs[j - 1]] > 1 ? counts[vs[j - 1]] : 1;
-                if (kprev >= key) break;
-                vs[j] = vs[j - 1];
-                j--;
-            }
-            vs[j] = (uint16_t)s;
-        }
-        enc_varint(&enc, num_counted);
-        for (uint32_t i = 0; i < num_counted; i++) enc_raw(&enc, vs[i], 9);
-        orc_symrank init;
-        orc_symrank_new(&init);
-        orc_symrank_init(&init, vs);
-        for (int i = 0; i < 512; i++) c->symranks[i] = init;
-        c->first_block = 0;
-    }
-
-    enc_varint(&enc, (uint32_t)(spos < sbuf_len ? spos : sbuf_len)); /* :268-269 */
-    enc_varint(&enc, (uint32_t)n_items);
-
-    uint32_t w1[2][ORC_NUM_SYMBOLS]; /* :272-305 */
-    uint32_t w2[ORC_MATCH_MAX_LEN];
-    memset(w1, 0, sizeof w1);
-    memset(w2, 0, sizeof w2);
-    for (size_t i = 0; i < n_items; i++) {
-        mitem* p = &items[i];
-        uint16_t r = orc_symrank_encode(&c->symranks[p->symrank_context], p->symbol, p->symrank_unlikely);
-        w1[p->after_literal][r]++;
-        if (p->is_match && p->encoded_match_len >= LZ_LENID_SIZE - 1) w2[p->encoded_match_len]++;
-        p->symbol = r;
-        if (e->trace && trace_base + i < e->trace->n) e->trace->items[trace_base + i].rank = r;
-    }
-    uint8_t l0[ORC_NUM_SYMBOLS], l1[ORC_NUM_SYMBOLS], l2[ORC_MATCH_MAX_LEN]; /* :306-318 */
-    uint16_t k0[ORC_NUM_SYMBOLS], k1[ORC_NUM_SYMBOLS], k2[ORC_MATCH_MAX_LEN];
-    orc_huffman_lengths(w1[0], ORC_NUM_SYMBOLS, 15, l0);
-    orc_huffman_lengths(w1[1], ORC_NUM_SYMBOLS, 15, l1);
-    orc_huffman_lengths(w2, ORC_MATCH_MAX_LEN, 15, l2);
-    enc_huffman_table(&enc, l0, ORC_NUM_SYMBOLS);
-    enc_huffman_table(&enc, l1, ORC_NUM_SYMBOLS);
-    enc_huffman_table(&enc, l2, ORC_MATCH_MAX_LEN);
-    orc_huffman_codes(l0, ORC_NUM_SYMBOLS, k0);
-    orc_huffman_codes(l1, ORC_NUM_SYMBOLS, k1);
-    orc_huffman_codes(l2, ORC_MATCH_MAX_LEN, k2);
-
-    for (size_t i = 0; i < n_items; i++) { /* :320-342 */
-        const mitem* p = &items[i];
-        const uint16_t* kk = p->after_literal ? k1 : k0;
-        const uint8_t* ll = p->after_literal ? l1 : l0;
-        enc_reserve(&enc);
-        bb_put(&enc.b, ll[p->symbol], kk[p->symbol]);
-        if (p->is_match) {
-            enc_raw(&enc, p->robits, p->robitlen);
-            if (p->encoded_match_len >= LZ_LENID_SIZE - 1) {
-                enc_reserve(&enc);
-                bb_put(&enc.b, l2[p->encoded_match_len], k2[p->encoded_match_len]);
-            }
-        }
-    }
     *spos_out = spos;
-    *tlen_out = enc_finish(&enc);
+    *tlen_out = emit_items(e, items, n_items, spos, sbuf_len, tbuf, trace_base);
+}
+
+/* ---- plan-driven encoder ------------------------------------------------------------------
+ * The reference decoder accepts ANY parse that its state machine can express.
+ * orc_lz_encoder_encode_plan encodes a caller-supplied parse (item starts, types, match sources and
+ * lengths) with exactly the state updates of LZEncoder::encode (src/lz.rs:191-233) and the same emit
+ * half (emit_items above) -- i.e. "what the reference encoder would write had its match finder made
+ * these choices".  Every item is checked for representability (src/lz.rs:173-177,459-467): source is a
+ * live ring node of the item's context, bytes equal, 4 <= len <= 240, len >= max(len_min,4), WORD
+ * prediction true.  It is the checker for the GPU's fast parse mode; the product never calls it. */
+static int plan_fail(orc_plan_error* err, size_t pos, int code) {
+    if (err) { err->pos = pos; err->code = code; }
+    return -1;
+}
+int orc_lz_encoder_encode_plan(orc_lz_encoder* e, const uint8_t* sbuf, size_t sbuf_len, uint8_t* tbuf,
+                               size_t spos, const orc_plan_item* plan, size_t nplan, size_t* nused_out,
+                               size_t* spos_out, size_t* tlen_out, orc_plan_error* err) {
+    lzctx* c = &e->ctx;
+    mitem* items = e->items;
+    size_t n_items = 0, ip = 0;
+    size_t trace_base = e->trace ? e->trace->n : 0;
+    if (!e->nodeof) {
+        e->nodeof = (uint16_t*)calloc((size_t)ORC_LZ_BLOCK_SIZE + 1, sizeof(uint16_t));
+        if (!e->nodeof) return plan_fail(err, spos, ORC_PLAN_ENOMEM);
+    }
+    while (spos < sbuf_len && n_items < ORC_LZ_CHUNK_SIZE) {
+        if (ip >= nplan) return plan_fail(err, spos, ORC_PLAN_ESHORT);
+        const orc_plan_item* d = &plan[ip++];
+        if (d->pos != spos) return plan_fail(err, spos, ORC_PLAN_EPOS);
+        const uint8_t* lwe = c->words[hash2(sbuf, spos - 1)];
+        uint8_t w0 = lwe[0], w1 = lwe[1];
+        size_t h1 = hash1(sbuf, spos - 1);
+        bucket* b = &c->buckets[h1];
+        mitem it;
+        orc_item tr;
+        memset(&tr, 0, sizeof tr);
+        tr.pos = (uint32_t)spos;
+        it.symrank_context = (uint16_t)(h1 | ((size_t)c->after_literal << 8));
+        it.symrank_unlikely = w0;
+        it.robitlen = 0;
+        it.robits = 0;
+        it.encoded_match_len = 0;
+        it.after_literal = (uint8_t)c->after_literal;
+        it.is_match = 0;
+        size_t adv;
+        if (d->type == ORC_PLAN_MATCH) {
+            size_t L = d->len, q = d->src;
+            if (L < ORC_MATCH_MIN_LEN || L > ORC_MATCH_MAX_LEN) return plan_fail(err, spos, ORC_PLAN_ELEN);
+            if (spos + L > sbuf_len) return plan_fail(err, spos, ORC_PLAN_EEND);
+            if (q == 0 || q >= spos) return plan_fail(err, spos, ORC_PLAN_ESRC);
+            size_t node = e->nodeof[q];
+            if (b->pos[node] != q) return plan_fail(err, spos, ORC_PLAN_ESRC); /* not (any more) in this ring */
+            if (memcmp(sbuf + q, sbuf + spos, L) != 0 && q + L <= spos) return plan_fail(err, spos, ORC_PLAN_EBYTES);
+            for (size_t k = 0; k < L; k++) /* overlapping sources compare byte-wise like the decoder copies */
+                if (sbuf[q + k] != sbuf[spos + k]) return plan_fail(err, spos, ORC_PLAN_EBYTES);
+            size_t ro = nb_sub(b->head, node);
+            size_t lmin = b->len_min[node] > ORC_MATCH_MIN_LEN ? b->len_min[node] : ORC_MATCH_MIN_LEN;
+            size_t lexp = b->len_expected[node] > ORC_MATCH_MIN_LEN ? b->len_expected[node] : ORC_MATCH_MIN_LEN;
+            if (L < lmin) return plan_fail(err, spos, ORC_PLAN_ELENMIN);
+            uint8_t enc_len = L > lexp ? (uint8_t)(L - lmin) : (L < lexp ? (uint8_t)(L - lmin + 1) : 0);
+            uint8_t lenid = enc_len < LZ_LENID_SIZE - 1 ? enc_len : LZ_LENID_SIZE - 1;
+            it.symbol = (uint16_t)(256 + g_roid_enc_id[ro] * LZ_LENID_SIZE + lenid);
+            it.robitlen = g_roid_enc_bits[ro];
+            it.robits = g_roid_enc_rest[ro];
+            it.encoded_match_len = enc_len;
+            it.is_match = 1;
+            tr.reduced_offset = (uint16_t)ro;
+            tr.match_len = (uint8_t)L;
+            tr.enc_len = enc_len;
+            bucket_update(b, spos, ro, L);
+            adv = L;
+        } else if (d->type == ORC_PLAN_WORD) {
+            if (spos + 1 >= sbuf_len) return plan_fail(err, spos, ORC_PLAN_EEND);
+            if (sbuf[spos] != w0 || sbuf[spos + 1] != w1) return plan_fail(err, spos, ORC_PLAN_EWORD);
+            it.symbol = ORC_WORD_SYMBOL;
+            bucket_update(b, spos, 0, 0);
+            adv = 2;
+        } else if (d->type == ORC_PLAN_LITERAL) {
+            it.symbol = sbuf[spos];
+            bucket_update(b, spos, 0, 0);
+            adv = 1;
+        } else {
+            return plan_fail(err, spos, ORC_PLAN_ETYPE);
+        }
+        e->nodeof[spos] = (uint16_t)b->head;
+        items[n_items++] = it;
+        if (e->trace && e->trace->n < e->trace->cap) {
+            tr.symbol = it.symbol;
+            tr.ctx = it.symrank_context;
+            tr.unlikely = w0;
+            tr.after_literal = it.after_literal;
+            e->trace->items[e->trace->n++] = tr;
+        }
+        spos += adv;
+        c->after_literal = d->type == ORC_PLAN_LITERAL;
+        if (d->type != ORC_PLAN_WORD) { /* src/lz.rs:203,233 */
+            size_t k = hash2(sbuf, spos - 3);
+            c->words[k][0] = sbuf[spos - 2];
+            c->words[k][1] = sbuf[spos - 1];
+        }
+    }
+    *nused_out = ip;
+    *spos_out = spos;
+    *tlen_out = emit_items(e, items, n_items, spos, sbuf_len, tbuf, trace_base);
+    return 0;
 }
 
 struct orc_lz_decoder { /* LZDecoder, src/lz.rs:348-350 */
@@ -1013,6 +1129,66 @@ done:
     free(out.p);
     free(sbvec_buf);
     free(tbvec);
+    orc_lz_encoder_free(enc);
+    return rc;
+}
+
+/* orz::encode (src/lib.rs:58-92) with a caller-supplied parse in STREAM offsets. */
+int orc_encode_plan_mem(const uint8_t* src, size_t src_len, const orc_plan_item* plan, size_t nplan,
+                        uint8_t** dst, size_t* dst_len, orc_trace* trace, orc_plan_error* err) {
+    orc_lz_encoder* enc = orc_lz_encoder_new();
+    uint8_t* sbvec_buf = (uint8_t*)calloc(ORC_LZ_BLOCK_SIZE + ORC_SENTINEL_LEN * 2, 1);
+    uint8_t* tbvec = (uint8_t*)malloc((size_t)ORC_PREMATCH_LEN * 3);
+    orc_plan_item* wplan = (orc_plan_item*)malloc(((size_t)ORC_LZ_CHUNK_SIZE + 1) * sizeof(orc_plan_item));
+    obuf out = {NULL, 0, 0};
+    int rc = -1;
+    if (!enc || !sbvec_buf || !tbvec || !wplan) goto done;
+    orc_lz_encoder_set_trace(enc, trace);
+    if (trace) trace->n = 0;
+    uint8_t* sbvec = sbvec_buf + ORC_SENTINEL_LEN;
+    size_t off = 0, ip = 0;
+    for (;;) {
+        size_t room = ORC_LZ_BLOCK_SIZE - ORC_PREMATCH_LEN;
+        size_t n = src_len - off < room ? src_len - off : room;
+        if (n == 0) break;
+        memcpy(sbvec + ORC_PREMATCH_LEN, src + off, n);
+        size_t spos = ORC_PREMATCH_LEN;
+        while (spos < ORC_PREMATCH_LEN + n) {
+            /* stream offsets -> window offsets for the items that can fall into this chunk */
+            size_t k = 0;
+            while (k < ORC_LZ_CHUNK_SIZE && ip + k < nplan && plan[ip + k].pos < off + n) {
+                wplan[k] = plan[ip + k];
+                wplan[k].pos = (uint32_t)(plan[ip + k].pos - off + ORC_PREMATCH_LEN);
+                if (wplan[k].type == ORC_PLAN_MATCH) {
+                    uint64_t back = (uint64_t)plan[ip + k].pos - plan[ip + k].src;
+                    wplan[k].src = back < wplan[k].pos ? (uint32_t)(wplan[k].pos - back) : 0;
+                }
+                k++;
+            }
+            size_t s, t, used;
+            if (orc_lz_encoder_encode_plan(enc, sbvec, ORC_PREMATCH_LEN + n, tbvec, spos, wplan, k, &used, &s, &t, err)) {
+                if (err) err->pos = err->pos - ORC_PREMATCH_LEN + off;
+                goto done;
+            }
+            ip += used;
+            if (ob_write_len(&out, t) || ob_write(&out, tbvec, t)) goto done;
+            spos = s;
+        }
+        off += n;
+        memmove(sbvec, sbvec + ORC_LZ_BLOCK_SIZE - ORC_PREMATCH_LEN, ORC_PREMATCH_LEN);
+        orc_lz_encoder_forward(enc, ORC_LZ_BLOCK_SIZE - ORC_PREMATCH_LEN);
+    }
+    if (ip != nplan) { plan_fail(err, off, ORC_PLAN_ESHORT); goto done; }
+    if (ob_write_len(&out, 0)) goto done;
+    *dst = out.p;
+    *dst_len = out.n;
+    out.p = NULL;
+    rc = 0;
+done:
+    free(out.p);
+    free(sbvec_buf);
+    free(tbvec);
+    free(wplan);
     orc_lz_encoder_free(enc);
     return rc;
 }

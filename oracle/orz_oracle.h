@@ -91,6 +91,24 @@ int orc_decode_mem(const uint8_t* src, size_t src_len, uint8_t** dst, size_t* ds
                    size_t* consumed);
 void orc_free(void* p);
 
+/* Plan-driven encoder: encode a caller-supplied parse with the reference's state machine and emit
+ * half; fails (-1, *err filled) on any item the format cannot express.  Checker for the GPU fast mode. */
+enum { ORC_PLAN_WORD = 0, ORC_PLAN_LITERAL = 1, ORC_PLAN_MATCH = 2 };
+enum { ORC_PLAN_ENOMEM = 1, ORC_PLAN_ESHORT, ORC_PLAN_EPOS, ORC_PLAN_ELEN, ORC_PLAN_EEND, ORC_PLAN_ESRC,
+       ORC_PLAN_EBYTES, ORC_PLAN_ELENMIN, ORC_PLAN_EWORD, ORC_PLAN_ETYPE };
+typedef struct {
+    uint64_t pos;  /* item start: window offset (object level) or stream offset (orc_encode_plan_mem) */
+    uint64_t src;  /* match source, same coordinate system; ignored for word / literal */
+    uint8_t type;  /* ORC_PLAN_* */
+    uint8_t len;   /* match length (4..240); ignored otherwise */
+} orc_plan_item;
+typedef struct { size_t pos; int code; } orc_plan_error;
+int orc_lz_encoder_encode_plan(orc_lz_encoder*, const uint8_t* sbuf, size_t sbuf_len, uint8_t* tbuf, size_t spos,
+                               const orc_plan_item* plan, size_t nplan, size_t* nused_out, size_t* spos_out,
+                               size_t* tlen_out, orc_plan_error* err);
+int orc_encode_plan_mem(const uint8_t* src, size_t src_len, const orc_plan_item* plan, size_t nplan,
+                        uint8_t** dst, size_t* dst_len, orc_trace* trace, orc_plan_error* err);
+
 /* Building blocks exposed for per-stage parity tests. */
 /* HuffmanTable::new_from_sym_weights, src/huffman.rs:27-111; returns max code length */
 int orc_huffman_lengths(const uint32_t* weights, size_t n, int max_code_len, uint8_t* lens_out);

@@ -136,6 +136,9 @@ class HipBackend {
         size_t s3 = 0;
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, s3, u, u, u, u, (size_t)kWLen, 0, 32, stream_));
         if (s3 > s1) s1 = s3;
+        size_t s4 = 0;
+        ORZ_HIP_CHECK(rocprim::inclusive_scan(nullptr, s4, u, u, (size_t)kWLen, rocprim::maximum<uint32_t>(), stream_));
+        if (s4 > s2) s2 = s4;
         tmp_bytes_ = (s1 > s2 ? s1 : s2) + 256;
         ORZ_HIP_CHECK(hipMalloc(&tmps_[0], tmp_bytes_));
         ORZ_HIP_CHECK(hipMalloc(&tmps_[1], tmp_bytes_));
@@ -263,6 +266,11 @@ class HipBackend {
         if (n == 0) return;
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::exclusive_scan(tmp_, sz, in, out, 0u, n, rocprim::plus<uint32_t>(), stream_));
+    }
+    void inclusive_max_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
+        if (n == 0) return;
+        size_t sz = tmp_bytes_;
+        ORZ_HIP_CHECK(rocprim::inclusive_scan(tmp_, sz, in, out, n, rocprim::maximum<uint32_t>(), stream_));
     }
     // HIP-event bracket around the dominant kernel's launches (bench.py roofline leg)
     void timed_begin() {

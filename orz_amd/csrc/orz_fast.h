@@ -1,0 +1,574 @@
+// orz_fast.h -- the GPU-native ("fast") parse mode of the MI355X ROLZ encoder.
+//
+// The reference parse (LZEncoder::encode, /root/reference/src/lz.rs:131-235) is one serial chain: the
+// ring of a context holds item starts only (src/matcher.rs:62-80), so which positions may serve as match
+// sources is decided by the parse itself.  The decoder, however, accepts ANY parse its state machine can
+// express.  The fast mode keeps the reference's decision rules but evaluates them for
+// every position at once against a snapshot of the item starts, and removes the serial chain with a
+// pipelined Gauss-Seidel schedule:
+//
+//   * the block's new bytes are cut into tiles of `tile` positions; at step s tile t runs its round s - t
+//     (1..R): all active tiles re-decide every position from the current snapshot, then the path through
+//     the active range is re-extracted.  A tile's last round therefore sees every earlier tile final, so
+//     only sources inside its own tile can have been stale.
+//   * candidate lists are static per block: positions radix-sorted by (ctx, hash) as in the exact mode;
+//     for each new position the common prefixes with its K predecessors in the run are tabulated once
+//     (`rows`), so a round costs one row + a window of the member bitmap per position.
+//   * afterwards the item boundaries are frozen and sources are assigned: every match takes the NEWEST
+//     item start of its run whose common prefix covers its length.  With that rule the lengths referring to
+//     one source ascend, so len >= len_min holds by construction (the argument of src/matcher.rs:32-50).
+//     A match without such a source is cut to the longest prefix some item start offers and the rest of
+//     its span is re-parsed (item starts are only ever added); WORD items are checked against the exact
+//     predictor state.  Repeat until nothing changes; then the unchanged post stage encodes the items.
+//
+// Parity for this mode (BASELINE.json north_star): the stream decodes bit-exactly with the reference
+// decoder and its size is within +-0.5 % of the reference encoder's at the same level -- not an identical
+// parse.  tests/model/fast_model.c is the CPU model the design was measured with.
+#pragma once
+#include "orz_kernels.h"
+#include "orz_parse.h"
+
+namespace orz {
+
+constexpr uint32_t kSub = 4096;                    // positions per ordinal subtile (= path chunk)
+constexpr uint32_t kSeg64 = 64;                    // positions per path segment
+constexpr uint32_t kNSub = kNewMax / kSub + 2;
+constexpr uint32_t kEntries = 240;                 // a path enters a chunk / tile within its first 240 positions
+
+struct FastArgs {
+    const uint8_t* win;
+    uint32_t len, n;            // window end, new bytes
+    uint32_t K, depth, lazy1, lazy2, tile;
+    // static per block
+    const uint32_t *idx, *epos, *kidx, *kpos, *krun;
+    const uint8_t* rows;        // [n][K]
+    const uint8_t* rlen;        // [n] min(255, slots of the run below the position)
+    const uint16_t* kw;         // [n+1] the two bytes at each word-list slot's position
+    const uint8_t* wsnap;       // words[] at the block start
+    const uint32_t* ORD;        // exact ring ordinals of history item starts
+    // dynamic
+    uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
+    uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
+    uint32_t* bs;               // [n+8] best source (window offset)
+    uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
+    uint64_t* sbits;            // [n/64+8] item starts of the current path, bit per new position
+    uint8_t *mf, *ef;           // [n+264] what vbits / kbits currently hold for each position
+    uint8_t *x0, *x1, *x2;      // path maps: per position, per (chunk, entry), per (tile, entry)
+    uint32_t *centry, *tentry;  // path entry of each chunk / tile
+    uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
+    uint32_t* nchg;
+};
+
+ORZ_D uint32_t fast_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// 64 bits of a bitmap starting at bit `start` (bits below zero read as 0)
+ORZ_D uint64_t bits_at(const uint64_t* bm, int64_t start) {
+    if (start <= -64) return 0;
+    if (start < 0) return bm[0] << (uint32_t)(-start);
+    const uint32_t sh = (uint32_t)(start & 63);
+    const uint64_t lo = bm[start >> 6] >> sh;
+    return sh ? lo | (bm[(start >> 6) + 1] << (64 - sh)) : lo;
+}
+ORZ_D void atom_xor64(uint64_t* p, uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicXor((unsigned long long*)p, (unsigned long long)v);
+#else
+    *p ^= v;
+#endif
+}
+ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicSub(p, v);
+#else
+    *p -= v;
+#endif
+}
+
+// ---- static per block --------------------------------------------------------------------------------
+struct FastSlotInit {  // thread per slot: history slots are item starts for good; run depth of each new position
+    const uint32_t *epos, *keys, *runstart;
+    uint32_t nent;
+    uint64_t* vbits;
+    uint8_t* rlen;
+    ORZ_HD void operator()(size_t j) const {
+        if (j >= nent) return;
+        const uint32_t p = epos[j];
+        if (p < kPre) { atom_or64(&vbits[j >> 6], 1ull << (j & 63)); return; }
+        const uint32_t d = (uint32_t)j - runstart[keys[j]];
+        rlen[p - kPre] = (uint8_t)(d < 255 ? d : 255);
+    }
+};
+struct FastKw {
+    const uint8_t* win;
+    const uint32_t* kpos;
+    uint32_t nk;
+    uint16_t* kw;
+    ORZ_HD void operator()(size_t s) const {
+        if (s >= nk) return;
+        const uint32_t u = kpos[s];
+        kw[s] = (uint16_t)(win[u] | (win[u + 1] << 8));
+    }
+};
+// common prefixes of a new position with its K predecessors in the (ctx, hash) run (simple form: thread
+// per position straight from the window; FastRowsWave below is the LDS-staged form the GPU runs)
+struct FastRows {
+    const uint8_t* win;
+    const uint32_t *idx, *epos;
+    const uint8_t* rlen;
+    uint32_t n, K;
+    uint8_t* rows;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= n) return;
+        const uint32_t p = kPre + (uint32_t)i, j = idx[p], r = fast_min(K, rlen[i]);
+        uint8_t* row = rows + (size_t)i * K;
+        for (uint32_t k = 0; k < K; k++) row[k] = k < r ? (uint8_t)lcp240u(win + epos[j - 1 - k], win + p) : 0;
+    }
+};
+// Same table, one wavefront per 64 consecutive slots: the 16 leading bytes of the 64 + K slots involved are
+// staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 16 bytes go to the window.
+struct FastRowsWave {
+    const uint8_t* win;
+    const uint32_t* epos;
+    const uint8_t* rlen;
+    uint32_t nent, K;
+    uint8_t* rows;
+    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 24; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint64_t* t0 = (uint64_t*)w.lds();            // [64+K] bytes 0..7
+        uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..15
+        uint32_t* ps = (uint32_t*)(t1 + (64 + K));    // [64+K] positions
+        const int64_t base = (int64_t)w.block() * 64 - K;  // slot of LDS entry 0
+        for (uint32_t e = w.lane(); e < 64 + K; e += 64) {
+            const int64_t s = base + e;
+            uint32_t q = 0;
+            uint64_t a = 0, b = 0;
+            if (s >= 0 && s < (int64_t)nent) { q = epos[s]; a = ldu64(win + q); b = ldu64(win + q + 8); }
+            t0[e] = a; t1[e] = b; ps[e] = q;
+        }
+        w.sync();
+        const uint32_t me = K + w.lane();
+        const uint32_t p = ps[me];
+        if ((int64_t)w.block() * 64 + w.lane() >= (int64_t)nent || p < kPre) return;
+        const uint32_t r = fast_min(K, rlen[p - kPre]);
+        const uint64_t a0 = t0[me], a1 = t1[me];
+        uint8_t* row = rows + (size_t)(p - kPre) * K;
+        for (uint32_t k0 = 0; k0 < K; k0 += 8) {
+            uint64_t pack = 0;
+            for (uint32_t kk = 0; kk < 8; kk++) {
+                const uint32_t k = k0 + kk;
+                uint32_t l = 0;
+                if (k < r) {
+                    const uint32_t e = me - 1 - k;
+                    const uint64_t x0 = t0[e] ^ a0;
+                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
+                    else {
+                        const uint64_t x1 = t1[e] ^ a1;
+                        l = x1 ? 8 + ((uint32_t)ctz64(x1) >> 3) : 16 + lcp240u(win + ps[e] + 16, win + p + 16, kMaxLen - 16);
+                    }
+                }
+                pack |= (uint64_t)l << (8 * kk);
+            }
+            *reinterpret_cast<uint64_t*>(row + k0) = pack;  // rows are 8-byte aligned (K is a multiple of 16)
+        }
+    }
+};
+
+// ---- one round: every position of the active range decides from the snapshot --------------------------
+struct FastEval {
+    FastArgs a;
+    uint32_t lo, hi;  // window offsets [lo, hi)
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t p = lo + (uint32_t)tid;
+        if (p >= hi) return;
+        const uint8_t* win = a.win;
+        const uint32_t i = p - kPre, c = hash1(win, p - 1), K = a.K;
+        const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
+        const uint8_t* row = a.rows + (size_t)i * K;
+        const uint32_t sp = i / kSub;
+        const uint32_t op_lo = a.cp[(size_t)sp * 256 + c];
+        const uint32_t op_hi = op_lo + a.cm[(size_t)sp * 256 + c];
+        uint32_t best = 0, bsrc = 0, b510 = 0, m1 = 0, m2 = 0, seen = 0;
+        bool stop = false;
+        for (uint32_t m = 0; m * 64 < r && !stop && seen < a.depth; m++) {
+            uint64_t mask = bits_at(a.vbits, (int64_t)j - 64 * (int64_t)(m + 1));
+            const uint32_t span = r - m * 64;  // slots of this group that still belong to the run window
+            if (span < 64) mask &= ~0ull << (64 - span);
+            while (mask && seen < a.depth) {
+                const uint32_t t = 63 - (uint32_t)clz64(mask);
+                mask &= ~(1ull << t);
+                const uint32_t k = m * 64 + 63 - t;
+                const uint32_t l = row[k];
+                if (l > best || (seen < a.lazy1 && l > m1) || (seen < a.lazy2 && l > m2)) {
+                    // ring check, only for candidates that matter (validity is monotone: older = further)
+                    const uint32_t q = a.epos[j - 1 - k];
+                    uint32_t ro_hi, ro_mid;
+                    if (q >= kPre) {
+                        const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
+                        ro_hi = op_hi - oq;
+                        ro_mid = op_lo - oq;
+                    } else {
+                        ro_hi = op_hi - 1 - a.ORD[q];
+                        ro_mid = op_lo - 1 - a.ORD[q];
+                    }
+                    if (ro_hi > kRing - 1) { stop = true; break; }
+                    if (l > best) { best = l; bsrc = q; b510 = (int32_t)ro_mid < 510; }
+                    if (seen < a.lazy1 && l > m1) m1 = l;
+                    if (seen < a.lazy2 && l > m2) m2 = l;
+                }
+                seen++;
+                if (l == kMaxLen) { stop = true; break; }
+            }
+        }
+        // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
+        const uint32_t key2 = hash2(win, p - 1);
+        const uint32_t kj = a.kidx[p], klo = a.krun[key2];
+        uint32_t rk = kj - klo;
+        uint64_t kmask = bits_at(a.kbits, (int64_t)kj - 64);
+        if (rk < 64) kmask &= rk ? ~0ull << (64 - rk) : 0;
+        if (rk && hash2(win, p - 2) == key2) kmask &= ~(1ull << 63);  // the slot right below is u = p-1
+        uint32_t w;
+        if (kmask) w = a.kw[kj - 64 + (63 - (uint32_t)clz64(kmask))];
+        else w = (uint32_t)a.wsnap[key2 * 2] | ((uint32_t)a.wsnap[key2 * 2 + 1] << 8);
+        const uint32_t lwm = w == ((uint32_t)win[p] | ((uint32_t)win[p + 1] << 8));
+        a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
+        a.bs[i] = bsrc;
+    }
+};
+struct FastDecide {  // src/lz.rs:139-234 on the snapshot's answers
+    FastArgs a;
+    uint32_t lo, hi;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t p = lo + (uint32_t)tid;
+        if (p >= hi) return;
+        const uint32_t i = p - kPre, e = a.ev[i];
+        uint32_t L = e & 0xff;
+        if (p + L >= a.len) L = a.len - 1 - p;  // an item never reaches the block end (src/matcher.rs:183)
+        if (L < kMinLen) L = 0;
+        const uint32_t lwm = (e >> 24) & 1;
+        uint32_t lazy = 0;
+        if (L > 0 && L < kMaxLen / 2) {
+            const uint32_t l1 = L + 1 + ((e >> 25) & 1), l2 = l1 - lwm;
+            const uint32_t e1 = p + 1 < a.len ? a.ev[i + 1] : 0, e2 = p + 2 < a.len ? a.ev[i + 2] : 0;
+            if (((e1 >> 8) & 0xff) >= l1) lazy = 1;
+            else if (((e2 >> 16) & 0xff) >= l2) lazy = 2;
+        }
+        if (L > 0 && lazy == 0) { a.ty[i] = kTyMatch; a.nl[i] = (uint8_t)L; }
+        else if (p + 1 < a.len && lazy != 1 && lwm) { a.ty[i] = kTyWord; a.nl[i] = 2; }
+        else { a.ty[i] = kTyLit; a.nl[i] = 1; }
+    }
+};
+
+// ---- path through the active range: exit maps per segment / chunk / tile, then entries top-down --------
+ORZ_D uint32_t seg_end(uint32_t s, uint32_t len) { return fast_min(len, kPre + (s + 1) * kSeg64); }
+ORZ_D uint32_t chunk_end(uint32_t c, uint32_t len) { return fast_min(len, kPre + (c + 1) * kSub); }
+struct PathSeg {  // x0[p] = where a walk from p first leaves p's 64-position segment, as an offset past its end
+    FastArgs a;
+    uint32_t lo, hi;
+    ORZ_HD void operator()(size_t tid) const {
+        uint32_t x = lo + (uint32_t)tid;
+        if (x >= hi) return;
+        const uint32_t i = x - kPre, e = seg_end(i / kSeg64, a.len);
+        while (x < e) { const uint32_t d = a.nl[x - kPre]; x += d ? d : 1; }
+        a.x0[i] = (uint8_t)(x - e);
+    }
+};
+struct PathChunk {  // x1[c][e] = exit offset past chunk c when entering it at offset e
+    FastArgs a;
+    uint32_t c0, nc;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = c0 + (uint32_t)(tid / kEntries), e = (uint32_t)(tid % kEntries);
+        if (c >= c0 + nc) return;
+        const uint32_t end = chunk_end(c, a.len);
+        uint32_t x = kPre + c * kSub + e;
+        while (x < end) {
+            const uint32_t s = (x - kPre) / kSeg64;
+            x = seg_end(s, a.len) + a.x0[x - kPre];
+        }
+        a.x1[(size_t)c * kEntries + e] = (uint8_t)(x >= end ? x - end : 0);
+    }
+};
+ORZ_D uint32_t tile_end(uint32_t t, uint32_t tile, uint32_t len) { return fast_min(len, kPre + (t + 1) * tile); }
+struct PathTile {
+    FastArgs a;
+    uint32_t t0, nt;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t t = t0 + (uint32_t)(tid / kEntries), e = (uint32_t)(tid % kEntries);
+        if (t >= t0 + nt) return;
+        const uint32_t end = tile_end(t, a.tile, a.len);
+        uint32_t x = kPre + t * a.tile + e;
+        while (x < end) {
+            const uint32_t c = (x - kPre) / kSub;
+            x = chunk_end(c, a.len) + a.x1[(size_t)c * kEntries + (x - kPre - c * kSub)];
+        }
+        a.x2[(size_t)t * kEntries + e] = (uint8_t)(x >= end ? x - end : 0);
+    }
+};
+struct PathDown {  // thread per chunk of the range (+1 for the entry of the tile after the range)
+    FastArgs a;
+    uint32_t t0, nt;  // tiles of the range
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t cpt = a.tile / kSub;
+        const uint32_t c0 = t0 * cpt;
+        const uint32_t nchunks = (fast_min(a.len, kPre + (t0 + nt) * a.tile) - (kPre + c0 * kSub) + kSub - 1) / kSub;
+        if (tid > nchunks) return;
+        const bool tail = tid == nchunks;
+        const uint32_t c = c0 + (uint32_t)tid, t = tail ? t0 + nt : c / cpt;
+        uint32_t x = a.tentry[t0];
+        for (uint32_t tt = t0; tt < t; tt++) {
+            const uint32_t end = tile_end(tt, a.tile, a.len);
+            if (x < end) x = end + a.x2[(size_t)tt * kEntries + (x - kPre - tt * a.tile)];
+        }
+        if (tail) { a.tentry[t] = x; return; }
+        if (c == t * cpt && t > t0) a.tentry[t] = x;
+        for (uint32_t cc = t * cpt; cc < c; cc++) {
+            const uint32_t end = chunk_end(cc, a.len);
+            if (x < end) x = end + a.x1[(size_t)cc * kEntries + (x - kPre - cc * kSub)];
+        }
+        a.centry[c] = x;
+    }
+};
+struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the type of every item at its end
+    FastArgs a;
+    uint32_t s0, ns;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t s = s0 + (uint32_t)tid;
+        if (tid >= ns) return;
+        const uint32_t start = kPre + s * kSeg64, end = seg_end(s, a.len);
+        uint32_t x = a.centry[(start - kPre) / kSub];
+        while (x < start) {
+            const uint32_t ss = (x - kPre) / kSeg64;
+            x = seg_end(ss, a.len) + a.x0[x - kPre];
+        }
+        uint64_t m = 0;
+        while (x < end) {
+            m |= 1ull << (x - start);
+            const uint32_t d = a.nl[x - kPre];
+            const uint32_t e = x + (d ? d : 1);
+            a.pt[e - kPre] = a.ty[x - kPre];
+            x = e;
+        }
+        a.sbits[s] = m;
+    }
+};
+// bring the slot-order bitmaps and the per-(subtile, ctx) counts in line with the path
+struct FastFlip {
+    FastArgs a;
+    uint32_t lo, hi;     // positions y in [lo, hi]
+    uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t y = lo + (uint32_t)tid;
+        if (y > hi) return;
+        const uint32_t i = y - kPre;
+        uint32_t s = 0;
+        if (next_entry != ~0u ? a.tentry[next_entry] == y : y == a.len) s = 1;  // where the path leaves the range / the block
+        if (y < a.len) {
+            s |= (uint32_t)((a.sbits[i / 64] >> (i & 63)) & 1);
+            if (s != a.mf[i]) {
+                a.mf[i] = (uint8_t)s;
+                const uint32_t j = a.idx[y];
+                atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+                uint32_t* cnt = &a.cm[(size_t)(i / kSub) * 256 + hash1(a.win, y - 1)];
+                if (s) atom_add32(cnt, 1); else atom_sub32(cnt, 1);
+            }
+        }
+        if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
+            const uint32_t e = s && a.pt[i] != kTyWord;
+            if (e != a.ef[i]) {
+                a.ef[i] = (uint8_t)e;
+                const uint32_t ku = a.kidx[y - 2];
+                atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+            }
+        }
+    }
+};
+struct FastPrefix {  // cp[s+1][c] = cp[s][c] + cm[s][c] over the subtiles [s0, s1)
+    FastArgs a;
+    uint32_t s0, s1;
+    ORZ_HD void operator()(size_t c) const {
+        if (c >= 256) return;
+        uint32_t v = a.cp[(size_t)s0 * 256 + c];
+        for (uint32_t s = s0; s < s1; s++) {
+            v += a.cm[(size_t)s * 256 + c];
+            a.cp[(size_t)(s + 1) * 256 + c] = v;
+        }
+    }
+};
+
+// ---- after the rounds: sources, repairs, exact predictor ---------------------------------------------
+struct MemberFlags32 {
+    const uint64_t* sbits;
+    uint32_t n;
+    uint32_t* f;
+    ORZ_HD void operator()(size_t i) const {
+        if (i < n) f[i] = (uint32_t)((sbits[i / 64] >> (i & 63)) & 1);
+    }
+};
+struct CtxKeys {
+    const uint8_t* win;
+    const uint32_t* ipos;
+    uint32_t nitems;
+    uint32_t* keys;
+    ORZ_HD void operator()(size_t t) const {
+        if (t < nitems) keys[t] = hash1(win, ipos[t] - 1);
+    }
+};
+struct CtxStarts {  // first sorted index of each ctx (binary search), c in [0, 256]
+    const uint32_t* keys;
+    uint32_t n;
+    uint32_t* cstart;
+    ORZ_HD void operator()(size_t c) const {
+        if (c > 256) return;
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (keys[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        cstart[c] = lo;
+    }
+};
+struct OrdAssign {  // exact ring ordinals (Bucket.head arithmetic, src/matcher.rs:62-80) of the block's item starts
+    const uint32_t *keys, *pos, *cstart, *ctxcount;
+    uint32_t n;
+    uint32_t* ORD;
+    ORZ_HD void operator()(size_t t) const {
+        if (t < n) ORD[pos[t]] = ctxcount[keys[t]] + (uint32_t)t - cstart[keys[t]];
+    }
+};
+struct FastSource {
+    FastArgs a;
+    uint32_t* SRC;
+    uint32_t* cutend;  // [n] old end of an item that lost part of its length in this pass (0 = none)
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
+        const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], K = a.K;
+        const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]), op = a.ORD[p];
+        const uint8_t* row = a.rows + (size_t)i * K;
+        uint32_t best = 0, bsrc = 0, seen = 0, found = 0;
+        bool stop = false;
+        for (uint32_t m = 0; m * 64 < r && !stop && !found && seen < a.depth; m++) {
+            uint64_t mask = bits_at(a.vbits, (int64_t)j - 64 * (int64_t)(m + 1));
+            const uint32_t span = r - m * 64;
+            if (span < 64) mask &= ~0ull << (64 - span);
+            while (mask && seen < a.depth) {
+                const uint32_t t = 63 - (uint32_t)clz64(mask);
+                mask &= ~(1ull << t);
+                const uint32_t k = m * 64 + 63 - t;
+                const uint32_t l = row[k];
+                if (l >= kMinLen && (l >= L || l > best)) {
+                    const uint32_t q = a.epos[j - 1 - k];
+                    if (op - 1 - a.ORD[q] > kRing - 1) { stop = true; break; }  // left the ring: so did everything older
+                    if (l >= L) { found = q; break; }
+                    best = l; bsrc = q;
+                }
+                seen++;
+            }
+        }
+        if (found) { SRC[p] = found; return; }
+        atom_add32(a.nchg, 1);
+        cutend[i] = p + L;
+        if (best >= kMinLen) { a.nl[i] = (uint8_t)best; SRC[p] = bsrc; }
+        else { a.ty[i] = kTyLit; a.nl[i] = 1; }
+    }
+};
+struct FastRecut {  // the rest of a shortened item's span, from the last round's decisions, cut at the old end
+    FastArgs a;
+    uint32_t* cutend;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || !cutend[i]) return;
+        const uint32_t end = cutend[i];
+        cutend[i] = 0;
+        uint32_t x = kPre + (uint32_t)i + a.nl[i];
+        a.pt[x - kPre] = a.ty[i];
+        while (x < end) {
+            const uint32_t xi = x - kPre;
+            uint32_t t = a.ty[xi], L = a.nl[xi];
+            if (L == 0) { t = kTyLit; L = 1; }
+            if (x + L > end) {
+                if (t == kTyMatch && end - x >= kMinLen) L = end - x;
+                else { t = kTyLit; L = 1; }
+            }
+            a.ty[xi] = (uint8_t)t; a.nl[xi] = (uint8_t)L;
+            atom_or64(&a.sbits[xi / 64], 1ull << (xi & 63));
+            x += L;
+            a.pt[x - kPre] = (uint8_t)t;
+        }
+    }
+};
+struct KbitVals {  // v[s] = s + 1 where the word-update bit of slot s is set, else 0 (for the running maximum)
+    const uint64_t* kbits;
+    uint32_t nk;
+    uint32_t* v;
+    ORZ_HD void operator()(size_t s) const {
+        if (s < nk) v[s] = ((kbits[s >> 6] >> (s & 63)) & 1) ? (uint32_t)s + 1 : 0;
+    }
+};
+// exact words[] answer for an item starting at p (src/lz.rs:132-133), from the running maximum `laste`
+ORZ_D uint32_t fast_word_at(const FastArgs& a, const uint32_t* laste, uint32_t p) {
+    const uint32_t key2 = hash2(a.win, p - 1);
+    const uint32_t kj = a.kidx[p], klo = a.krun[key2];
+    uint32_t below = kj;  // slots [klo, below) are the candidates
+    if (kj > klo && hash2(a.win, p - 2) == key2) below = kj - 1;  // u = p-1 does not count yet
+    const uint32_t le = below > klo ? laste[below - 1] : 0;
+    if (le > klo) return a.kw[le - 1];
+    return (uint32_t)a.wsnap[key2 * 2] | ((uint32_t)a.wsnap[key2 * 2 + 1] << 8);
+}
+struct FastWordCheck {  // a WORD item whose prediction the exact state does not make becomes two literals
+    FastArgs a;
+    const uint32_t* laste;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
+        const uint32_t p = kPre + (uint32_t)i;
+        const uint32_t w = fast_word_at(a, laste, p);
+        if (w == ((uint32_t)a.win[p] | ((uint32_t)a.win[p + 1] << 8))) return;
+        atom_add32(a.nchg, 1);
+        a.ty[i] = kTyLit; a.nl[i] = 1;
+        a.ty[i + 1] = kTyLit; a.nl[i + 1] = 1;
+        atom_or64(&a.sbits[(i + 1) / 64], 1ull << ((i + 1) & 63));
+        a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
+    }
+};
+struct FastCommit {  // per-position arrays the post stage reads (orz_stream.h)
+    FastArgs a;
+    const uint32_t* laste;
+    uint32_t lt0;  // type of the item that ended at the block start
+    uint8_t *S, *TY, *ML, *W0;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n) return;
+        const uint32_t p = kPre + (uint32_t)i;
+        if (!((a.sbits[i / 64] >> (i & 63)) & 1)) { S[p] = 0; ML[p] = 0; return; }
+        const uint32_t t = a.ty[i], prev = i ? a.pt[i] : lt0;
+        S[p] = 1;
+        TY[p] = (uint8_t)(t | ((prev == kTyLit) << 2));
+        ML[p] = t == kTyMatch ? a.nl[i] : 0;
+        W0[p] = (uint8_t)(fast_word_at(a, laste, p) & 0xff);
+    }
+};
+struct FastWordsCarry {  // words[] for the next block: per hash2 key the last update of this block
+    FastArgs a;
+    const uint32_t *laste, *krunend;
+    uint8_t* wsnap;
+    ORZ_HD void operator()(size_t key) const {
+        if (key >= 32768) return;
+        const uint32_t lo = a.krun[key], hi = krunend[key];
+        if (hi <= lo) return;
+        const uint32_t le = laste[hi - 1];
+        if (le > lo) { const uint32_t w = a.kw[le - 1]; wsnap[key * 2] = (uint8_t)w; wsnap[key * 2 + 1] = (uint8_t)(w >> 8); }
+    }
+};
+struct FastCtxCarry {
+    const uint32_t* cp;
+    uint32_t nsub;
+    uint32_t* ctxcount;
+    ORZ_HD void operator()(size_t c) const {
+        if (c < 256) ctxcount[c] = cp[(size_t)nsub * 256 + c];
+    }
+};
+struct FastCpInit {
+    const uint32_t* ctxcount;
+    uint32_t* cp;
+    ORZ_HD void operator()(size_t c) const {
+        if (c < 256) cp[c] = ctxcount[c];
+    }
+};
+
+}  // namespace orz

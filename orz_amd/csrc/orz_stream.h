@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "orz_fast.h"
 #include "orz_kernels.h"
 #include "orz_parse.h"
 
@@ -213,8 +214,18 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
 
-    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072)
-        : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs) {
+    // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
+    // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
+    StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072, bool fast = false,
+                  uint32_t fast_tile = 65536, uint32_t fast_rounds = 8)
+        : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs), fast_(fast), ftile_(fast_tile), frounds_(fast_rounds) {
+        if (fast_) {
+            if (ftile_ < kSub || ftile_ % kSub) throw std::runtime_error("fast tile must be a multiple of 4096");
+            if (frounds_ < 1 || frounds_ > 64) throw std::runtime_error("fast rounds must be in [1, 64]");
+            fK_ = ((uint32_t)cfg.depth * 4 + 15) / 16 * 16;
+            if (fK_ < 32) fK_ = 32;
+            if (fK_ > 192) fK_ = 192;
+        }
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
         dmax_ = (uint32_t)std::max(cfg.depth, std::max(cfg.lazy1, cfg.lazy2));
@@ -251,12 +262,38 @@ class StreamEncoder {
         kbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 2);
         k1_ = be_.template alloc<uint64_t>(kNewMax / 4096 + 2);
         k2_ = be_.template alloc<uint64_t>(kNewMax / 262144 + 2);
-        srec_ = be_.template alloc<SlotRec>(kWLen);
-        exitst_ = be_.template alloc<uint64_t>((size_t)nseg_max_ + 2);
-        hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
-        base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
-        ctl_ = be_.template alloc<ParseCtl>(1);
-        partial_ = be_.template alloc<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
+        if (!fast_) {
+            srec_ = be_.template alloc<SlotRec>(kWLen);
+            exitst_ = be_.template alloc<uint64_t>((size_t)nseg_max_ + 2);
+            hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
+            base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
+            ctl_ = be_.template alloc<ParseCtl>(1);
+            partial_ = be_.template alloc<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
+        } else {
+            const size_t nn = (size_t)kNewMax + 512;
+            frows_ = be_.template alloc<uint8_t>((size_t)kNewMax * fK_ + 64);
+            frlen_ = be_.template alloc<uint8_t>(nn);
+            fkw_ = be_.template alloc<uint16_t>(nn);
+            fev_ = be_.template alloc<uint32_t>(nn);
+            fbs_ = be_.template alloc<uint32_t>(nn);
+            fty_ = be_.template alloc<uint8_t>(nn);
+            fnl_ = be_.template alloc<uint8_t>(nn);
+            fpt_ = be_.template alloc<uint8_t>(nn);
+            fmf_ = be_.template alloc<uint8_t>(nn);
+            fef_ = be_.template alloc<uint8_t>(nn);
+            fx0_ = be_.template alloc<uint8_t>(nn);
+            fx1_ = be_.template alloc<uint8_t>((size_t)(kNSub + 2) * kEntries);
+            fx2_ = be_.template alloc<uint8_t>((size_t)(kNewMax / ftile_ + 4) * kEntries);
+            fsbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 16);
+            fcentry_ = be_.template alloc<uint32_t>(kNSub + 2);
+            ftentry_ = be_.template alloc<uint32_t>(kNewMax / ftile_ + 4);
+            fcm_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
+            fcp_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
+            fcut_ = be_.template alloc<uint32_t>(nn);
+            flaste_ = be_.template alloc<uint32_t>(nn);
+            fnchg_ = be_.template alloc<uint32_t>(4);
+            fcstart_ = be_.template alloc<uint32_t>(260);
+        }
         f32_ = be_.template alloc<uint32_t>(kWLen);
         sc32_ = be_.template alloc<uint32_t>(kWLen);
         hpos_ = be_.template alloc<uint32_t>(kPre + 1);
@@ -302,8 +339,9 @@ class StreamEncoder {
                         kpos_, runstart_, krun_, krunend_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
-                        hdrbits_, tot_, outoff_, out_};
-        for (void* p : ptrs) be_.free(p);
+                        hdrbits_, tot_, outoff_, out_, frows_, frlen_, fkw_, fev_, fbs_, fty_, fnl_, fpt_, fmf_, fef_, fx0_, fx1_, fx2_,
+                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_};
+        for (void* p : ptrs) if (p) be_.free(p);
     }
     StreamEncoder(const StreamEncoder&) = delete;
     StreamEncoder& operator=(const StreamEncoder&) = delete;
@@ -328,6 +366,10 @@ class StreamEncoder {
     uint8_t* dwinbuf() { return winbuf_; }       // device address of the allocation (sentinel included)
     uint32_t seg_size() const { return seg_; }
     uint32_t window_segs() const { return wsegs_; }
+    bool fast() const { return fast_; }
+    uint32_t fast_tile() const { return ftile_; }
+    uint32_t fast_rounds() const { return frounds_; }
+    uint32_t fast_row() const { return fK_; }
 
     // Encode the block whose n new bytes sit at dwin()[kPre, kPre+n).  Appends
     // { LEB128(t) chunk[t] }* (src/lib.rs:76-82, src/ioutil.rs:79-88) to `out`; optionally reports
@@ -366,6 +408,16 @@ class StreamEncoder {
         be_.memset(krun_, 0, 32769 * 4);
         be_.memset(krunend_, 0, 32769 * 4);
         be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_, krunend_});
+        if (fast_) {
+            be_.sync();
+            double tf = be_.now();
+            stats.t_prep += tf - t0;
+            fast_parse(n, len, nent, keysB);
+            double t2f = be_.now();
+            stats.t_parse += t2f - tf;
+            post_stage(n, len, out, chunk_ends, t2f);
+            return;
+        }
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 1) * 8);
         be_.memset(v1_, 0, ((size_t)kWLen / 4096 + 2) * 8);
         be_.memset(v2_, 0, ((size_t)kWLen / 262144 + 2) * 8);
@@ -504,6 +556,105 @@ class StreamEncoder {
         }
 #endif
 
+        post_stage(n, len, out, chunk_ends, t2);
+    }
+
+    // The GPU-native parse of one block (orz_fast.h): fills S_/TY_/ML_/SRC_/ORD_/W0_ for the new region and
+    // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
+    void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys) {
+        const uint8_t* win = dwin();
+        const uint32_t nk = n + 1, K = fK_;
+        be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
+        be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
+        be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
+        be_.launch(nent, FastSlotInit{epos_, slot_keys, runstart_, nent, vbits_, frlen_});
+        be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
+        be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, frlen_, nent, K, frows_}, FastRowsWave::lds_bytes(K));
+        const size_t nn = (size_t)n + 264;
+        be_.memset(fev_, 0, ((size_t)n + 8) * 4);
+        be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
+        be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
+        be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
+        const uint32_t nsub = (n + kSub - 1) / kSub;
+        be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
+        be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
+        be_.launch(256, FastCpInit{ctxcount_, fcp_});
+        { uint32_t e0 = kPre; be_.h2d(ftentry_, &e0, 4); }
+        FastArgs a;
+        a.win = win; a.len = len; a.n = n; a.K = K; a.depth = (uint32_t)cfg_.depth; a.lazy1 = (uint32_t)cfg_.lazy1;
+        a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_;
+        a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
+        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.vbits = vbits_; a.kbits = kbits_; a.ev = fev_; a.bs = fbs_;
+        a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mf = fmf_; a.ef = fef_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = fnchg_;
+        // ---- pipelined Gauss-Seidel rounds
+        const uint32_t T = ftile_, R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
+        for (uint32_t step = 1; step <= ntile + R - 1; step++) {
+            const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
+            const uint32_t lo = kPre + t_lo * T;
+            const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
+            const uint32_t hi2 = std::min(len, hi + 2);
+            be_.timed_begin();
+            be_.launch(hi2 - lo, FastEval{a, lo, hi2});
+            be_.timed_end();
+            be_.launch(hi - lo, FastDecide{a, lo, hi});
+            be_.launch(hi - lo, PathSeg{a, lo, hi});
+            const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
+            be_.launch((size_t)nc * kEntries, PathChunk{a, c0, nc});
+            be_.launch((size_t)nt * kEntries, PathTile{a, t_lo, nt});
+            be_.launch((size_t)nc + 1, PathDown{a, t_lo, nt});
+            const uint32_t s0 = (lo - kPre) / kSeg64, ns = (hi - lo + kSeg64 - 1) / kSeg64;
+            be_.launch(ns, PathMark{a, s0, ns});
+            const uint32_t fhi = std::min(len, hi + 240);
+            be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1});
+            be_.launch(256, FastPrefix{a, c0, c0 + nc});
+            stats.sweeps++;
+        }
+        // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes
+        uint32_t* ckeys = (uint32_t*)entA_;
+        uint32_t* ckeys2 = ckeys + kWLen;
+        uint32_t* cvals = (uint32_t*)entB_;
+        uint32_t* fipos = cvals + kWLen;
+        bool done = false;
+        for (int pass = 0; pass < 200 && !done; pass++) {
+            be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u});
+            be_.launch(n, MemberFlags32{fsbits_, n, f32_});
+            be_.exclusive_scan_u32(f32_, sc32_, n);
+            uint32_t x0, x1;
+            be_.d2h(&x0, sc32_ + (n - 1), 4);
+            be_.d2h(&x1, f32_ + (n - 1), 4);
+            const uint32_t nmem = x0 + x1;
+            be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, fipos});
+            be_.launch(nmem, CtxKeys{win, fipos, nmem, ckeys});
+            be_.sort_pairs_u32(ckeys, ckeys2, fipos, cvals, nmem, 8);
+            be_.launch(257, CtxStarts{ckeys2, nmem, fcstart_});
+            be_.launch(nmem, OrdAssign{ckeys2, cvals, fcstart_, ctxcount_, nmem, ORD_});
+            be_.memset(fnchg_, 0, 4);
+            be_.launch(n, FastSource{a, SRC_, fcut_});
+            be_.launch(n, FastRecut{a, fcut_});
+            be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u});
+            be_.launch(nk, KbitVals{kbits_, nk, f32_});
+            be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+            be_.launch(n, FastWordCheck{a, flaste_});
+            uint32_t chg = 0;
+            be_.d2h(&chg, fnchg_, 4);
+            stats.seg_evals += chg;  // (fast mode: repairs made)
+            done = chg == 0;
+        }
+        if (!done) throw std::runtime_error("fast parse: repairs did not converge");
+        // ---- hand over to the post stage; carry the model state
+        be_.launch(n, FastCommit{a, flaste_, (uint32_t)lt_carry_, S_, TY_, ML_, W0_});
+        be_.launch(32768, FastWordsCarry{a, flaste_, krunend_, wsnap_});
+        be_.launch(256, FastPrefix{a, 0, nsub});
+        be_.launch(256, FastCtxCarry{fcp_, nsub, ctxcount_});
+        uint8_t last_ty = kTyLit;
+        be_.d2h(&last_ty, fpt_ + n, 1);
+        lt_carry_ = last_ty;
+    }
+
+    // Second half of a block: items -> len_min -> symbols -> symrank -> Huffman -> bit pack (shared by both parse modes)
+    void post_stage(uint32_t n, uint32_t len, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends, double t2) {
+        const uint8_t* win = dwin();
         // ---- items (the item arrays are shared with the previous block's tail stage: let it finish)
         if (pending_) be_.wait(1);
         be_.launch(n, Flags32{S_, n, f32_});
@@ -529,13 +680,16 @@ class StreamEncoder {
             be_.launch((size_t)512 * kSyms, CensusFill{order_, srstate_});
         }
         // ---- model state carried to the next block (still on the main stream)
-        be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
-        uint64_t ex;
-        be_.d2h(&ex, exitst_ + nseg, 8);
-        const uint8_t ltf = (uint8_t)(ExitPair::exit(ex) & 3);
-        be_.launch(32768, WordsLastRun{kbits_, k1_, k2_, kpos_, krun_, krunend_, wlast_});
-        be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
-        lt_carry_ = ltf;
+        if (!fast_) {
+            const uint32_t nseg = (n + seg_ - 1) / seg_;
+            be_.d2d(ctxcount_, base_ + (size_t)(nseg % ring_) * 256, 256 * 4);
+            uint64_t ex;
+            be_.d2h(&ex, exitst_ + nseg, 8);
+            const uint8_t ltf = (uint8_t)(ExitPair::exit(ex) & 3);
+            be_.launch(32768, WordsLastRun{kbits_, k1_, k2_, kpos_, krun_, krunend_, wlast_});
+            be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
+            lt_carry_ = ltf;
+        }  // (the fast mode carried its state at the end of fast_parse)
 
         // ---- the previous block's tail has long finished: take its output, then start this block's tail
         collect(out, nullptr);
@@ -636,6 +790,14 @@ class StreamEncoder {
     BE& be_;
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
+    bool fast_ = false;
+    uint32_t ftile_ = 65536, frounds_ = 8, fK_ = 64;
+    uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
+            *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
+    uint16_t* fkw_ = nullptr;
+    uint32_t *fev_ = nullptr, *fbs_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
+             *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr;
+    uint64_t* fsbits_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
     bool pending_ = false;
@@ -646,12 +808,12 @@ class StreamEncoder {
     uint32_t *ORD_, *SRC_;
     uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_, *krunend_;
     uint64_t *entA_, *entB_, *vbits_, *v1_, *v2_, *kbits_, *k1_, *k2_;
-    SlotRec* srec_;
-    uint64_t* exitst_;
-    uint8_t* hist_;
-    uint32_t* base_;
-    ParseCtl* ctl_;
-    uint32_t* partial_;
+    SlotRec* srec_ = nullptr;
+    uint64_t* exitst_ = nullptr;
+    uint8_t* hist_ = nullptr;
+    uint32_t* base_ = nullptr;
+    ParseCtl* ctl_ = nullptr;
+    uint32_t* partial_ = nullptr;
     uint32_t *f32_, *sc32_, *hpos_, *ctxcount_, *tailkey_;
     uint8_t* wsnap_;
     uint32_t* wlast_;

@@ -100,6 +100,10 @@ struct EmuBackend {
         uint32_t run = 0;
         for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = run; run += v; }
     }
+    void inclusive_max_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
+        uint32_t run = 0;
+        for (size_t i = 0; i < n; i++) { if (in[i] > run) run = in[i]; out[i] = run; }
+    }
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
         for (uint32_t c = 0; c < 512; c++) {
             uint16_t value[orz::kSyms], index[orz::kSyms];
@@ -129,6 +133,28 @@ extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, in
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emu_encode: %s\n", e.what());
+        return -1;
+    }
+}
+// the fast parse mode (orz_fast.h) on the emulation backend
+extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, unsigned tile, unsigned rounds,
+                               uint8_t** dst, size_t* dst_len, unsigned long long* stats5) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, tile ? tile : 65536, rounds ? rounds : 8);
+        std::vector<uint8_t> out;
+        orz::encode_stream(enc, be, src, n, false, out);
+        *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        if (stats5) {
+            stats5[0] = enc.stats.blocks; stats5[1] = enc.stats.sweeps; stats5[2] = enc.stats.seg_evals;
+            stats5[3] = enc.stats.items; stats5[4] = enc.stats.chunks;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
         return -1;
     }
 }
