@@ -2,20 +2,24 @@
 """bench.py -- orz -l1 encode throughput on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch: the full orz encode (`LZEncoder::encode`
-driven by `orz::encode`, /root/reference/src/lib.rs:58-92) of the 100,000,000-byte text workload
-at -l1, input already resident in HBM, one 16 MiB block in flight (BASELINE configs[1]).
+driven by `orz::encode`, /root/reference/src/lib.rs:58-92) of the 100,000,000-byte enwik8-shaped
+workload (tools/enwik_like.py: seeded, box-independent, SHA-256 pinned) at -l1, input already
+resident in HBM, one stream, one 16 MiB block in flight (BASELINE configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--mode fast|exact]
   (N > 1: launched by torch.distributed.run, one rank per GPU; every rank encodes its own member
    -- a distinct rotation of the workload -- and the finished bitstreams are gathered to rank 0
    over RCCL; weak scaling.)
 
-Rank 0 prints ONE JSON line.  `roofline` is about the dominant kernel (the speculative parse,
-ParseWave): algorithmic bytes per launch = 1.27 B per input byte (read the window
-once + write the bitstream, r ~= 0.27) x the input bytes one launch retires on average
-(input bytes / launches), over that kernel's average launch duration measured with HIP events on
-the encoder's own stream.  `cpu_baseline` times the CPU oracle (a C restatement of the reference
-encoder, single thread like the reference) on the same workload on this box's host cores.
+Rank 0 prints ONE JSON line.  `config` is read back from the encoder (orz_stream_get_config), not
+written down here.  `roofline` describes the kernel with the largest share of device time, from HIP
+events recorded inside the library on the stream each kernel runs on (orz_stream_get_kernel_times);
+`roofline_others` carries the next ones.  Algorithmic bytes per launch = 1.27 B per input byte
+(read the window once + write the bitstream, r ~= 0.27) x the input bytes one launch
+retires (input bytes / launches).  `traffic` is the PMC-measured HBM bytes per launch from this
+round's rocprofv3 passes (profiles/, FETCH_SIZE and WRITE_SIZE collected separately) when that file
+names the same kernel, else null.  `cpu_baseline` times the CPU oracle (a C restatement of the
+reference encoder, single thread like the reference) on the same workload on this box's host cores.
 """
 import argparse
 import hashlib
@@ -67,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=WORKLOAD_BYTES, help="workload size (default: BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
+                    help="fast: GPU-native parse (reference-decodable, size within +-0.5 %%); exact: the reference's parse item for item")
     args = ap.parse_args()
 
     import torch
@@ -95,15 +101,20 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
 
-    base = corpus.text_corpus(args.bytes)
+    base = corpus.enwik_like(args.bytes)  # raises if the canonical 100,000,000 bytes do not hash to the pinned SHA-256
     sha = hashlib.sha256(base).hexdigest()
+    if args.bytes == WORKLOAD_BYTES:
+        import enwik_like
+
+        assert sha == enwik_like.MANIFEST[WORKLOAD_BYTES], "workload differs from the pinned one"
     # each rank's member is a distinct rotation of the workload (same statistics, different bytes in flight)
     rot = (rank * 12_345_679) % max(1, len(base))
     data = base[rot:] + base[:rot]
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
-    enc = orz_amd.StreamEncoder(device=local_rank, level=LEVEL)
+    enc = orz_amd.StreamEncoder(device=local_rank, level=LEVEL, mode=args.mode)
+    cfg = enc.config()
 
     def barrier():
         if distributed:
@@ -122,12 +133,16 @@ def main():
         step()
     barrier()
     t0 = time.time()
-    agg = {"parse_kernel_ms": 0.0, "parse_launches": 0, "sweeps": 0, "t_prep_s": 0.0, "t_parse_s": 0.0, "t_post_s": 0.0}
+    agg = {"sweeps": 0, "seg_evals": 0, "items": 0, "t_prep_s": 0.0, "t_parse_s": 0.0, "t_post_s": 0.0}
+    kt = [[0.0, 0] for _ in range(4)]
     out = b""
     for _ in range(args.steps):
         out, st = step()
         for k in agg:
             agg[k] += st[k]
+        for i, (ms, n) in enumerate(enc.kernel_times()):
+            kt[i][0] += ms
+            kt[i][1] += n
     barrier()
     dt = time.time() - t0
     if distributed:
@@ -138,18 +153,30 @@ def main():
     if rank == 0:
         total_bytes = len(data) * world * args.steps
         value = total_bytes / dt / 1e6
-        launches = max(1, agg["parse_launches"])
-        avg_launch_s = agg["parse_kernel_ms"] / 1e3 / launches
-        bytes_per_launch = ALGO_BYTES_PER_INPUT_BYTE * len(data) * args.steps / launches
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
-        # WRITE_SIZE collected in separate rocprofv3 runs on one 16 MiB block, profiles/): not live
-        traffic = None
+        names = ["orz_wave_kernel<ParseWave>" if args.mode == "exact" else "orz_thread_kernel<FastEval>", "orz_symrank_kernel",
+                 "orz_wave_kernel<FastRowsWave>", "orz_wave_kernel<PathUpWave>"]
+        # HBM bytes per launch from this round's PMC passes (tools/profile_round.sh), only if it is about the same kernel
+        pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic_16MiB_l1.json")) as f:
-                traffic = json.load(f).get("parse_wave_hbm_bytes_per_launch")
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_16MiB_l1.json")) as f:
+                pmc = json.load(f).get("by_name", {})
         except Exception:
-            traffic = None
+            pmc = {}
+
+        def roof(i):
+            ms, n = kt[i]
+            if not n or ms <= 0:
+                return None
+            avg_s = ms / 1e3 / n
+            bpl = ALGO_BYTES_PER_INPUT_BYTE * len(data) * args.steps / n
+            ach = bpl / avg_s / 1e9
+            return {"bound": "hbm", "kernel": names[i], "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 8), "traffic": pmc.get(names[i]), "launches_per_step": n // args.steps,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": round(bpl, 1),
+                    "device_ms_per_step": round(ms / args.steps, 2)}
+
+        order = sorted(range(4), key=lambda i: -kt[i][0])
+        roofs = [r for r in (roof(i) for i in order) if r]
         res = {
             "metric": "orz -l1 encode throughput (enwik8-shaped text, 100 MB, one 16 MiB block in flight)",
             "value": round(value, 3),
@@ -162,34 +189,25 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic: deterministic text corpus assembled from text files of this image (tools/corpus.py), "
-                    "sha256 " + sha[:16],
+            "data": "synthetic: enwik8-shaped text from a committed word-level Markov model, seeded (tools/enwik_like.py; gzip -6 "
+                    "36.4 %, bzip2 -9 29.1 % like enwik8), sha256 " + sha[:16],
             "config": {
-                "workload": "BASELINE configs[1]: orz -l1, %d bytes of text, single stream per GPU, one 16 MiB block in flight"
+                "workload": "BASELINE configs[1]: orz -l1, %d bytes of enwik8-shaped text, single stream per GPU, one 16 MiB block in flight"
                             % len(data),
+                "mode": "fast" if cfg["mode"] == 1 else "exact",
                 "level": LEVEL,
-                "lzcfg": [15, 9, 6],
+                "lzcfg": [int(enc.cfg.match_depth), int(enc.cfg.lazy_match_depth1), int(enc.cfg.lazy_match_depth2)],
                 "members": world,
-                "segment_bytes": 62,
-                "window_segments": 3072,
-                "handoff_lookback_segments": 24,
-                "handoff_deadline_us": 110,
+                "encoder": cfg,  # read back through orz_stream_get_config
                 "input": "resident in HBM",
             },
             "compressed_bytes": len(out),
             "ratio": round(len(out) / len(data), 5),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "orz_wave_kernel<ParseWave>",
-                "achieved": round(achieved, 4),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 8),
-                "traffic": traffic,
-                "launches_per_step": launches // args.steps,
-                "avg_launch_us": round(avg_launch_s * 1e6, 2),
-                "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
-            },
+            "items_per_byte": round(agg["items"] / args.steps / len(data), 4),
+            "rounds_or_sweeps_per_step": agg["sweeps"] // args.steps,
+            "repairs_per_step": agg["seg_evals"] // args.steps if cfg["mode"] == 1 else None,
+            "roofline": roofs[0] if roofs else None,
+            "roofline_others": roofs[1:],
             "stage_seconds_per_step": {
                 "prep": round(agg["t_prep_s"] / args.steps, 4),
                 "parse": round(agg["t_parse_s"] / args.steps, 4),

@@ -96,6 +96,25 @@ typedef struct {
 typedef struct orz_stream orz_stream;
 orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg);
 void orz_stream_free(orz_stream*);
+/* Parse mode.  ORZ_MODE_EXACT reproduces the reference encoder's parse (src/lz.rs:131-235) item for item, so
+ * the stream is byte-identical to `orz encode`; ORZ_MODE_FAST is the GPU-native parse (orz_amd/csrc/orz_fast.h):
+ * same bitstream format, decodes bit-exactly with the reference decoder, size within +-0.5 % of the
+ * reference's at the same level (BASELINE.json north_star), an order of magnitude faster.  New encoders start
+ * in fast mode unless the environment says ORZ_MODE=exact.  tile_bytes (multiple of 4096) / rounds: 0 = keep. */
+#define ORZ_MODE_EXACT 0
+#define ORZ_MODE_FAST 1
+int orz_stream_set_mode(orz_stream*, int mode, unsigned tile_bytes, unsigned rounds);
+typedef struct {
+    int mode;
+    unsigned segment_bytes, window_segments;               /* exact mode: speculative segment / sweep window */
+    unsigned fast_tile_bytes, fast_rounds, fast_row_entries; /* fast mode: Gauss-Seidel tile, rounds, candidates tabulated per position */
+} orz_stream_config;
+/* what the encoder actually runs with (bench.py reports these instead of literals) */
+int orz_stream_get_config(orz_stream*, orz_stream_config* out);
+/* HIP-event time and launch count of four kernels over the last orz_stream_encode call made with stats != NULL:
+ * [0] the parse's per-position kernel (exact: ParseWave, fast: FastEval), [1] symbol ranking, [2] candidate table
+ * build (fast mode), [3] path maps (fast mode).  What bench.py's roofline leg is computed from. */
+int orz_stream_get_kernel_times(orz_stream*, double* ms4, uint64_t* launches4);
 /* tuning: bytes per speculative segment and segments per sweep window (0 = keep) */
 int orz_stream_set_tuning(orz_stream*, unsigned seg_bytes, unsigned window_segs);
 /* Encode `n` bytes at `src` (host memory, or device memory when src_on_device != 0) into a
@@ -117,7 +136,8 @@ typedef struct {
     uint8_t unlikely;       /* symrank_unlikely */
     uint8_t enc_len;        /* encoded_match_len */
     uint8_t after_literal;  /* bit 0: after_literal, bit 1: item is a match */
-    uint8_t pad;
+    uint8_t match_len;      /* match length (0 for literal / WORD) */
+    uint32_t src;           /* window offset of the match source (0 for literal / WORD) */
 } orz_item;
 int orz_stream_set_item_trace(orz_stream*, int on);
 /* copies up to cap items to out, returns the total number traced (or a negative error) */

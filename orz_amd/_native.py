@@ -41,11 +41,21 @@ class EncodeStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class StreamConfig(ctypes.Structure):  # orz_stream_config
+    _fields_ = [
+        ("mode", ctypes.c_int), ("segment_bytes", ctypes.c_uint), ("window_segments", ctypes.c_uint),
+        ("fast_tile_bytes", ctypes.c_uint), ("fast_rounds", ctypes.c_uint), ("fast_row_entries", ctypes.c_uint),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class Item(ctypes.Structure):
     _fields_ = [
         ("block", ctypes.c_uint32), ("pos", ctypes.c_uint32), ("symbol", ctypes.c_uint16), ("rank", ctypes.c_uint16),
         ("ctx", ctypes.c_uint16), ("robits", ctypes.c_uint16), ("unlikely", ctypes.c_uint8), ("enc_len", ctypes.c_uint8),
-        ("after_literal", ctypes.c_uint8), ("pad", ctypes.c_uint8),
+        ("after_literal", ctypes.c_uint8), ("match_len", ctypes.c_uint8), ("src", ctypes.c_uint32),
     ]
 
 
@@ -103,6 +113,9 @@ SYMBOLS = [
     ("orz_stream_new", ctypes.c_void_p, [ctypes.c_int, ctypes.POINTER(LZCfg)]),
     ("orz_stream_free", None, [ctypes.c_void_p]),
     ("orz_stream_set_tuning", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    ("orz_stream_set_mode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint]),
+    ("orz_stream_get_config", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StreamConfig)]),
+    ("orz_stream_get_kernel_times", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
     (
         "orz_stream_encode",
         ctypes.c_int,

@@ -32,12 +32,34 @@ def cfg_for_level(level):
 class StreamEncoder:
     """One orz stream encoder bound to one GPU; reusable across inputs."""
 
-    def __init__(self, device=0, level=1, cfg=None):
+    def __init__(self, device=0, level=1, cfg=None, mode=None, tile_bytes=0, rounds=0):
+        """mode: "fast" (GPU-native parse: reference-decodable, size within +-0.5 %), "exact" (the reference's
+        parse item for item: byte-identical stream) or None = the library default (fast unless ORZ_MODE=exact)."""
         self._lib = _native.load()
         self.cfg = cfg if cfg is not None else cfg_for_level(level)
         self._h = self._lib.orz_stream_new(int(device), ctypes.byref(self.cfg))
         if not self._h:
             raise OrzError("orz_stream_new failed: " + _native.last_error())
+        if mode is not None or tile_bytes or rounds:
+            if mode is None:
+                mode = "fast" if self.config()["mode"] == 1 else "exact"
+            if mode not in ("fast", "exact"):
+                raise ValueError("mode must be 'fast' or 'exact'")
+            _check(self._lib.orz_stream_set_mode(self._h, 1 if mode == "fast" else 0, int(tile_bytes), int(rounds)),
+                   "orz_stream_set_mode")
+
+    def config(self):
+        """What the encoder runs with (orz_stream_get_config)."""
+        c = _native.StreamConfig()
+        _check(self._lib.orz_stream_get_config(self._h, ctypes.byref(c)), "orz_stream_get_config")
+        return c.as_dict()
+
+    def kernel_times(self):
+        """[(ms, launches)] x 4 of the last encode(stats=True): parse kernel, symbol ranking, candidate tables, path maps"""
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_uint64 * 4)()
+        _check(self._lib.orz_stream_get_kernel_times(self._h, ms, n), "orz_stream_get_kernel_times")
+        return [(ms[i], n[i]) for i in range(4)]
 
     def set_tuning(self, seg_bytes=0, window_segs=0):
         _check(self._lib.orz_stream_set_tuning(self._h, seg_bytes, window_segs), "orz_stream_set_tuning")
@@ -80,7 +102,8 @@ class StreamEncoder:
         buf = (_native.Item * max(n, 1))()
         self._lib.orz_stream_get_item_trace(self._h, buf, n)
         dt = np.dtype([("block", "<u4"), ("pos", "<u4"), ("symbol", "<u2"), ("rank", "<u2"), ("ctx", "<u2"),
-                       ("robits", "<u2"), ("unlikely", "u1"), ("enc_len", "u1"), ("after_literal", "u1"), ("pad", "u1")])
+                       ("robits", "<u2"), ("unlikely", "u1"), ("enc_len", "u1"), ("after_literal", "u1"), ("match_len", "u1"),
+                       ("src", "<u4")])
         return np.frombuffer(buf, dtype=dt, count=n).copy()
 
     def close(self):

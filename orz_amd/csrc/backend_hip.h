@@ -85,38 +85,95 @@ __global__ __launch_bounds__(64) void orz_huff_kernel(HuffBuild f) {
     if (threadIdx.x == 0) f.build(tid, w0, sc);
 }
 
-// SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context, the 389-entry value and
-// index tables live in LDS; lane 0 walks the context's item run (the chain is serial by
-// definition), all 64 lanes move the tables in and out of LDS.
+// SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context.  The chain is serial by definition and a
+// lone wavefront issues one instruction every four cycles, so what counts is the number of instructions per item.
+// The 64 best-ranked symbols live in ONE vector register (lane r holds value[r]): "which rank has symbol v" is a
+// compare + s_ff1, the 3-way rotate is two v_readlane and three v_writelane with scalar operands, and the whole
+// loop runs on the scalar unit -- no LDS round trip on the common path.  Ranks >= 64 stay in LDS (value[] for
+// those ranks; index[] for the symbols that sit there).  Items are fetched 64 at a time into a register and
+// handed out with v_readlane; the ranks go back through v_writelane the same way.
+__device__ __forceinline__ int orz_writelane(int old, uint32_t sval, uint32_t slane) {  // old[slane] = sval (both uniform)
+    // (VOP3 reads one SGPR only: the lane select travels in M0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sval), "s"(slane) : "m0");
+    return old;
+}
 __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank,
                                                          const uint32_t* rstart) {
-    __shared__ uint16_t tab[2 * kSyms + 4];
-    __shared__ uint32_t magic[392];  // reciprocals for the rank update's division by the (small) item count
-    const uint32_t c = blockIdx.x;
+    __shared__ uint16_t val[kSyms + 3];
+    __shared__ uint16_t idx[kSyms + 3];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
     const uint32_t a = rstart[c], e = rstart[c + 1];
     if (a >= e) return;
     uint16_t* state = srstate + (size_t)c * kSrWords;
-    for (uint32_t i = threadIdx.x; i < kSrWords; i += 64) tab[i] = state[i];
-    for (uint32_t d = threadIdx.x; d < 392; d += 64) magic[d] = d >= 2 ? (uint32_t)(0x100000000ull / d) + 1 : 0;
+    for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = state[i]; idx[i] = state[kSyms + i]; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint16_t* value = tab;
-        uint16_t* index = tab + kSyms;
-        uint32_t cnt = tab[2 * kSyms] | ((uint32_t)tab[2 * kSyms + 1] << 16);
-        uint32_t sum = tab[2 * kSyms + 2] | ((uint32_t)tab[2 * kSyms + 3] << 16);
-        uint32_t g = gsym[a];
-        for (uint32_t j = a; j < e; j++) {
-            uint32_t gn = j + 1 < e ? gsym[j + 1] : 0;  // prefetch the next item behind the table update
-            grank[j] = symrank_encode(value, index, cnt, sum, (uint16_t)(g & 0xffff), (uint16_t)(g >> 16), magic);
-            g = gn;
+    int vreg = val[lane];
+    uint32_t cnt = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms] | ((uint32_t)state[2 * kSyms + 1] << 16)));
+    uint32_t sum = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms + 2] | ((uint32_t)state[2 * kSyms + 3] << 16)));
+    // reciprocals of the steady-state counts 327 + lane: floor(n / d) == mulhi(n, floor(2^32 / d) + 1) for n < 2^17
+    const int mreg = (int)(0xffffffffu / (327 + lane) + 1);
+    for (uint32_t j0 = a; j0 < e; j0 += 64) {
+        const int items = j0 + lane < e ? (int)gsym[j0 + lane] : 0;
+        const uint32_t nthis = e - j0 < 64 ? e - j0 : 64;
+        int outr = 0;
+        for (uint32_t k = 0; k < nthis; k++) {
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane(items, (int)k);
+            const uint32_t v = g & 0xffff, vun = g >> 16;
+            const uint64_t m = __ballot(vreg == (int)v), mu = __ballot(vreg == (int)vun);
+            uint32_t i = m ? (uint32_t)__builtin_ctzll(m) : 64;
+            uint32_t iu = mu ? (uint32_t)__builtin_ctzll(mu) : 65;  // outside the register: certainly behind a register rank
+            if (__builtin_expect(i >= 64, 0)) {
+                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
+                if (!mu) iu = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
+            }
+            if (cnt > kSyms) {  // src/symrank.rs:63-66
+                cnt = cnt * 9 / 10;
+                sum = sum * 9 / 10;
+            }
+            cnt += 1;
+            sum += i;
+            const uint32_t n16 = sum >> 4;
+            uint32_t q;
+            if (__builtin_expect(cnt >= 327, 1)) q = __umulhi(n16, (uint32_t)__builtin_amdgcn_readlane(mreg, (int)(cnt - 327)));
+            else q = n16 / cnt;
+            const uint32_t dec = (i >> 4) + (q & 0xffff);
+            const uint32_t hi = i > dec ? i : dec;
+            uint32_t next_i = hi - dec;  // saturating i - dec
+            next_i = next_i > (i >> 1) ? next_i : (i >> 1);
+            const uint32_t ni1 = next_i + ((i - next_i) >> 1);
+            // value[i] <- value[ni1] <- value[next_i] <- v  (for a one-step move ni1 == next_i and this is the swap;
+            // for no move all three coincide and nothing changes: one straight line covers src/symrank.rs:75-96)
+            if (__builtin_expect(i < 64, 1)) {  // everything involved sits in the register
+                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(vreg, (int)ni1);
+                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(vreg, (int)next_i);
+                vreg = orz_writelane(vreg, nv1, i);
+                vreg = orz_writelane(vreg, nv2, ni1);
+                vreg = orz_writelane(vreg, v, next_i);
+            } else if (i != next_i) {
+                const uint32_t nv1 = ni1 < 64 ? (uint32_t)__builtin_amdgcn_readlane(vreg, (int)ni1) : (uint32_t)__builtin_amdgcn_readfirstlane((int)val[ni1]);
+                const uint32_t nv2 = next_i < 64 ? (uint32_t)__builtin_amdgcn_readlane(vreg, (int)next_i) : (uint32_t)__builtin_amdgcn_readfirstlane((int)val[next_i]);
+                val[i] = (uint16_t)nv1; idx[nv1] = (uint16_t)i;  // i >= 64
+                if (ni1 != next_i) {
+                    if (ni1 < 64) vreg = orz_writelane(vreg, nv2, ni1); else { val[ni1] = (uint16_t)nv2; idx[nv2] = (uint16_t)ni1; }
+                }
+                if (next_i < 64) vreg = orz_writelane(vreg, v, next_i); else { val[next_i] = (uint16_t)v; idx[v] = (uint16_t)next_i; }
+            }
+            const uint32_t r = i == iu ? kSyms - 1 : i - (i > iu);
+            outr = orz_writelane(outr, r, k);
         }
-        tab[2 * kSyms] = (uint16_t)cnt;
-        tab[2 * kSyms + 1] = (uint16_t)(cnt >> 16);
-        tab[2 * kSyms + 2] = (uint16_t)sum;
-        tab[2 * kSyms + 3] = (uint16_t)(sum >> 16);
+        if (j0 + lane < e) grank[j0 + lane] = (uint16_t)outr;
     }
+    // tables back to HBM: the register's 64 ranks first
+    val[lane] = (uint16_t)vreg;
+    idx[vreg] = (uint16_t)lane;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kSrWords; i += 64) state[i] = tab[i];
+    for (uint32_t i = lane; i < kSyms; i += 64) { state[i] = val[i]; state[kSyms + i] = idx[i]; }
+    if (lane == 0) {
+        state[2 * kSyms] = (uint16_t)cnt;
+        state[2 * kSyms + 1] = (uint16_t)(cnt >> 16);
+        state[2 * kSyms + 2] = (uint16_t)sum;
+        state[2 * kSyms + 3] = (uint16_t)(sum >> 16);
+    }
 }
 
 class HipBackend {
@@ -272,9 +329,12 @@ class HipBackend {
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::inclusive_scan(tmp_, sz, in, out, n, rocprim::maximum<uint32_t>(), stream_));
     }
-    // HIP-event bracket around the dominant kernel's launches (bench.py roofline leg)
-    void timed_begin() {
-        if (!timing_ || cur_ != 0) return;
+    // HIP-event brackets around selected kernels (bench.py roofline leg): slot 0 = the parse's per-position kernel
+    // (ParseWave / FastEval), 1 = symbol ranking, 2 = candidate table build, 3 = path extraction.  Events are recorded on
+    // the stream the kernel is launched on.
+    static constexpr int kTimedSlots = 4;
+    void timed_begin(int slot = 0) {
+        if (!timing_) return;
         if (ev_used_ + 2 > ev_.size()) {
             for (int i = 0; i < 256; i++) {
                 hipEvent_t e;
@@ -283,29 +343,41 @@ class HipBackend {
             }
         }
         ORZ_HIP_CHECK(hipEventRecord(ev_[ev_used_], stream_));
+        ev_slot_.resize(ev_.size() / 2 + 1);
+        ev_slot_[ev_used_ / 2] = slot;
     }
-    void timed_end() {
-        if (!timing_ || cur_ != 0) return;
+    void timed_end(int = 0) {
+        if (!timing_) return;
         ORZ_HIP_CHECK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
     }
     void set_timing(bool on) { timing_ = on; }
-    // sum of the bracketed intervals in ms since the last call; also returns their count
-    double collect_timed(uint64_t* launches) {
+    // sums of the bracketed intervals in ms per slot since the last call, and their counts; returns slot 0's sum
+    double collect_timed(uint64_t* launches, double* ms_by_slot = nullptr, uint64_t* n_by_slot = nullptr) {
         ORZ_HIP_CHECK(hipStreamSynchronize(streams_[0]));
-        double ms = 0;
+        ORZ_HIP_CHECK(hipStreamSynchronize(streams_[1]));
+        double ms[kTimedSlots] = {0, 0, 0, 0};
+        uint64_t cnt[kTimedSlots] = {0, 0, 0, 0};
         for (size_t i = 0; i + 1 < ev_used_; i += 2) {
             float t = 0;
             ORZ_HIP_CHECK(hipEventElapsedTime(&t, ev_[i], ev_[i + 1]));
-            ms += t;
+            const int sl = ev_slot_[i / 2] & (kTimedSlots - 1);
+            ms[sl] += t;
+            cnt[sl]++;
         }
-        if (launches) *launches = ev_used_ / 2;
+        if (launches) *launches = cnt[0];
+        for (int i = 0; i < kTimedSlots; i++) {
+            if (ms_by_slot) ms_by_slot[i] = ms[i];
+            if (n_by_slot) n_by_slot[i] = cnt[i];
+        }
         ev_used_ = 0;
-        return ms;
+        return ms[0];
     }
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
+        timed_begin(1);
         hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart);
         ORZ_HIP_CHECK(hipGetLastError());
+        timed_end(1);
     }
 
    private:
@@ -319,6 +391,7 @@ class HipBackend {
     size_t tmp_bytes_ = 0;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
+    std::vector<int> ev_slot_;
     size_t ev_used_ = 0;
 };
 

@@ -43,6 +43,12 @@ unsigned env_u(const char* name, unsigned dflt) {
 
 using Enc = orz::StreamEncoder<orz::HipBackend>;
 
+// parse mode of a new encoder: the GPU-native fast mode unless ORZ_MODE=exact asks for the reference-identical parse
+bool mode_from_env() {
+    const char* v = std::getenv("ORZ_MODE");
+    return !(v && std::string(v) == "exact");
+}
+
 unsigned window_for(const orz::HipBackend& be, const orz_lzcfg& c, unsigned asked) {
     if (asked) return asked;
     const size_t dmax = std::max(c.match_depth, std::max(c.lazy_match_depth1, c.lazy_match_depth2));
@@ -58,9 +64,13 @@ struct orz_stream {
     unsigned seg, win;
     orz::ItemTrace trace;
     bool tracing = false;
+    bool fast = false;
+    unsigned ftile = 65536, frounds = 8;
+    double kernel_ms[4] = {0, 0, 0, 0};
+    uint64_t kernel_n[4] = {0, 0, 0, 0};
     void rebuild() {
         enc.reset();
-        enc.reset(new Enc(*be, to_cfg(&cfg), seg, window_for(*be, cfg, win)));
+        enc.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
         enc->trace = tracing ? &trace : nullptr;
     }
 };
@@ -112,6 +122,9 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         s->cfg = *cfg;
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
         s->win = env_u("ORZ_WIN", 0);
+        s->fast = mode_from_env();
+        s->ftile = env_u("ORZ_FAST_TILE", 65536);
+        s->frounds = env_u("ORZ_FAST_ROUNDS", 8);
         s->rebuild();
         return s.release();
     } catch (const std::exception& e) {
@@ -135,6 +148,33 @@ int orz_stream_set_tuning(orz_stream* s, unsigned seg_bytes, unsigned window_seg
     } catch (const std::exception& e) {
         return fail(ORZ_EINVAL, e.what());
     }
+}
+int orz_stream_set_mode(orz_stream* s, int mode, unsigned tile_bytes, unsigned rounds) {
+    if (!s || (mode != ORZ_MODE_EXACT && mode != ORZ_MODE_FAST)) return fail(ORZ_EINVAL, "bad mode");
+    try {
+        s->fast = mode == ORZ_MODE_FAST;
+        if (tile_bytes) s->ftile = tile_bytes;
+        if (rounds) s->frounds = rounds;
+        s->rebuild();
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
+}
+int orz_stream_get_kernel_times(orz_stream* s, double* ms4, uint64_t* launches4) {
+    if (!s || !ms4 || !launches4) return fail(ORZ_EINVAL, "null argument");
+    for (int i = 0; i < 4; i++) { ms4[i] = s->kernel_ms[i]; launches4[i] = s->kernel_n[i]; }
+    return ORZ_OK;
+}
+int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
+    if (!s || !out) return fail(ORZ_EINVAL, "null argument");
+    out->mode = s->enc->fast() ? ORZ_MODE_FAST : ORZ_MODE_EXACT;
+    out->segment_bytes = s->enc->seg_size();
+    out->window_segments = s->enc->window_segs();
+    out->fast_tile_bytes = s->enc->fast_tile();
+    out->fast_rounds = s->enc->fast_rounds();
+    out->fast_row_entries = s->enc->fast_row();
+    return ORZ_OK;
 }
 int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
                       orz_encode_stats* stats) {
@@ -162,7 +202,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             stats->items = st.items; stats->chunks = st.chunks; stats->in_bytes = st.in_bytes;
             stats->out_bytes = out.size();
             stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
-            stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches);
+            stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
             stats->total_ms = total;
         }
         uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
@@ -190,7 +230,8 @@ long orz_stream_get_item_trace(orz_stream* s, orz_item* out, size_t cap) {
     for (size_t i = 0; i < n && i < cap && out; i++) {
         orz_item it;
         it.block = t.block[i]; it.pos = t.pos[i]; it.symbol = t.sym[i]; it.rank = t.rank[i]; it.ctx = t.ctx[i];
-        it.robits = t.rob[i]; it.unlikely = t.unl[i]; it.enc_len = t.enc[i]; it.after_literal = t.al[i]; it.pad = 0;
+        it.robits = t.rob[i]; it.unlikely = t.unl[i]; it.enc_len = t.enc[i]; it.after_literal = t.al[i]; it.match_len = t.mlen[i];
+        it.src = t.src[i];
         out[i] = it;
     }
     return (long)n;
@@ -341,7 +382,9 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
         const bool same_cfg = e->enc && std::memcmp(&e->cfg, cfg, sizeof *cfg) == 0;
         if (!e->enc) {
             e->cfg = *cfg;
-            e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, window_for(*e->be, *cfg, e->win)));
+            const bool fast = mode_from_env();
+            e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, fast ? 64 : window_for(*e->be, *cfg, e->win), fast,
+                                 env_u("ORZ_FAST_TILE", 65536), env_u("ORZ_FAST_ROUNDS", 8)));
         } else if (!same_cfg) {
             return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
         }

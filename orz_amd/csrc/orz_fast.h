@@ -46,6 +46,9 @@ struct FastArgs {
     const uint16_t* kw;         // [n+1] the two bytes at each word-list slot's position
     const uint8_t* wsnap;       // words[] at the block start
     const uint32_t* ORD;        // exact ring ordinals of history item starts
+    const uint64_t* stext;      // [nent][2] 16 leading bytes of each slot's position
+    const uint32_t* runstart;   // first slot of each (ctx, hash) run
+    uint32_t far;               // slots searched beyond the tabulated K when a long run shows too few item starts
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
@@ -93,6 +96,7 @@ struct FastSlotInit {  // thread per slot: history slots are item starts for goo
         if (j >= nent) return;
         const uint32_t p = epos[j];
         if (p < kPre) { atom_or64(&vbits[j >> 6], 1ull << (j & 63)); return; }
+        if (!keys) return;  // (bitmap only: the run depths are already there)
         const uint32_t d = (uint32_t)j - runstart[keys[j]];
         rlen[p - kPre] = (uint8_t)(d < 255 ? d : 255);
     }
@@ -125,53 +129,95 @@ struct FastRows {
 };
 // Same table, one wavefront per 64 consecutive slots: the 16 leading bytes of the 64 + K slots involved are
 // staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 16 bytes go to the window.
+// The rows leave through LDS as well, 64 columns at a time, so that every 64-byte piece of a row is written by
+// four neighbouring lanes in one go (a lane storing its own row eight bytes at a time costs a partial line per store).
+struct FastText {  // the 16 leading bytes of every slot's position, in slot order (one scattered read per slot, once per block)
+    const uint8_t* win;
+    const uint32_t* epos;
+    uint32_t nent;
+    uint64_t* stext;
+    ORZ_HD void operator()(size_t j) const {
+        if (j >= nent) return;
+        const uint8_t* p = win + epos[j];
+        stext[2 * j] = ldu64(p);
+        stext[2 * j + 1] = ldu64(p + 8);
+    }
+};
 struct FastRowsWave {
     const uint8_t* win;
     const uint32_t* epos;
+    const uint64_t* stext;
     const uint8_t* rlen;
-    uint32_t nent, K;
+    uint32_t nent, K;  // K is a multiple of 64
     uint8_t* rows;
-    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 24; }
+    static constexpr uint32_t kOutStride = 72;  // bytes per lane in the staging tile (64 + pad against bank conflicts)
+    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint64_t* t0 = (uint64_t*)w.lds();            // [64+K] bytes 0..7
         uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..15
         uint32_t* ps = (uint32_t*)(t1 + (64 + K));    // [64+K] positions
+        uint8_t* outL = (uint8_t*)(ps + (64 + K));    // [64][kOutStride]
+        const uint32_t lane = w.lane();
         const int64_t base = (int64_t)w.block() * 64 - K;  // slot of LDS entry 0
-        for (uint32_t e = w.lane(); e < 64 + K; e += 64) {
+        for (uint32_t e = lane; e < 64 + K; e += 64) {
             const int64_t s = base + e;
             uint32_t q = 0;
             uint64_t a = 0, b = 0;
-            if (s >= 0 && s < (int64_t)nent) { q = epos[s]; a = ldu64(win + q); b = ldu64(win + q + 8); }
+            if (s >= 0 && s < (int64_t)nent) { q = epos[s]; a = stext[2 * s]; b = stext[2 * s + 1]; }
             t0[e] = a; t1[e] = b; ps[e] = q;
         }
         w.sync();
-        const uint32_t me = K + w.lane();
+        const uint32_t me = K + lane;
         const uint32_t p = ps[me];
-        if ((int64_t)w.block() * 64 + w.lane() >= (int64_t)nent || p < kPre) return;
-        const uint32_t r = fast_min(K, rlen[p - kPre]);
+        const bool mine = (int64_t)w.block() * 64 + lane < (int64_t)nent && p >= kPre;
+        const uint32_t r = mine ? fast_min(K, rlen[p - kPre]) : 0;
         const uint64_t a0 = t0[me], a1 = t1[me];
-        uint8_t* row = rows + (size_t)(p - kPre) * K;
-        for (uint32_t k0 = 0; k0 < K; k0 += 8) {
-            uint64_t pack = 0;
-            for (uint32_t kk = 0; kk < 8; kk++) {
-                const uint32_t k = k0 + kk;
-                uint32_t l = 0;
-                if (k < r) {
-                    const uint32_t e = me - 1 - k;
-                    const uint64_t x0 = t0[e] ^ a0;
-                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
-                    else {
-                        const uint64_t x1 = t1[e] ^ a1;
-                        l = x1 ? 8 + ((uint32_t)ctz64(x1) >> 3) : 16 + lcp240u(win + ps[e] + 16, win + p + 16, kMaxLen - 16);
+        for (uint32_t c0 = 0; c0 < K; c0 += 64) {
+            for (uint32_t k0 = 0; k0 < 64; k0 += 8) {
+                uint64_t pack = 0;
+                for (uint32_t kk = 0; kk < 8; kk++) {
+                    const uint32_t k = c0 + k0 + kk;
+                    uint32_t l = 0;
+                    if (k < r) {
+                        const uint32_t e = me - 1 - k;
+                        const uint64_t x0 = t0[e] ^ a0;
+                        if (x0) l = (uint32_t)ctz64(x0) >> 3;
+                        else {
+                            const uint64_t x1 = t1[e] ^ a1;
+                            l = x1 ? 8 + ((uint32_t)ctz64(x1) >> 3) : 16 + lcp240u(win + ps[e] + 16, win + p + 16, kMaxLen - 16);
+                        }
                     }
+                    pack |= (uint64_t)l << (8 * kk);
                 }
-                pack |= (uint64_t)l << (8 * kk);
+                *reinterpret_cast<uint64_t*>(outL + lane * kOutStride + k0) = pack;
             }
-            *reinterpret_cast<uint64_t*>(row + k0) = pack;  // rows are 8-byte aligned (K is a multiple of 16)
+            w.sync();
+            for (uint32_t it = 0; it < 4; it++) {  // 16 rows per pass, four lanes per 64-byte piece
+                const uint32_t row = it * 16 + (lane >> 2), part = lane & 3;
+                const uint32_t pr = ps[K + row];
+                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {
+                    const uint64_t v0 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16);
+                    const uint64_t v1 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16 + 8);
+                    uint64_t* dst = reinterpret_cast<uint64_t*>(rows + (size_t)(pr - kPre) * K + c0 + part * 16);
+                    dst[0] = v0; dst[1] = v1;
+                }
+            }
+            w.sync();
         }
     }
 };
+
+
+// common prefix of position p (its 16 leading bytes in a0/a1) with the position of slot s: from the text records,
+// through the window only when all 16 bytes agree
+ORZ_D uint32_t far_lcp(const FastArgs& a, uint32_t p, uint64_t a0, uint64_t a1, uint32_t s) {
+    const uint64_t x0 = a.stext[2 * (size_t)s] ^ a0;
+    if (x0) return (uint32_t)ctz64(x0) >> 3;
+    const uint64_t x1 = a.stext[2 * (size_t)s + 1] ^ a1;
+    if (x1) return 8 + ((uint32_t)ctz64(x1) >> 3);
+    return 16 + lcp240u(a.win + a.epos[s] + 16, a.win + p + 16, kMaxLen - 16);
+}
 
 // ---- one round: every position of the active range decides from the snapshot --------------------------
 struct FastEval {
@@ -217,6 +263,42 @@ struct FastEval {
                 }
                 seen++;
                 if (l == kMaxLen) { stop = true; break; }
+            }
+        }
+        if (!stop && seen < a.depth && a.rlen[i] > K && a.far) {
+            // a long run whose tabulated K predecessors hold too few item starts (runs of "interior" 4-grams, zero runs):
+            // walk the bitmap further back and take the prefixes from the text records
+            const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
+            const uint32_t top = j - K;  // slots [lo2, top) are searched, newest first
+            const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+            const uint64_t a0 = ldu64(win + p), a1 = ldu64(win + p + 8);
+            for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && seen < a.depth; wbase -= 64) {
+                uint64_t mask = bits_at(a.vbits, wbase);
+                if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
+                while (mask && seen < a.depth) {
+                    const uint32_t t = 63 - (uint32_t)clz64(mask);
+                    mask &= ~(1ull << t);
+                    const uint32_t sl = (uint32_t)(wbase + t);
+                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                    if (l > best || (seen < a.lazy1 && l > m1) || (seen < a.lazy2 && l > m2)) {
+                        const uint32_t q = a.epos[sl];
+                        uint32_t ro_hi, ro_mid;
+                        if (q >= kPre) {
+                            const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
+                            ro_hi = op_hi - oq;
+                            ro_mid = op_lo - oq;
+                        } else {
+                            ro_hi = op_hi - 1 - a.ORD[q];
+                            ro_mid = op_lo - 1 - a.ORD[q];
+                        }
+                        if (ro_hi > kRing - 1) { stop = true; break; }
+                        if (l > best) { best = l; bsrc = q; b510 = (int32_t)ro_mid < 510; }
+                        if (seen < a.lazy1 && l > m1) m1 = l;
+                        if (seen < a.lazy2 && l > m2) m2 = l;
+                    }
+                    seen++;
+                    if (l == kMaxLen) { stop = true; break; }
+                }
             }
         }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
@@ -287,6 +369,99 @@ struct PathChunk {  // x1[c][e] = exit offset past chunk c when entering it at o
         a.x1[(size_t)c * kEntries + e] = (uint8_t)(x >= end ? x - end : 0);
     }
 };
+// The same two maps, one wavefront per 4096-position chunk with the advance lengths staged in LDS: lane s
+// fills x0 for segment s by a backward sweep (a position either leaves the segment or inherits the exit of
+// the position it jumps to), then the 240 chunk entries are walked through LDS.  Rows are padded to 68 bytes
+// so that the 64 lanes, which walk 64 different segments in lockstep, hit different banks.
+ORZ_D uint32_t pad68(uint32_t x) { return (x >> 6) * 68 + (x & 63); }
+struct PathUpWave {
+    FastArgs a;
+    uint32_t c0;
+    static size_t lds_bytes() { return 2 * 64 * 68 + 64; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint8_t* nlL = w.lds();
+        uint8_t* x0L = nlL + 64 * 68 + 32;
+        const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
+        const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
+        for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
+            const uint32_t wi = k * 64 + lane, x = wi * 8;
+            uint64_t v = x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0;
+            for (uint32_t b = 0; b < 8; b++) nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
+        }
+        w.sync();
+        {
+            const uint32_t s0 = lane * 64, s1 = fast_min(s0 + 64, clen);
+            for (uint32_t p = s1; p-- > s0 && s0 < clen;) {
+                const uint32_t d = nlL[pad68(p)], x = p + (d ? d : 1);
+                x0L[pad68(p)] = x >= s1 ? (uint8_t)(x - s1) : x0L[pad68(x)];
+            }
+        }
+        w.sync();
+        for (uint32_t k = part * 2; k < part * 2 + 2; k++) {  // every part writes a quarter of x0
+            const uint32_t wi = k * 64 + lane, x = wi * 8;
+            if (x >= clen) continue;
+            uint64_t v = 0;
+            for (uint32_t b = 0; b < 8; b++) v |= (uint64_t)x0L[pad68(x + b)] << (8 * b);
+            *reinterpret_cast<uint64_t*>(a.x0 + (cs - kPre) + x) = v;
+        }
+        if (lane < 60) {
+            const uint32_t e = part * 60 + lane;
+            uint32_t x = e;
+            while (x < clen) {
+                const uint32_t s1 = fast_min(((x >> 6) + 1) * 64, clen);
+                x = s1 + x0L[pad68(x)];
+            }
+            a.x1[(size_t)c * kEntries + e] = (uint8_t)(x - clen);
+        }
+    }
+};
+struct PathMarkWave {  // one wavefront per chunk, lane = segment
+    FastArgs a;
+    uint32_t c0;
+    static size_t lds_bytes() { return 3 * (64 * 68 + 32); }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint8_t* nlL = w.lds();
+        uint8_t* x0L = nlL + 64 * 68 + 32;
+        uint8_t* tyL = x0L + 64 * 68 + 32;
+        const uint32_t c = c0 + w.block(), lane = w.lane();
+        const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t wi = k * 64 + lane, x = wi * 8;
+            uint64_t v = 0, u = 0, t = 0;
+            if (x < clen) {
+                v = *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x);
+                u = *reinterpret_cast<const uint64_t*>(a.x0 + (cs - kPre) + x);
+                t = *reinterpret_cast<const uint64_t*>(a.ty + (cs - kPre) + x);
+            }
+            for (uint32_t b = 0; b < 8; b++) {
+                nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
+                x0L[pad68(x + b)] = (uint8_t)(u >> (8 * b));
+                tyL[pad68(x + b)] = (uint8_t)(t >> (8 * b));
+            }
+        }
+        w.sync();
+        const uint32_t s0 = lane * 64;
+        if (s0 >= clen) return;
+        const uint32_t s1 = fast_min(s0 + 64, clen);
+        const uint32_t ce = a.centry[c];
+        uint32_t x = ce >= cs ? ce - cs : 0;
+        while (x < s0) {
+            const uint32_t e1 = fast_min(((x >> 6) + 1) * 64, clen);
+            x = e1 + x0L[pad68(x)];
+        }
+        uint64_t m = 0;
+        while (x < s1) {
+            m |= 1ull << (x - s0);
+            const uint32_t d = nlL[pad68(x)];
+            const uint32_t e = x + (d ? d : 1);
+            a.pt[(cs - kPre) + e] = tyL[pad68(x)];
+            x = e;
+        }
+        a.sbits[(cs - kPre) / 64 + lane] = m;
+    }
+};
 ORZ_D uint32_t tile_end(uint32_t t, uint32_t tile, uint32_t len) { return fast_min(len, kPre + (t + 1) * tile); }
 struct PathTile {
     FastArgs a;
@@ -350,38 +525,90 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// bring the slot-order bitmaps and the per-(subtile, ctx) counts in line with the path
+// bring the slot-order bitmaps in line with the path (thread per 8 positions)
 struct FastFlip {
     FastArgs a;
-    uint32_t lo, hi;     // positions y in [lo, hi]
+    uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t y = lo + (uint32_t)tid;
-        if (y > hi) return;
-        const uint32_t i = y - kPre;
-        uint32_t s = 0;
-        if (next_entry != ~0u ? a.tentry[next_entry] == y : y == a.len) s = 1;  // where the path leaves the range / the block
-        if (y < a.len) {
-            s |= (uint32_t)((a.sbits[i / 64] >> (i & 63)) & 1);
-            if (s != a.mf[i]) {
-                a.mf[i] = (uint8_t)s;
-                const uint32_t j = a.idx[y];
-                atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
-                uint32_t* cnt = &a.cm[(size_t)(i / kSub) * 256 + hash1(a.win, y - 1)];
-                if (s) atom_add32(cnt, 1); else atom_sub32(cnt, 1);
+        const uint32_t y0 = lo + (uint32_t)tid * 8;
+        if (y0 > hi) return;
+        const uint32_t i0 = y0 - kPre;
+        const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;  // where the path leaves the range / the block
+        const uint32_t sb = (uint32_t)((a.sbits[i0 / 64] >> (i0 & 63)) & 0xff);
+        uint64_t mfw = *reinterpret_cast<const uint64_t*>(a.mf + i0);
+        uint64_t efw = *reinterpret_cast<const uint64_t*>(a.ef + i0);
+        const uint64_t ptw = *reinterpret_cast<const uint64_t*>(a.pt + i0);
+        const uint64_t mf0 = mfw, ef0 = efw;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t y = y0 + k;
+            if (y > hi) break;
+            uint32_t s = y == exit_at;
+            if (y < a.len) {
+                s |= (sb >> k) & 1;
+                if (s != ((mfw >> (8 * k)) & 0xff)) {
+                    mfw = (mfw & ~(0xffull << (8 * k))) | ((uint64_t)s << (8 * k));
+                    const uint32_t j = a.idx[y];
+                    atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+                }
+            }
+            if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
+                const uint32_t e = s && ((ptw >> (8 * k)) & 0xff) != kTyWord;
+                if (e != ((efw >> (8 * k)) & 0xff)) {
+                    efw = (efw & ~(0xffull << (8 * k))) | ((uint64_t)e << (8 * k));
+                    const uint32_t ku = a.kidx[y - 2];
+                    atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+                }
             }
         }
-        if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
-            const uint32_t e = s && a.pt[i] != kTyWord;
-            if (e != a.ef[i]) {
-                a.ef[i] = (uint8_t)e;
-                const uint32_t ku = a.kidx[y - 2];
-                atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-            }
-        }
+        if (mfw != mf0) *reinterpret_cast<uint64_t*>(a.mf + i0) = mfw;
+        if (efw != ef0) *reinterpret_cast<uint64_t*>(a.ef + i0) = efw;
     }
 };
-struct FastPrefix {  // cp[s+1][c] = cp[s][c] + cm[s][c] over the subtiles [s0, s1)
+// item starts per (subtile, ctx) of the current path: one wavefront per 4096-position subtile, lane = 64 positions,
+// counters in LDS (the ring ordinals of a round are estimated from these: FastEval)
+struct CountWave {
+    FastArgs a;
+    uint32_t s0;
+    static size_t lds_bytes() { return 256 * 4; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* cnt = (uint32_t*)w.lds();
+        const uint32_t s = s0 + w.block(), lane = w.lane();
+        for (uint32_t c = lane; c < 256; c += 64) cnt[c] = 0;
+        w.sync();
+        const uint32_t i0 = s * kSub + lane * 64;
+        if (i0 < a.n) {
+            uint64_t m = a.sbits[i0 / 64];
+            const uint8_t* b = a.win + kPre + i0;
+            while (m) {
+                const uint32_t t = (uint32_t)ctz64(m);
+                m &= m - 1;
+                if (i0 + t < a.n) atom_add32(&cnt[(uint32_t)(b[(int)t - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)t - 2]) << 7)], 1);
+            }
+        }
+        w.sync();
+        for (uint32_t c = lane; c < 256; c += 64) a.cm[(size_t)s * 256 + c] = cnt[c];
+    }
+};
+struct FastPrefix {  // cp[s][c] = cp[s0][c] + sum of cm[s0 .. s)[c] for s in (s0, s1]: thread per (s, ctx), independent loads
+    FastArgs a;
+    uint32_t s0, s1;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = (uint32_t)(tid & 255), s = s0 + 1 + (uint32_t)(tid >> 8);
+        if (s > s1) return;
+        uint32_t v0 = a.cp[(size_t)s0 * 256 + c], v1 = 0, v2 = 0, v3 = 0;
+        uint32_t t = s0;
+        for (; t + 4 <= s; t += 4) {
+            v0 += a.cm[(size_t)t * 256 + c]; v1 += a.cm[(size_t)(t + 1) * 256 + c];
+            v2 += a.cm[(size_t)(t + 2) * 256 + c]; v3 += a.cm[(size_t)(t + 3) * 256 + c];
+        }
+        for (; t < s; t++) v0 += a.cm[(size_t)t * 256 + c];
+        a.cp[(size_t)s * 256 + c] = v0 + v1 + v2 + v3;
+    }
+};
+
+struct FastPrefixSerial {  // whole block, thread per ctx (the loads do not depend on each other, only the adds chain)
     FastArgs a;
     uint32_t s0, s1;
     ORZ_HD void operator()(size_t c) const {
@@ -445,11 +672,11 @@ struct FastSource {
         const uint8_t* row = a.rows + (size_t)i * K;
         uint32_t best = 0, bsrc = 0, seen = 0, found = 0;
         bool stop = false;
-        for (uint32_t m = 0; m * 64 < r && !stop && !found && seen < a.depth; m++) {
+        for (uint32_t m = 0; m * 64 < r && !stop && !found; m++) {  // (no depth limit here: any ring member may serve)
             uint64_t mask = bits_at(a.vbits, (int64_t)j - 64 * (int64_t)(m + 1));
             const uint32_t span = r - m * 64;
             if (span < 64) mask &= ~0ull << (64 - span);
-            while (mask && seen < a.depth) {
+            while (mask) {
                 const uint32_t t = 63 - (uint32_t)clz64(mask);
                 mask &= ~(1ull << t);
                 const uint32_t k = m * 64 + 63 - t;
@@ -461,6 +688,28 @@ struct FastSource {
                     best = l; bsrc = q;
                 }
                 seen++;
+            }
+        }
+        if (!found && !stop && a.rlen[i] > K && a.far) {
+            const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(a.win, p)];
+            const uint32_t top = j - K;
+            const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+            const uint64_t a0 = ldu64(a.win + p), a1 = ldu64(a.win + p + 8);
+            for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && !found; wbase -= 64) {
+                uint64_t mask = bits_at(a.vbits, wbase);
+                if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
+                while (mask) {
+                    const uint32_t t = 63 - (uint32_t)clz64(mask);
+                    mask &= ~(1ull << t);
+                    const uint32_t sl = (uint32_t)(wbase + t);
+                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                    if (l >= kMinLen && (l >= L || l > best)) {
+                        const uint32_t q = a.epos[sl];
+                        if (op - 1 - a.ORD[q] > kRing - 1) { stop = true; break; }
+                        if (l >= L) { found = q; break; }
+                        best = l; bsrc = q;
+                    }
+                }
             }
         }
         if (found) { SRC[p] = found; return; }

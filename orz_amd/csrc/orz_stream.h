@@ -27,10 +27,10 @@ namespace orz {
 
 // optional per-item trace of the encoder (parity tests compare it with the oracle's trace)
 struct ItemTrace {
-    std::vector<uint32_t> block, pos;
+    std::vector<uint32_t> block, pos, src;
     std::vector<uint16_t> sym, ctx, rank, rob;
-    std::vector<uint8_t> unl, enc, al;
-    void clear() { block.clear(); pos.clear(); sym.clear(); ctx.clear(); rank.clear(); rob.clear(); unl.clear(); enc.clear(); al.clear(); }
+    std::vector<uint8_t> unl, enc, al, mlen;
+    void clear() { block.clear(); pos.clear(); src.clear(); sym.clear(); ctx.clear(); rank.clear(); rob.clear(); unl.clear(); enc.clear(); al.clear(); mlen.clear(); }
 };
 
 struct EncodeStats {
@@ -222,9 +222,11 @@ class StreamEncoder {
         if (fast_) {
             if (ftile_ < kSub || ftile_ % kSub) throw std::runtime_error("fast tile must be a multiple of 4096");
             if (frounds_ < 1 || frounds_ > 64) throw std::runtime_error("fast rounds must be in [1, 64]");
-            fK_ = ((uint32_t)cfg.depth * 4 + 15) / 16 * 16;
-            if (fK_ < 32) fK_ = 32;
-            if (fK_ > 192) fK_ = 192;
+            // run predecessors tabulated per position: item starts are about a quarter of a run's positions on text and far
+            // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
+            fK_ = 128;  // (one 128-byte line per row; deeper runs are searched through the bitmap + text records)
+            if (const char* k = getenv("ORZ_FAST_K")) fK_ = (uint32_t)atoi(k);  // experiments
+            if (fK_ < 64 || fK_ > 192 || fK_ % 64) throw std::runtime_error("ORZ_FAST_K must be 64, 128 or 192");
         }
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
@@ -273,6 +275,7 @@ class StreamEncoder {
             const size_t nn = (size_t)kNewMax + 512;
             frows_ = be_.template alloc<uint8_t>((size_t)kNewMax * fK_ + 64);
             frlen_ = be_.template alloc<uint8_t>(nn);
+            fstext_ = be_.template alloc<uint64_t>((size_t)kWLen * 2);
             fkw_ = be_.template alloc<uint16_t>(nn);
             fev_ = be_.template alloc<uint32_t>(nn);
             fbs_ = be_.template alloc<uint32_t>(nn);
@@ -283,10 +286,10 @@ class StreamEncoder {
             fef_ = be_.template alloc<uint8_t>(nn);
             fx0_ = be_.template alloc<uint8_t>(nn);
             fx1_ = be_.template alloc<uint8_t>((size_t)(kNSub + 2) * kEntries);
-            fx2_ = be_.template alloc<uint8_t>((size_t)(kNewMax / ftile_ + 4) * kEntries);
+            fx2_ = be_.template alloc<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
             fsbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 16);
             fcentry_ = be_.template alloc<uint32_t>(kNSub + 2);
-            ftentry_ = be_.template alloc<uint32_t>(kNewMax / ftile_ + 4);
+            ftentry_ = be_.template alloc<uint32_t>(kNewMax / kSub + 4);
             fcm_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
             fcp_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
             fcut_ = be_.template alloc<uint32_t>(nn);
@@ -340,7 +343,7 @@ class StreamEncoder {
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_, frows_, frlen_, fkw_, fev_, fbs_, fty_, fnl_, fpt_, fmf_, fef_, fx0_, fx1_, fx2_,
-                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_};
+                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_, fstext_};
         for (void* p : ptrs) if (p) be_.free(p);
     }
     StreamEncoder(const StreamEncoder&) = delete;
@@ -563,89 +566,116 @@ class StreamEncoder {
     // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
     void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys) {
         const uint8_t* win = dwin();
-        const uint32_t nk = n + 1, K = fK_;
+        const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub;
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
         be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
         be_.launch(nent, FastSlotInit{epos_, slot_keys, runstart_, nent, vbits_, frlen_});
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
-        be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, frlen_, nent, K, frows_}, FastRowsWave::lds_bytes(K));
-        const size_t nn = (size_t)n + 264;
-        be_.memset(fev_, 0, ((size_t)n + 8) * 4);
-        be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
-        be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
-        be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
-        const uint32_t nsub = (n + kSub - 1) / kSub;
-        be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
-        be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
-        be_.launch(256, FastCpInit{ctxcount_, fcp_});
-        { uint32_t e0 = kPre; be_.h2d(ftentry_, &e0, 4); }
+        uint64_t* stext = fstext_;
+        be_.launch(nent, FastText{win, epos_, nent, stext});
+        be_.timed_begin(2);
+        be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_}, FastRowsWave::lds_bytes(K));
+        be_.timed_end(2);
         FastArgs a;
         a.win = win; a.len = len; a.n = n; a.K = K; a.depth = (uint32_t)cfg_.depth; a.lazy1 = (uint32_t)cfg_.lazy1;
         a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_;
         a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
-        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.vbits = vbits_; a.kbits = kbits_; a.ev = fev_; a.bs = fbs_;
+        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_;
+        a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 4096; a.vbits = vbits_; a.kbits = kbits_; a.ev = fev_; a.bs = fbs_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mf = fmf_; a.ef = fef_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = fnchg_;
-        // ---- pipelined Gauss-Seidel rounds
-        const uint32_t T = ftile_, R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
-        for (uint32_t step = 1; step <= ntile + R - 1; step++) {
-            const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
-            const uint32_t lo = kPre + t_lo * T;
-            const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
-            const uint32_t hi2 = std::min(len, hi + 2);
-            be_.timed_begin();
-            be_.launch(hi2 - lo, FastEval{a, lo, hi2});
-            be_.timed_end();
-            be_.launch(hi - lo, FastDecide{a, lo, hi});
-            be_.launch(hi - lo, PathSeg{a, lo, hi});
-            const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
-            be_.launch((size_t)nc * kEntries, PathChunk{a, c0, nc});
-            be_.launch((size_t)nt * kEntries, PathTile{a, t_lo, nt});
-            be_.launch((size_t)nc + 1, PathDown{a, t_lo, nt});
-            const uint32_t s0 = (lo - kPre) / kSeg64, ns = (hi - lo + kSeg64 - 1) / kSeg64;
-            be_.launch(ns, PathMark{a, s0, ns});
-            const uint32_t fhi = std::min(len, hi + 240);
-            be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1});
-            be_.launch(256, FastPrefix{a, c0, c0 + nc});
-            stats.sweeps++;
+        // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
+        // anyway), and a block whose parse turns out unstable -- many items lost their source -- is redone with tiles
+        // a quarter the size (match-dense, highly repetitive data; never seen on text).
+        uint32_t T = ftile_;
+        {
+            const uint32_t want = ((n / 256 + kSub - 1) / kSub) * kSub;
+            T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
         }
-        // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes
-        uint32_t* ckeys = (uint32_t*)entA_;
-        uint32_t* ckeys2 = ckeys + kWLen;
-        uint32_t* cvals = (uint32_t*)entB_;
-        uint32_t* fipos = cvals + kWLen;
-        bool done = false;
-        for (int pass = 0; pass < 200 && !done; pass++) {
-            be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u});
-            be_.launch(n, MemberFlags32{fsbits_, n, f32_});
-            be_.exclusive_scan_u32(f32_, sc32_, n);
-            uint32_t x0, x1;
-            be_.d2h(&x0, sc32_ + (n - 1), 4);
-            be_.d2h(&x1, f32_ + (n - 1), 4);
-            const uint32_t nmem = x0 + x1;
-            be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, fipos});
-            be_.launch(nmem, CtxKeys{win, fipos, nmem, ckeys});
-            be_.sort_pairs_u32(ckeys, ckeys2, fipos, cvals, nmem, 8);
-            be_.launch(257, CtxStarts{ckeys2, nmem, fcstart_});
-            be_.launch(nmem, OrdAssign{ckeys2, cvals, fcstart_, ctxcount_, nmem, ORD_});
-            be_.memset(fnchg_, 0, 4);
-            be_.launch(n, FastSource{a, SRC_, fcut_});
-            be_.launch(n, FastRecut{a, fcut_});
-            be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u});
-            be_.launch(nk, KbitVals{kbits_, nk, f32_});
-            be_.inclusive_max_scan_u32(f32_, flaste_, nk);
-            be_.launch(n, FastWordCheck{a, flaste_});
-            uint32_t chg = 0;
-            be_.d2h(&chg, fnchg_, 4);
-            stats.seg_evals += chg;  // (fast mode: repairs made)
-            done = chg == 0;
+        for (;;) {
+            a.tile = T;
+            be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
+            be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
+            be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
+            const size_t nn = (size_t)n + 264;
+            be_.memset(fev_, 0, ((size_t)n + 8) * 4);
+            be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
+            be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
+            be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
+            be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
+            be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
+            be_.launch(256, FastCpInit{ctxcount_, fcp_});
+            { uint32_t e0 = kPre; be_.h2d(ftentry_, &e0, 4); }
+            // ---- pipelined Gauss-Seidel rounds
+            const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
+            for (uint32_t step = 1; step <= ntile + R - 1; step++) {
+                const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
+                const uint32_t lo = kPre + t_lo * T;
+                const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
+                const uint32_t hi2 = std::min(len, hi + 2);
+                be_.timed_begin();
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2});
+                be_.timed_end();
+                be_.launch(hi - lo, FastDecide{a, lo, hi});
+                const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
+                be_.timed_begin(3);
+                be_.launch_waves((size_t)nc * 4, PathUpWave{a, c0}, PathUpWave::lds_bytes());
+                be_.timed_end(3);
+                be_.launch((size_t)nt * kEntries, PathTile{a, t_lo, nt});
+                be_.launch((size_t)nc + 1, PathDown{a, t_lo, nt});
+                be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
+                const uint32_t fhi = std::min(len, hi + 240);
+                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1});
+                be_.launch_waves(nc, CountWave{a, c0}, CountWave::lds_bytes());
+                be_.launch((size_t)nc * 256, FastPrefix{a, c0, c0 + nc});
+                stats.sweeps++;
+            }
+            // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes
+            uint32_t* ckeys = (uint32_t*)entA_;
+            uint32_t* ckeys2 = ckeys + kWLen;
+            uint32_t* cvals = (uint32_t*)entB_;
+            uint32_t* fipos = cvals + kWLen;
+            bool done = false;
+            uint64_t total_repairs = 0;
+            uint32_t nmem_last = 0;
+            for (int pass = 0; pass < 200 && !done; pass++) {
+                be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
+                be_.launch(n, MemberFlags32{fsbits_, n, f32_});
+                be_.exclusive_scan_u32(f32_, sc32_, n);
+                uint32_t x0, x1;
+                be_.d2h(&x0, sc32_ + (n - 1), 4);
+                be_.d2h(&x1, f32_ + (n - 1), 4);
+                const uint32_t nmem = x0 + x1;
+                be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, fipos});
+                be_.launch(nmem, CtxKeys{win, fipos, nmem, ckeys});
+                be_.sort_pairs_u32(ckeys, ckeys2, fipos, cvals, nmem, 8);
+                be_.launch(257, CtxStarts{ckeys2, nmem, fcstart_});
+                be_.launch(nmem, OrdAssign{ckeys2, cvals, fcstart_, ctxcount_, nmem, ORD_});
+                be_.memset(fnchg_, 0, 4);
+                be_.launch(n, FastSource{a, SRC_, fcut_});
+                be_.launch(n, FastRecut{a, fcut_});
+                be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
+                be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                be_.launch(n, FastWordCheck{a, flaste_});
+                uint32_t chg = 0;
+                be_.d2h(&chg, fnchg_, 4);
+                stats.seg_evals += chg;  // (fast mode: repairs made)
+                total_repairs += chg;
+                nmem_last = nmem;
+                done = chg == 0;
+            }
+            if (!done) throw std::runtime_error("fast parse: repairs did not converge");
+            if (T <= kSub || total_repairs * 200 < (uint64_t)nmem_last) break;  // fewer than 0.5 % of the items were repaired
+            T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
+            stats.seg_evals -= total_repairs;  // (count the repairs of the parse that is kept)
         }
-        if (!done) throw std::runtime_error("fast parse: repairs did not converge");
         // ---- hand over to the post stage; carry the model state
         be_.launch(n, FastCommit{a, flaste_, (uint32_t)lt_carry_, S_, TY_, ML_, W0_});
         be_.launch(32768, FastWordsCarry{a, flaste_, krunend_, wsnap_});
-        be_.launch(256, FastPrefix{a, 0, nsub});
+        be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
+        be_.launch(256, FastPrefixSerial{a, 0, nsub});
         be_.launch(256, FastCtxCarry{fcp_, nsub, ctxcount_});
         uint8_t last_ty = kTyLit;
         be_.d2h(&last_ty, fpt_ + n, 1);
@@ -765,6 +795,18 @@ class StreamEncoder {
             be_.d2h(trace->unl.data() + at, iunl_, nitems);
             be_.d2h(trace->enc.data() + at, ienc_, nitems);
             be_.d2h(trace->al.data() + at, ial_, nitems);
+            // match source and length of each item (window offsets), gathered on the host: diagnostics only
+            std::vector<uint32_t> hsrc(len);
+            std::vector<uint8_t> hml(len);
+            be_.d2h(hsrc.data() + kPre, SRC_ + kPre, (size_t)(len - kPre) * 4);
+            be_.d2h(hml.data() + kPre, ML_ + kPre, len - kPre);
+            trace->src.resize(at + nitems); trace->mlen.resize(at + nitems);
+            for (uint32_t i = 0; i < nitems; i++) {
+                const uint32_t p = trace->pos[at + i];
+                const bool is_match = (trace->al[at + i] & 2) != 0;
+                trace->src[at + i] = is_match ? hsrc[p] : 0;
+                trace->mlen[at + i] = is_match ? hml[p] : 0;
+            }
         }
         be_.select(0);
     }
@@ -797,7 +839,7 @@ class StreamEncoder {
     uint16_t* fkw_ = nullptr;
     uint32_t *fev_ = nullptr, *fbs_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
              *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr;
-    uint64_t* fsbits_ = nullptr;
+    uint64_t *fsbits_ = nullptr, *fstext_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
     bool pending_ = false;

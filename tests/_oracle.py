@@ -83,3 +83,47 @@ def decode(stream):
     out = ctypes.string_at(dst, n.value)
     L.orc_free(dst)
     return out, used.value
+
+
+class PlanItem(ctypes.Structure):  # orc_plan_item
+    _fields_ = [("pos", ctypes.c_uint64), ("src", ctypes.c_uint64), ("type", ctypes.c_uint8), ("len", ctypes.c_uint8)]
+
+
+class PlanError(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_size_t), ("code", ctypes.c_int)]
+
+
+P = (1 << 25) // 2 - 1  # SBVEC_PREMATCH_LEN
+NEW = 1 << 24
+
+
+def plan_from_trace(trace, n):
+    """parse of a device encoder (orz_stream_get_item_trace: block, window offsets) -> plan in stream offsets"""
+    plan = (PlanItem * max(1, len(trace)))()
+    for i, it in enumerate(trace):
+        base = int(it["block"]) * NEW
+        plan[i].pos = base + int(it["pos"]) - P
+        is_match = bool(int(it["after_literal"]) & 2)
+        plan[i].type = 2 if is_match else (0 if int(it["symbol"]) == 388 else 1)
+        plan[i].len = int(it["match_len"]) if is_match else 0
+        plan[i].src = base + int(it["src"]) - P if is_match else 0
+    return plan, len(trace)
+
+
+def encode_plan(data, plan_n):
+    """the reference's state machine + emit half applied to a given parse (orc_encode_plan_mem); raises if the
+    format cannot express an item"""
+    plan, nplan = plan_n
+    L = lib()
+    L.orc_encode_plan_mem.restype = ctypes.c_int
+    dst = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    err = PlanError()
+    data = bytes(data)
+    rc = L.orc_encode_plan_mem(data, ctypes.c_size_t(len(data)), plan, ctypes.c_size_t(nplan), ctypes.byref(dst), ctypes.byref(n),
+                               None, ctypes.byref(err))
+    if rc != 0:
+        raise ValueError("oracle plan encoder rejected the item at stream offset %d (code %d)" % (err.pos, err.code))
+    out = ctypes.string_at(dst, n.value)
+    L.orc_free(dst)
+    return out

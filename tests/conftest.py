@@ -56,6 +56,19 @@ def emu():
         lib.emu_free(dst)
         return out, list(st)
 
+    def encode_fast(data, cfg=(15, 9, 6), tile=0, rounds=0):
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        st = (ctypes.c_ulonglong * 5)()
+        data = bytes(data)
+        rc = lib.emu_encode_fast(data, ctypes.c_size_t(len(data)), cfg[0], cfg[1], cfg[2], tile, rounds, ctypes.byref(dst),
+                                 ctypes.byref(n), st)
+        assert rc == 0
+        out = ctypes.string_at(dst, n.value)
+        lib.emu_free(dst)
+        return out, list(st)
+
+    encode.fast = encode_fast
     return encode
 
 
@@ -69,7 +82,7 @@ def gpu_encoder_factory():
 
     def get(level):
         if level not in cache:
-            cache[level] = orz_amd.StreamEncoder(device=0, level=level)
+            cache[level] = orz_amd.StreamEncoder(device=0, level=level, mode="exact")
         return cache[level]
 
     yield get

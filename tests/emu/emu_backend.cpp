@@ -33,8 +33,8 @@ struct EmuBackend {
     void select(int) {}
     void record(int) {}
     void wait(int) {}
-    void timed_begin() {}
-    void timed_end() {}
+    void timed_begin(int = 0) {}
+    void timed_end(int = 0) {}
     void set_timing(bool) {}
     double collect_timed(uint64_t* n) { if (n) *n = 0; return 0.0; }
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -1,0 +1,78 @@
+"""CPU tier of the FAST parse mode: the kernel bodies of orz_amd/csrc/orz_fast.h run on the host emulation backend
+(thread kernels as loops, the wave kernels on the SIMT emulator).  Parity for this mode: the stream decodes
+bit-exactly with the oracle's decoder and its size stays close to the oracle encoder's; the GPU tier
+(test_gpu_fast.py) holds the +-0.5 % band on the text workload at full size."""
+import pytest
+
+import _data
+
+LEVELS = {0: (5, 3, 2), 1: (15, 9, 6), 2: (45, 27, 18)}
+
+
+def _roundtrip(emu, oracle, data, level=1, band=None, **kw):
+    out, st = emu.fast(data, cfg=LEVELS[level], **kw)
+    back, used = oracle.decode(out)
+    assert used == len(out) and back == data
+    if band is not None:
+        ref = oracle.encode(data, level)
+        assert abs(len(out) - len(ref)) <= band * len(ref) + 64, (len(out), len(ref))
+    return out, st
+
+
+@pytest.mark.parametrize("name", sorted(_data.SMALL_CASES))
+def test_small_cases(emu, oracle, name):
+    _roundtrip(emu, oracle, _data.SMALL_CASES[name])
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_text_levels(emu, oracle, level):
+    _roundtrip(emu, oracle, _data.text(60_000, seed=level + 1), level, band=0.02)
+
+
+@pytest.mark.parametrize("maker", ["mixed", "zeros", "random", "p1", "p2", "p3", "p5"])
+def test_data_shapes(emu, oracle, maker):
+    n = 40_000
+    data = {"mixed": lambda: _data.mixed(n, seed=11), "zeros": lambda: _data.zeros_noise(n), "random": lambda: _data.random_bytes(n),
+            "p1": lambda: _data.periodic(n, 1), "p2": lambda: _data.periodic(n, 2), "p3": lambda: _data.periodic(n, 3),
+            "p5": lambda: _data.periodic(n, 5)}[maker]()
+    _roundtrip(emu, oracle, data, 1, band=0.03)
+
+
+@pytest.mark.parametrize("tile,rounds", [(4096, 1), (4096, 4), (8192, 3), (65536, 8)])
+def test_tile_and_round_settings(emu, oracle, tile, rounds):
+    """any schedule yields a valid stream (the repairs see to that); more rounds / finer tiles only make it smaller"""
+    _roundtrip(emu, oracle, _data.mixed(50_000, seed=3), 1, tile=tile, rounds=rounds)
+
+
+def test_enwik_like_text_is_within_the_band(emu, oracle):
+    import corpus
+
+    data = corpus.enwik_like(1_500_000)
+    out, st = _roundtrip(emu, oracle, data, 1, band=0.005)
+    assert st[2] < st[3] // 100  # repairs are a small fraction of the items
+
+
+def test_plan_encoder_accepts_what_it_wrote(oracle):
+    """the oracle's plan-driven encoder on the oracle's own parse reproduces the oracle's stream (checker of the checker)"""
+    import ctypes
+
+    data = _data.mixed(80_000, seed=5)
+    ref, tr = oracle.encode(data, 1, trace_cap=80_000)
+    # the oracle's trace carries reduced offsets, not source positions: rebuild sources by replaying the rings
+    heads = {}
+    rings = {}
+    plan = (oracle.PlanItem * len(tr))()
+    P = oracle.P
+    for i, it in enumerate(tr):
+        pos = it.pos - P
+        ctx = it.ctx & 0xff
+        ring = rings.setdefault(ctx, [])
+        plan[i].pos = pos
+        if it.match_len:
+            plan[i].type = 2
+            plan[i].len = it.match_len
+            plan[i].src = ring[len(ring) - 1 - it.reduced_offset]
+        else:
+            plan[i].type = 0 if it.symbol == 388 else 1
+        ring.append(pos)
+    assert oracle.encode_plan(data, (plan, len(tr))) == ref

@@ -1,0 +1,120 @@
+"""GPU tier of the FAST parse mode (orz_amd/csrc/orz_fast.h) through the C ABI.  Parity for this mode is
+BASELINE.json's: the stream decodes bit-exactly with the reference decoder (the oracle's restatement of
+LZDecoder, /root/reference/src/lz.rs:366-478) and its size stays within +-0.5 % of the reference encoder's
+(the oracle's) at the same level -- measured on the text workload; the small and degenerate inputs must
+round-trip and stay within a looser band, since a handful of items moves their size by more than that."""
+import os
+import sys
+
+import pytest
+
+import _data
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+SIZE_BAND = 0.005  # north_star: +-0.5 % of the reference at the same -l level
+
+
+@pytest.fixture(scope="module")
+def fast_encoders():
+    import orz_amd
+
+    cache = {}
+
+    def get(level):
+        if level not in cache:
+            cache[level] = orz_amd.StreamEncoder(device=0, level=level, mode="fast")
+        return cache[level]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def _check(enc, oracle, data, level, band):
+    out = enc.encode(data)
+    back, used = oracle.decode(out)
+    assert used == len(out)
+    assert back == data
+    ref = oracle.encode(data, level)
+    if band is not None and len(ref) > 64:
+        assert abs(len(out) - len(ref)) <= band * len(ref) + 64, (len(out), len(ref))
+    return len(out), len(ref)
+
+
+def test_default_mode_is_fast():
+    import orz_amd
+
+    enc = orz_amd.StreamEncoder(device=0, level=1)
+    try:
+        assert enc.config()["mode"] == 1
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("name", sorted(_data.SMALL_CASES))
+def test_small_cases_round_trip(fast_encoders, oracle, name):
+    _check(fast_encoders(1), oracle, _data.SMALL_CASES[name], 1, None)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("shape", ["text", "mixed", "zeros", "random", "p1", "p3"])
+def test_data_shapes_round_trip_and_size(fast_encoders, oracle, shape, level):
+    n = 600_000
+    data = {"text": lambda: _data.text(n, seed=5), "mixed": lambda: _data.mixed(n, seed=7), "zeros": lambda: _data.zeros_noise(n),
+            "random": lambda: _data.random_bytes(n), "p1": lambda: _data.periodic(n // 4, 1), "p3": lambda: _data.periodic(n // 4, 3)}[shape]()
+    # synthetic shapes: a loose band (they are dominated by a few thousand items); the text workload below holds +-0.5 %
+    _check(fast_encoders(level), oracle, data, level, 0.03)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_text_workload_size_band(fast_encoders, oracle, level):
+    """BASELINE configs[1]-shaped input (prose-like text, several MB): size within +-0.5 % of the reference's"""
+    import corpus
+
+    data = corpus.enwik_like(24_000_000)[:20_000_000 if level == 1 else 6_000_000]
+    out_n, ref_n = _check(fast_encoders(level), oracle, data, level, SIZE_BAND)
+    print("level %d: fast %d reference %d (%+.3f %%)" % (level, out_n, ref_n, 100.0 * (out_n - ref_n) / ref_n))
+
+
+def test_two_blocks_and_short_tail(fast_encoders, oracle):
+    """the window slide: history item starts, carried ring ordinals / words[] / len_min across blocks"""
+    import corpus
+
+    data = corpus.enwik_like(40_000_000)[: (1 << 24) + (1 << 24) + 123_457]
+    _check(fast_encoders(1), oracle, data, 1, SIZE_BAND)
+
+
+def test_fast_parse_is_a_valid_plan(fast_encoders, oracle):
+    """the post stage is shared with the exact mode: the oracle's plan-driven encoder, fed the GPU's parse
+    (positions, types, lengths, sources), must write the very same bytes"""
+    import numpy as np
+
+    enc = fast_encoders(1)
+    data = _data.mixed(900_000, seed=21)
+    enc.set_item_trace(True)
+    try:
+        out = enc.encode(data)
+        tr = enc.item_trace()
+    finally:
+        enc.set_item_trace(False)
+    plan = oracle.plan_from_trace(tr, len(data))
+    assert oracle.encode_plan(data, plan) == out
+
+
+def test_tile_and_round_settings_keep_validity(oracle):
+    import orz_amd
+
+    data = _data.mixed(700_000, seed=9)
+    for tile, rounds in [(4096, 2), (8192, 5), (65536, 1), (131072, 10)]:
+        enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast", tile_bytes=tile, rounds=rounds)
+        try:
+            cfg = enc.config()
+            assert cfg["fast_tile_bytes"] == tile and cfg["fast_rounds"] == rounds
+            out = enc.encode(data)
+            assert oracle.decode(out)[0] == data
+        finally:
+            enc.close()

@@ -10,6 +10,12 @@ import pytest
 import _data
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _exact_mode(monkeypatch):
+    """this module is the byte-identical tier: every encoder built here runs the reference-identical parse"""
+    monkeypatch.setenv("ORZ_MODE", "exact")
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

@@ -77,6 +77,37 @@ def text_corpus(nbytes):
     return data
 
 
+def enwik_like(nbytes):
+    """first `nbytes` of the enwik8-shaped workload (tools/enwik_like.py: committed word-level model + seeded
+    counter-based sampling, so the bytes are the same on every box).  The canonical 100,000,000-byte text is cached
+    under CACHE and its SHA-256 is checked against the value pinned in enwik_like.MANIFEST."""
+    import enwik_like
+
+    if nbytes <= 4_000_000:
+        return enwik_like.generate(nbytes)
+    full = 100_000_000
+    if nbytes > full:  # larger inputs: whole copies + a prefix (the repeat distance is far beyond the 32 MiB window)
+        base = enwik_like(full)
+        return (base * (nbytes // full + 1))[:nbytes]
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "E%d.bin" % full)
+    data = None
+    if os.path.exists(path) and os.path.getsize(path) == full:
+        with open(path, "rb") as f:
+            data = f.read()
+        if sha256(data) != enwik_like.MANIFEST[full]:
+            data = None
+    if data is None:
+        data = enwik_like.generate(full)
+        if sha256(data) != enwik_like.MANIFEST[full]:
+            raise RuntimeError("enwik-like workload does not hash to the pinned value: %s" % sha256(data))
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, path)
+    return data[:nbytes]
+
+
 def _splitmix64(first, n, seed):
     """splitmix64 outputs number first+1 .. first+n of the stream seeded with `seed`"""
     x = (np.arange(first + 1, first + n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)

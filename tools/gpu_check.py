@@ -35,7 +35,7 @@ def main():
     wins = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8192]
     level = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     text = corpus.text_corpus(max(max(sizes), 1 << 20))
-    enc = orz_amd.StreamEncoder(device=0, level=level)
+    enc = orz_amd.StreamEncoder(device=0, level=level, mode="exact")
     for n in sizes:
         data = text[:n]
         t0 = time.time()

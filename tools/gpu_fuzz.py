@@ -18,7 +18,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    encs = {lv: orz_amd.StreamEncoder(0, lv) for lv in (0, 1, 2)}
+    encs = {lv: orz_amd.StreamEncoder(0, lv, mode="exact") for lv in (0, 1, 2)}
     makers = [("text", _data.text), ("mixed", _data.mixed), ("zeros", lambda n, seed=0: _data.zeros_noise(n)),
               ("random", _data.random_bytes), ("p1", lambda n, seed=0: _data.periodic(n, 1)),
               ("p4", lambda n, seed=0: _data.periodic(n, 4)), ("p7", lambda n, seed=0: _data.periodic(n, 7))]

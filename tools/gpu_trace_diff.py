@@ -14,7 +14,7 @@ import orz_amd  # noqa: E402
 n = int(sys.argv[1]); level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 data = corpus.text_corpus(max(n, 1 << 20))[:n]
 ref, items = _oracle.encode(data, level, trace_cap=n + 16)
-enc = orz_amd.StreamEncoder(0, level)
+enc = orz_amd.StreamEncoder(0, level, mode="exact")
 enc.set_item_trace(True)
 out = enc.encode(data)
 tr = enc.item_trace()

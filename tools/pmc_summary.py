@@ -27,8 +27,15 @@ if __name__ == "__main__":
         rows.append({"kernel": name[:100], "dispatches": int(max(nf, nw)),
                      "fetch_KiB_per_dispatch": round(sf / nf, 1) if nf else None,
                      "write_KiB_per_dispatch": round(sw / nw, 1) if nw else None})
-    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes; scattered loads count 128 B per line, see pmc_calibrate.py)", "kernels": rows[:24]}
+    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes; scattered loads count 128 B per line, see pmc_calibrate.py)", "kernels": rows[:32]}
+    # HBM bytes per launch under the names bench.py uses for its roofline rows
+    short = {"FastEval": "orz_thread_kernel<FastEval>", "ParseWave": "orz_wave_kernel<ParseWave>", "orz_symrank_kernel": "orz_symrank_kernel",
+             "FastRowsWave": "orz_wave_kernel<FastRowsWave>", "PathUpWave": "orz_wave_kernel<PathUpWave>"}
+    res["by_name"] = {}
     for r in rows:
+        for key, name in short.items():
+            if key in r["kernel"]:
+                res["by_name"][name] = int(((r["fetch_KiB_per_dispatch"] or 0) + (r["write_KiB_per_dispatch"] or 0)) * 1024)
         if "ParseWave" in r["kernel"]:
             res["parse_wave_hbm_bytes_per_launch"] = int(((r["fetch_KiB_per_dispatch"] or 0) + (r["write_KiB_per_dispatch"] or 0)) * 1024)
     json.dump(res, open(out, "w"), indent=1)
