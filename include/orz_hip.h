@@ -151,6 +151,11 @@ long orz_stream_get_item_trace(orz_stream*, orz_item* out, size_t cap);
  * each piece (orz_decode_members_mem / `orz decode --members` loop over them). */
 typedef struct orz_members orz_members;
 orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs);
+/* the same across several GPUs of the node: `jobs_per_device` stream encoders on each of the listed
+ * devices, one host thread each; members go to whichever worker is free, the finished streams are collected in
+ * host memory in member order (the only "gather" the job needs: the output lives on the host).  Input must be host
+ * memory unless all workers sit on one device. */
+orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_lzcfg* cfg, int jobs_per_device);
 void orz_members_free(orz_members*);
 int orz_members_encode(orz_members*, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
                        size_t* dst_len, size_t* n_members_out);

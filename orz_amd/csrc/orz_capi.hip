@@ -184,9 +184,14 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
         out.reserve(n / 3 + 4096);
         orz::HipBackend& be = *s->be;
         be.set_timing(stats != nullptr);
-        hipEvent_t e0, e1;
-        ORZ_HIP_CHECK(hipEventCreate(&e0));
-        ORZ_HIP_CHECK(hipEventCreate(&e1));
+        struct Events {  // destroyed on every path out of this function
+            hipEvent_t a = nullptr, b = nullptr;
+            ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+        } ev;
+        ORZ_HIP_CHECK(hipSetDevice(be.device()));
+        ORZ_HIP_CHECK(hipEventCreate(&ev.a));
+        ORZ_HIP_CHECK(hipEventCreate(&ev.b));
+        hipEvent_t e0 = ev.a, e1 = ev.b;
         ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
         s->trace.clear();
         orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out);
@@ -194,8 +199,6 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
         be.sync();
         float total = 0;
         ORZ_HIP_CHECK(hipEventElapsedTime(&total, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         if (stats) {
             const orz::EncodeStats& st = s->enc->stats;
             stats->blocks = st.blocks; stats->sweeps = st.sweeps; stats->seg_evals = st.seg_evals;
@@ -241,20 +244,26 @@ long orz_stream_get_item_trace(orz_stream* s, orz_item* out, size_t cap) {
 struct orz_members {
     std::vector<orz_stream*> workers;
 };
-orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs) {
-    if (!cfg_ok(cfg) || jobs < 1 || jobs > 64) { fail(ORZ_EINVAL, "bad argument"); return nullptr; }
-    std::unique_ptr<orz_members> m(new orz_members);
-    for (int i = 0; i < jobs; i++) {
-        orz_stream* s = orz_stream_new(device, cfg);
-        if (!s) { for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
-        if (jobs > 1) {  // several streams share the GPU: a smaller speculative window each (same bytes out)
-            s->win = env_u("ORZ_MEMBER_WIN", std::max(256u, window_for(*s->be, *cfg, 0) / (unsigned)jobs));
-            try { s->rebuild(); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); for (orz_stream* w : m->workers) orz_stream_free(w); return nullptr; }
-        }
-        m->workers.push_back(s);
+orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_lzcfg* cfg, int jobs_per_device) {
+    if (!cfg_ok(cfg) || !devices || n_devices < 1 || n_devices > 64 || jobs_per_device < 1 || jobs_per_device > 64) {
+        fail(ORZ_EINVAL, "bad argument");
+        return nullptr;
     }
+    std::unique_ptr<orz_members> m(new orz_members);
+    auto drop = [&]() { for (orz_stream* w : m->workers) orz_stream_free(w); m->workers.clear(); };
+    for (int d = 0; d < n_devices; d++)
+        for (int i = 0; i < jobs_per_device; i++) {
+            orz_stream* s = orz_stream_new(devices[d], cfg);
+            if (!s) { drop(); return nullptr; }
+            if (jobs_per_device > 1 && !s->fast) {  // exact mode: several streams share the GPU: a smaller speculative window each
+                s->win = env_u("ORZ_MEMBER_WIN", std::max(256u, window_for(*s->be, *cfg, 0) / (unsigned)jobs_per_device));
+                try { s->rebuild(); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); drop(); return nullptr; }
+            }
+            m->workers.push_back(s);
+        }
     return m.release();
 }
+orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs) { return orz_members_new_multi(&device, 1, cfg, jobs); }
 void orz_members_free(orz_members* m) {
     if (!m) return;
     for (orz_stream* w : m->workers) orz_stream_free(w);
@@ -263,40 +272,52 @@ void orz_members_free(orz_members* m) {
 int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
                        size_t* dst_len, size_t* n_members_out) {
     if (!m || !dst || !dst_len || (!src && n) || member_bytes == 0) return fail(ORZ_EINVAL, "bad argument");
-    const size_t nm = n == 0 ? 1 : (n + member_bytes - 1) / member_bytes;
-    std::vector<std::vector<uint8_t>> outs(nm);
-    std::atomic<size_t> next{0};
-    std::atomic<int> rc{ORZ_OK};
-    std::string err;
-    auto work = [&](orz_stream* s) {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= nm || rc.load() != ORZ_OK) return;
-            const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
+    if (src_on_device && m->workers.size() > 1) {
+        const int d0 = m->workers[0]->be->device();
+        for (orz_stream* w : m->workers)
+            if (w->be->device() != d0) return fail(ORZ_EINVAL, "device-resident input needs all workers on that device");
+    }
+    try {
+        const size_t nm = n == 0 ? 1 : (n + member_bytes - 1) / member_bytes;
+        std::vector<std::vector<uint8_t>> outs(nm);
+        std::atomic<size_t> next{0};
+        std::atomic<int> rc{ORZ_OK};
+        std::string err;
+        auto work = [&](orz_stream* s) {
             try {
-                orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
+                ORZ_HIP_CHECK(hipSetDevice(s->be->device()));  // every host thread talks to its worker's device
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= nm || rc.load() != ORZ_OK) return;
+                    const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
+                    orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
+                }
             } catch (const std::exception& e) {
                 int expect = ORZ_OK;
                 if (rc.compare_exchange_strong(expect, ORZ_ENODEV)) err = e.what();
-                return;
             }
-        }
-    };
-    std::vector<std::thread> th;
-    for (size_t i = 1; i < m->workers.size(); i++) th.emplace_back(work, m->workers[i]);
-    work(m->workers[0]);
-    for (auto& t : th) t.join();
-    if (rc.load() != ORZ_OK) return fail(rc.load(), err);
-    size_t total = 0;
-    for (auto& o : outs) total += o.size();
-    uint8_t* p = (uint8_t*)std::malloc(total ? total : 1);
-    if (!p) return fail(ORZ_ENOMEM, "malloc failed");
-    size_t at = 0;
-    for (auto& o : outs) { std::memcpy(p + at, o.data(), o.size()); at += o.size(); }
-    *dst = p;
-    *dst_len = total;
-    if (n_members_out) *n_members_out = nm;
-    return ORZ_OK;
+        };
+        struct Joiner {  // joins whatever was started, also when starting a later thread throws
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+        } joiner;
+        for (size_t i = 1; i < m->workers.size(); i++) joiner.th.emplace_back(work, m->workers[i]);
+        work(m->workers[0]);
+        for (auto& t : joiner.th) t.join();
+        if (rc.load() != ORZ_OK) return fail(rc.load(), err);
+        size_t total = 0;
+        for (auto& o : outs) total += o.size();
+        uint8_t* p = (uint8_t*)std::malloc(total ? total : 1);
+        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
+        size_t at = 0;
+        for (auto& o : outs) { std::memcpy(p + at, o.data(), o.size()); at += o.size(); }
+        *dst = p;
+        *dst_len = total;
+        if (n_members_out) *n_members_out = nm;
+        return ORZ_OK;
+    } catch (const std::exception& e) {  // (allocation / thread start failures never cross the C boundary)
+        return fail(ORZ_ENOMEM, e.what());
+    }
 }
 int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* n_members_out) {
     if ((!src && n) || !dst || !dst_len) return fail(ORZ_EINVAL, "bad argument");

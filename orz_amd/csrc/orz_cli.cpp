@@ -48,7 +48,8 @@ void progress(void* c, int fin, size_t a, size_t b) {
 int usage() {
     fprintf(stderr,
             "an optimized ROLZ data compressor (MI355X encoder)\n\nUsage: orz <COMMAND>\n\nCommands:\n"
-            "  encode  Encode   [-s|--silent] [-l|--level <0..2>] [--device N] [source] [target]\n"
+            "  encode  Encode   [-s|--silent] [-l|--level <0..2>] [--mode fast|exact] [--backend hip] [--device N]\n"
+            "                   [--member-size BYTES [--jobs J] [--gpus N]] [source] [target]\n"
             "  decode  Decode   [-s|--silent] [source] [target]\n");
     return 2;
 }
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
     const std::string cmd = argv[1];
     if (cmd != "encode" && cmd != "decode") return usage();
     bool silent = false;
-    long level = 2, device = 0, jobs = 4;
+    long level = 2, device = 0, jobs = 4, gpus = 1;
     long long member_size = 0;
     bool all_members = false, gpu_decode = false;
     std::vector<std::string> pos;
@@ -72,6 +73,16 @@ int main(int argc, char** argv) {
         else if (cmd == "encode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }
         else if (cmd == "encode" && a == "--member-size") { if (++i >= argc) return usage(); member_size = strtoll(argv[i], nullptr, 10); }
         else if (cmd == "encode" && a == "--jobs") { if (++i >= argc) return usage(); jobs = strtol(argv[i], nullptr, 10); }
+        else if (cmd == "encode" && a == "--gpus") { if (++i >= argc) return usage(); gpus = strtol(argv[i], nullptr, 10); }
+        else if (cmd == "encode" && (a == "--backend" || a.rfind("--backend=", 0) == 0)) {
+            std::string v = a == "--backend" ? (++i < argc ? argv[i] : "") : a.substr(10);
+            if (v != "hip") { fprintf(stderr, "Error: \"backend %s: this build has the HIP backend only (there is no CPU fallback)\"\n", v.c_str()); return 1; }
+        }
+        else if (cmd == "encode" && (a == "--mode" || a.rfind("--mode=", 0) == 0)) {
+            std::string v = a == "--mode" ? (++i < argc ? argv[i] : "") : a.substr(7);
+            if (v != "fast" && v != "exact") return usage();
+            setenv("ORZ_MODE", v.c_str(), 1);  // (read by the library when an encoder is created)
+        }
         else if (cmd == "decode" && a == "--members") all_members = true;
         else if (cmd == "decode" && a == "--gpu") gpu_decode = true;
         else if (cmd == "decode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }
@@ -91,9 +102,12 @@ int main(int argc, char** argv) {
             return 1;
         }
         if (member_size > 0) {
-            orz_members* m = orz_members_new((int)device, &cfg, (int)jobs);
+            if (gpus < 1 || gpus > 64) return usage();
+            std::vector<int> devs;
+            for (long g = 0; g < gpus; g++) devs.push_back((int)(device + g));  // --gpus N: devices device .. device+N-1
+            orz_members* m = orz_members_new_multi(devs.data(), (int)devs.size(), &cfg, (int)jobs);
             if (!m) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
-            std::vector<uint8_t> buf((size_t)member_size * (size_t)jobs);
+            std::vector<uint8_t> buf((size_t)member_size * (size_t)jobs * (size_t)gpus);
             size_t in_total = 0, out_total = 0;
             bool any = false;
             rc = ORZ_OK;

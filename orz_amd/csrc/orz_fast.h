@@ -49,6 +49,7 @@ struct FastArgs {
     const uint64_t* stext;      // [nent][2] 16 leading bytes of each slot's position
     const uint32_t* runstart;   // first slot of each (ctx, hash) run
     uint32_t far;               // slots searched beyond the tabulated K when a long run shows too few item starts
+    uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
@@ -223,6 +224,10 @@ ORZ_D uint32_t far_lcp(const FastArgs& a, uint32_t p, uint64_t a0, uint64_t a1, 
 struct FastEval {
     FastArgs a;
     uint32_t lo, hi;  // window offsets [lo, hi)
+    // The far search (beyond the K tabulated predecessors) is the expensive part and its answer moves little from round
+    // to round: it runs in a tile's first round and again in its last one (when every earlier tile is final); the rounds
+    // in between merge the remembered answer.  far_lo / far_hi: window offsets from which / up to which it runs now.
+    uint32_t far_hi_from, far_lo_until;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
@@ -266,39 +271,50 @@ struct FastEval {
             }
         }
         if (!stop && seen < a.depth && a.rlen[i] > K && a.far) {
-            // a long run whose tabulated K predecessors hold too few item starts (runs of "interior" 4-grams, zero runs):
-            // walk the bitmap further back and take the prefixes from the text records
-            const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
-            const uint32_t top = j - K;  // slots [lo2, top) are searched, newest first
-            const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-            const uint64_t a0 = ldu64(win + p), a1 = ldu64(win + p + 8);
-            for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && seen < a.depth; wbase -= 64) {
-                uint64_t mask = bits_at(a.vbits, wbase);
-                if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
-                while (mask && seen < a.depth) {
-                    const uint32_t t = 63 - (uint32_t)clz64(mask);
-                    mask &= ~(1ull << t);
-                    const uint32_t sl = (uint32_t)(wbase + t);
-                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
-                    if (l > best || (seen < a.lazy1 && l > m1) || (seen < a.lazy2 && l > m2)) {
-                        const uint32_t q = a.epos[sl];
-                        uint32_t ro_hi, ro_mid;
-                        if (q >= kPre) {
-                            const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
-                            ro_hi = op_hi - oq;
-                            ro_mid = op_lo - oq;
-                        } else {
-                            ro_hi = op_hi - 1 - a.ORD[q];
-                            ro_mid = op_lo - 1 - a.ORD[q];
+            if (p < far_lo_until || p >= far_hi_from) {
+                // a long run whose tabulated K predecessors hold too few item starts (runs of "interior" 4-grams, zero runs):
+                // walk the bitmap further back and take the prefixes from the text records
+                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
+                const uint32_t top = j - K;  // slots [lo2, top) are searched, newest first
+                const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+                const uint64_t a0 = ldu64(win + p), a1 = ldu64(win + p + 8);
+                uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
+                for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && seen < a.depth; wbase -= 64) {
+                    uint64_t mask = bits_at(a.vbits, wbase);
+                    if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
+                    while (mask && seen < a.depth) {
+                        const uint32_t t = 63 - (uint32_t)clz64(mask);
+                        mask &= ~(1ull << t);
+                        const uint32_t sl = (uint32_t)(wbase + t);
+                        const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                        if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
+                            const uint32_t q = a.epos[sl];
+                            uint32_t ro_hi, ro_mid;
+                            if (q >= kPre) {
+                                const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
+                                ro_hi = op_hi - oq;
+                                ro_mid = op_lo - oq;
+                            } else {
+                                ro_hi = op_hi - 1 - a.ORD[q];
+                                ro_mid = op_lo - 1 - a.ORD[q];
+                            }
+                            if (ro_hi > kRing - 1) { stop = true; break; }
+                            if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
+                            if (seen < a.lazy1 && l > fm1) fm1 = l;
+                            if (seen < a.lazy2 && l > fm2) fm2 = l;
                         }
-                        if (ro_hi > kRing - 1) { stop = true; break; }
-                        if (l > best) { best = l; bsrc = q; b510 = (int32_t)ro_mid < 510; }
-                        if (seen < a.lazy1 && l > m1) m1 = l;
-                        if (seen < a.lazy2 && l > m2) m2 = l;
+                        seen++;
+                        if (l == kMaxLen) { stop = true; break; }
                     }
-                    seen++;
-                    if (l == kMaxLen) { stop = true; break; }
                 }
+                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+                a.farsrc[i] = fsrc;
+            }
+            const uint32_t fv = a.farv[i];
+            if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
+                if ((fv & 0xff) > best) { best = fv & 0xff; bsrc = a.farsrc[i]; b510 = (fv >> 24) & 1; }
+                if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
+                if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
             }
         }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)

@@ -224,7 +224,7 @@ class StreamEncoder {
             if (frounds_ < 1 || frounds_ > 64) throw std::runtime_error("fast rounds must be in [1, 64]");
             // run predecessors tabulated per position: item starts are about a quarter of a run's positions on text and far
             // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
-            fK_ = 128;  // (one 128-byte line per row; deeper runs are searched through the bitmap + text records)
+            fK_ = 64;  // (deeper runs are searched through the bitmap + the text records: FastEval's far search)
             if (const char* k = getenv("ORZ_FAST_K")) fK_ = (uint32_t)atoi(k);  // experiments
             if (fK_ < 64 || fK_ > 192 || fK_ % 64) throw std::runtime_error("ORZ_FAST_K must be 64, 128 or 192");
         }
@@ -296,6 +296,8 @@ class StreamEncoder {
             flaste_ = be_.template alloc<uint32_t>(nn);
             fnchg_ = be_.template alloc<uint32_t>(4);
             fcstart_ = be_.template alloc<uint32_t>(260);
+            ffarv_ = be_.template alloc<uint32_t>(nn);
+            ffarsrc_ = be_.template alloc<uint32_t>(nn);
         }
         f32_ = be_.template alloc<uint32_t>(kWLen);
         sc32_ = be_.template alloc<uint32_t>(kWLen);
@@ -343,7 +345,7 @@ class StreamEncoder {
                         hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
                         gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
                         hdrbits_, tot_, outoff_, out_, frows_, frlen_, fkw_, fev_, fbs_, fty_, fnl_, fpt_, fmf_, fef_, fx0_, fx1_, fx2_,
-                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_, fstext_};
+                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_, fstext_, ffarv_, ffarsrc_};
         for (void* p : ptrs) if (p) be_.free(p);
     }
     StreamEncoder(const StreamEncoder&) = delete;
@@ -581,7 +583,7 @@ class StreamEncoder {
         a.win = win; a.len = len; a.n = n; a.K = K; a.depth = (uint32_t)cfg_.depth; a.lazy1 = (uint32_t)cfg_.lazy1;
         a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_;
         a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
-        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_;
+        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
         a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 4096; a.vbits = vbits_; a.kbits = kbits_; a.ev = fev_; a.bs = fbs_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mf = fmf_; a.ef = fef_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = fnchg_;
@@ -600,6 +602,7 @@ class StreamEncoder {
             be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
             const size_t nn = (size_t)n + 264;
             be_.memset(fev_, 0, ((size_t)n + 8) * 4);
+            be_.memset(ffarv_, 0, ((size_t)n + 8) * 4);
             be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
             be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
             be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
@@ -615,7 +618,10 @@ class StreamEncoder {
                 const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
                 const uint32_t hi2 = std::min(len, hi + 2);
                 be_.timed_begin();
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2});
+                // far searches: the oldest active tile (its last round) and a tile in its first round (+ the halo behind it)
+                const uint32_t far_lo_until = std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_lo + 1) * T);
+                const uint32_t far_hi_from = step <= ntile ? kPre + t_hi * T : hi;
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, far_hi_from, far_lo_until});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -838,7 +844,7 @@ class StreamEncoder {
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
     uint16_t* fkw_ = nullptr;
     uint32_t *fev_ = nullptr, *fbs_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
-             *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr;
+             *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;

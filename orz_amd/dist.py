@@ -21,7 +21,8 @@ def members_of_rank(n_members, rank, world):
 
 def gather_members(local, n_members, rank, world, device=None):
     """local: {member index: bytes} encoded on this rank.  Returns the list of all members in member
-    order on rank 0 (None elsewhere).  One size all-gather + one padded byte gather."""
+    order on rank 0 (None elsewhere).  One all-gather of the sizes, then every rank sends exactly its bytes to
+    rank 0 (point-to-point: each peer has its own xGMI link to the root, nothing is padded)."""
     mine = members_of_rank(n_members, rank, world)
     assert sorted(local) == mine
     dev = device if device is not None else torch.device("cpu")
@@ -31,25 +32,28 @@ def gather_members(local, n_members, rank, world, device=None):
         sizes[i] = len(local[m])
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    cap = int(max(int(s.sum()) for s in all_sizes))
-    payload = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
     blob = b"".join(local[m] for m in mine)
-    if blob:
-        payload[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    if rank == 0:
-        bufs = [torch.zeros_like(payload) for _ in range(world)]
-        dist.gather(payload, bufs, dst=0)
-        out = [None] * n_members
-        for r in range(world):
-            raw = bufs[r].cpu().numpy().tobytes()
-            at = 0
-            for i, m in enumerate(members_of_rank(n_members, r, world)):
-                ln = int(all_sizes[r][i])
-                out[m] = raw[at:at + ln]
-                at += ln
-        return out
-    dist.gather(payload, None, dst=0)
-    return None
+    if rank != 0:
+        if blob:
+            dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst=0)
+        return None
+    out = [None] * n_members
+    for r in range(world):
+        total = int(all_sizes[r].sum())
+        if r == 0:
+            raw = blob
+        elif total:
+            buf = torch.empty(total, dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=r)
+            raw = buf.cpu().numpy().tobytes()
+        else:
+            raw = b""
+        at = 0
+        for i, m in enumerate(members_of_rank(n_members, r, world)):
+            ln = int(all_sizes[r][i])
+            out[m] = raw[at:at + ln]
+            at += ln
+    return out
 
 
 def split_members(container):

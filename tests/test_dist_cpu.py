@@ -42,6 +42,49 @@ def test_member_gather_world2():
     assert res[-1] == sum(1 + (m * 7) % 250 for m in range(n_members))
 
 
+def _worker_real(rank, world, port, n_members, q):
+    """every rank encodes ITS members with the oracle (standing in for its GPU), then the real gather"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch.distributed as dist
+
+    import _data
+    import _oracle
+    from orz_amd import dist as od
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = _data.mixed(300_000, seed=4)
+        size = (len(data) + n_members - 1) // n_members
+        local = {m: _oracle.encode(data[m * size:(m + 1) * size], 1) for m in od.members_of_rank(n_members, rank, world)}
+        got = od.gather_members(local, n_members, rank, world)
+        if rank == 0:
+            container = b"".join(got)
+            pieces = od.split_members(container)
+            back = b"".join(_oracle.decode(p)[0] for p in pieces)
+            q.put((len(pieces), back == data))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_streams_gather_and_decode_world2():
+    """world-2 job over gloo: members encoded on their ranks, gathered at exact sizes, container cut at the EOF chunks,
+    every member decoded by the oracle decoder: the input comes back"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == (5, True)
+
+
 def test_split_members_roundtrip(oracle):
     from orz_amd import dist as od
 

@@ -80,11 +80,11 @@ def text_corpus(nbytes):
 def enwik_like(nbytes):
     """first `nbytes` of the enwik8-shaped workload (tools/enwik_like.py: committed word-level model + seeded
     counter-based sampling, so the bytes are the same on every box).  The canonical 100,000,000-byte text is cached
-    under CACHE and its SHA-256 is checked against the value pinned in enwik_like.MANIFEST."""
-    import enwik_like
+    under CACHE and its SHA-256 is checked against the value pinned in _gen.MANIFEST."""
+    import enwik_like as _gen
 
     if nbytes <= 4_000_000:
-        return enwik_like.generate(nbytes)
+        return _gen.generate(nbytes)
     full = 100_000_000
     if nbytes > full:  # larger inputs: whole copies + a prefix (the repeat distance is far beyond the 32 MiB window)
         base = enwik_like(full)
@@ -95,11 +95,11 @@ def enwik_like(nbytes):
     if os.path.exists(path) and os.path.getsize(path) == full:
         with open(path, "rb") as f:
             data = f.read()
-        if sha256(data) != enwik_like.MANIFEST[full]:
+        if sha256(data) != _gen.MANIFEST[full]:
             data = None
     if data is None:
-        data = enwik_like.generate(full)
-        if sha256(data) != enwik_like.MANIFEST[full]:
+        data = _gen.generate(full)
+        if sha256(data) != _gen.MANIFEST[full]:
             raise RuntimeError("enwik-like workload does not hash to the pinned value: %s" % sha256(data))
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "wb") as f:
