@@ -115,6 +115,10 @@ int orz_stream_get_config(orz_stream*, orz_stream_config* out);
  * [0] the parse's per-position kernel (exact: ParseWave, fast: FastEval), [1] symbol ranking, [2] candidate table
  * build (fast mode), [3] path maps (fast mode).  What bench.py's roofline leg is computed from. */
 int orz_stream_get_kernel_times(orz_stream*, double* ms4, uint64_t* launches4);
+/* Profile mode: also bracket the kernels inside the fast parse's round loop ([0] and [3] above).  That loop normally
+ * runs as one hipGraph replay per block (its launch sequence is the same for every full block); brackets need
+ * individual launches, so a profiled encode is slower than a normal one -- use it for the roofline leg only. */
+int orz_stream_set_profile(orz_stream*, int on);
 /* tuning: bytes per speculative segment and segments per sweep window (0 = keep) */
 int orz_stream_set_tuning(orz_stream*, unsigned seg_bytes, unsigned window_segs);
 /* Encode `n` bytes at `src` (host memory, or device memory when src_on_device != 0) into a

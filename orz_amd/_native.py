@@ -115,6 +115,7 @@ SYMBOLS = [
     ("orz_stream_set_tuning", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     ("orz_stream_set_mode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint]),
     ("orz_stream_get_config", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StreamConfig)]),
+    ("orz_stream_set_profile", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("orz_stream_get_kernel_times", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
     (
         "orz_stream_encode",

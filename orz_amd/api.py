@@ -54,6 +54,10 @@ class StreamEncoder:
         _check(self._lib.orz_stream_get_config(self._h, ctypes.byref(c)), "orz_stream_get_config")
         return c.as_dict()
 
+    def set_profile(self, on=True):
+        """bracket the kernels inside the round loop too (no hipGraph replay then): for the roofline leg only"""
+        _check(self._lib.orz_stream_set_profile(self._h, 1 if on else 0), "orz_stream_set_profile")
+
     def kernel_times(self):
         """[(ms, launches)] x 4 of the last encode(stats=True): parse kernel, symbol ranking, candidate tables, path maps"""
         ms = (ctypes.c_double * 4)()

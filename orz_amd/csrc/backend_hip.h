@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <map>
 #include <rocprim/rocprim.hpp>
 #include <stdexcept>
 #include <string>
@@ -97,6 +98,16 @@ __device__ __forceinline__ int orz_writelane(int old, uint32_t sval, uint32_t sl
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sval), "s"(slane) : "m0");
     return old;
 }
+__device__ __forceinline__ uint32_t orz_ff1(uint64_t m) {  // index of the lowest set bit, 0xffffffff for 0 (s_ff1_i32_b64)
+    uint32_t r;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t orz_sub_sat(uint32_t a, uint32_t b) {  // max(a - b, 0) on the scalar unit
+    uint32_t r;
+    asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
 __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank,
                                                          const uint32_t* rstart) {
     __shared__ uint16_t val[kSyms + 3];
@@ -107,11 +118,22 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     uint16_t* state = srstate + (size_t)c * kSrWords;
     for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = state[i]; idx[i] = state[kSyms + i]; }
     __syncthreads();
-    int vreg = val[lane];
+    int v0 = val[lane], v1 = val[64 + lane];  // ranks 0..63 and 64..127 live in two registers
     uint32_t cnt = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms] | ((uint32_t)state[2 * kSyms + 1] << 16)));
     uint32_t sum = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms + 2] | ((uint32_t)state[2 * kSyms + 3] << 16)));
     // reciprocals of the steady-state counts 327 + lane: floor(n / d) == mulhi(n, floor(2^32 / d) + 1) for n < 2^17
     const int mreg = (int)(0xffffffffu / (327 + lane) + 1);
+    // value of rank r / store x at rank r, wherever that rank lives
+    auto get = [&](uint32_t r) -> uint32_t {
+        if (r < 64) return (uint32_t)__builtin_amdgcn_readlane(v0, (int)r);
+        if (r < 128) return (uint32_t)__builtin_amdgcn_readlane(v1, (int)(r - 64));
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)val[r]);
+    };
+    auto put = [&](uint32_t r, uint32_t x) {
+        if (r < 64) v0 = orz_writelane(v0, x, r);
+        else if (r < 128) v1 = orz_writelane(v1, x, r - 64);
+        else { val[r] = (uint16_t)x; idx[x] = (uint16_t)r; }
+    };
     for (uint32_t j0 = a; j0 < e; j0 += 64) {
         const int items = j0 + lane < e ? (int)gsym[j0 + lane] : 0;
         const uint32_t nthis = e - j0 < 64 ? e - j0 : 64;
@@ -119,14 +141,18 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         for (uint32_t k = 0; k < nthis; k++) {
             const uint32_t g = (uint32_t)__builtin_amdgcn_readlane(items, (int)k);
             const uint32_t v = g & 0xffff, vun = g >> 16;
-            const uint64_t m = __ballot(vreg == (int)v), mu = __ballot(vreg == (int)vun);
-            uint32_t i = m ? (uint32_t)__builtin_ctzll(m) : 64;
-            uint32_t iu = mu ? (uint32_t)__builtin_ctzll(mu) : 65;  // outside the register: certainly behind a register rank
-            if (__builtin_expect(i >= 64, 0)) {
-                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
-                if (!mu) iu = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
+            uint32_t i = orz_ff1(__ballot(v0 == (int)v));
+            uint32_t iu = orz_ff1(__ballot(v0 == (int)vun));  // 0xffffffff = not among the first 64: behind any of those
+            const bool fast = (int32_t)i >= 0;
+            if (__builtin_expect(!fast, 0)) {
+                const uint32_t i1 = orz_ff1(__ballot(v1 == (int)v));
+                i = (int32_t)i1 >= 0 ? 64 + i1 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
+                if ((int32_t)iu < 0) {
+                    const uint32_t u1 = orz_ff1(__ballot(v1 == (int)vun));
+                    iu = (int32_t)u1 >= 0 ? 64 + u1 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
+                }
             }
-            if (cnt > kSyms) {  // src/symrank.rs:63-66
+            if (__builtin_expect(cnt > kSyms, 0)) {  // src/symrank.rs:63-66
                 cnt = cnt * 9 / 10;
                 sum = sum * 9 / 10;
             }
@@ -135,37 +161,35 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             const uint32_t n16 = sum >> 4;
             uint32_t q;
             if (__builtin_expect(cnt >= 327, 1)) q = __umulhi(n16, (uint32_t)__builtin_amdgcn_readlane(mreg, (int)(cnt - 327)));
-            else q = n16 / cnt;
-            const uint32_t dec = (i >> 4) + (q & 0xffff);
-            const uint32_t hi = i > dec ? i : dec;
-            uint32_t next_i = hi - dec;  // saturating i - dec
-            next_i = next_i > (i >> 1) ? next_i : (i >> 1);
+            else q = (n16 / cnt) & 0xffff;
+            uint32_t next_i = orz_sub_sat(i, (i >> 4) + q);
+            const uint32_t half = i >> 1;
+            next_i = next_i > half ? next_i : half;
             const uint32_t ni1 = next_i + ((i - next_i) >> 1);
             // value[i] <- value[ni1] <- value[next_i] <- v  (for a one-step move ni1 == next_i and this is the swap;
             // for no move all three coincide and nothing changes: one straight line covers src/symrank.rs:75-96)
-            if (__builtin_expect(i < 64, 1)) {  // everything involved sits in the register
-                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(vreg, (int)ni1);
-                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(vreg, (int)next_i);
-                vreg = orz_writelane(vreg, nv1, i);
-                vreg = orz_writelane(vreg, nv2, ni1);
-                vreg = orz_writelane(vreg, v, next_i);
+            if (__builtin_expect(fast, 1)) {  // everything involved sits in the first register
+                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)ni1);
+                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)next_i);
+                v0 = orz_writelane(v0, nv1, i);
+                v0 = orz_writelane(v0, nv2, ni1);
+                v0 = orz_writelane(v0, v, next_i);
             } else if (i != next_i) {
-                const uint32_t nv1 = ni1 < 64 ? (uint32_t)__builtin_amdgcn_readlane(vreg, (int)ni1) : (uint32_t)__builtin_amdgcn_readfirstlane((int)val[ni1]);
-                const uint32_t nv2 = next_i < 64 ? (uint32_t)__builtin_amdgcn_readlane(vreg, (int)next_i) : (uint32_t)__builtin_amdgcn_readfirstlane((int)val[next_i]);
-                val[i] = (uint16_t)nv1; idx[nv1] = (uint16_t)i;  // i >= 64
-                if (ni1 != next_i) {
-                    if (ni1 < 64) vreg = orz_writelane(vreg, nv2, ni1); else { val[ni1] = (uint16_t)nv2; idx[nv2] = (uint16_t)ni1; }
-                }
-                if (next_i < 64) vreg = orz_writelane(vreg, v, next_i); else { val[next_i] = (uint16_t)v; idx[v] = (uint16_t)next_i; }
+                const uint32_t nv1 = get(ni1), nv2 = get(next_i);
+                put(i, nv1);
+                if (ni1 != next_i) put(ni1, nv2);
+                put(next_i, v);
             }
             const uint32_t r = i == iu ? kSyms - 1 : i - (i > iu);
             outr = orz_writelane(outr, r, k);
         }
         if (j0 + lane < e) grank[j0 + lane] = (uint16_t)outr;
     }
-    // tables back to HBM: the register's 64 ranks first
-    val[lane] = (uint16_t)vreg;
-    idx[vreg] = (uint16_t)lane;
+    // tables back to HBM: the registers' 128 ranks first
+    val[lane] = (uint16_t)v0;
+    val[64 + lane] = (uint16_t)v1;
+    idx[v0] = (uint16_t)lane;
+    idx[v1] = (uint16_t)(64 + lane);
     __syncthreads();
     for (uint32_t i = lane; i < kSyms; i += 64) { state[i] = val[i]; state[kSyms + i] = idx[i]; }
     if (lane == 0) {
@@ -209,6 +233,7 @@ class HipBackend {
         (void)hipFree(tmps_[1]);
         for (int i = 0; i < 2; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+        for (auto& kv : graph_exec_) (void)hipGraphExecDestroy(kv.second);
         (void)hipStreamDestroy(streams_[0]);
         (void)hipStreamDestroy(streams_[1]);
     }
@@ -334,7 +359,7 @@ class HipBackend {
     // the stream the kernel is launched on.
     static constexpr int kTimedSlots = 4;
     void timed_begin(int slot = 0) {
-        if (!timing_) return;
+        if (!timing_ || capturing_ || ((slot == 0 || slot == 3) && !profile_)) return;
         if (ev_used_ + 2 > ev_.size()) {
             for (int i = 0; i < 256; i++) {
                 hipEvent_t e;
@@ -346,8 +371,8 @@ class HipBackend {
         ev_slot_.resize(ev_.size() / 2 + 1);
         ev_slot_[ev_used_ / 2] = slot;
     }
-    void timed_end(int = 0) {
-        if (!timing_) return;
+    void timed_end(int slot = 0) {
+        if (!timing_ || capturing_ || ((slot == 0 || slot == 3) && !profile_)) return;
         ORZ_HIP_CHECK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
     }
@@ -373,6 +398,32 @@ class HipBackend {
         ev_used_ = 0;
         return ms[0];
     }
+    // hipGraph of a launch sequence that is identical from block to block (the fast parse's round loop over a full
+    // block: ~2,400 small kernels): captured once on the encoder's stream, replayed with one call per block.
+    bool graphs_enabled() const { return graphs_ && !profile_; }
+    bool graph_replay(uint64_t key) {
+        auto it = graph_exec_.find(key);
+        if (it == graph_exec_.end()) return false;
+        ORZ_HIP_CHECK(hipGraphLaunch(it->second, stream_));
+        return true;
+    }
+    void graph_capture_begin() { ORZ_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal)); capturing_ = true; }
+    void graph_capture_end(uint64_t key) {
+        hipGraph_t g = nullptr;
+        capturing_ = false;
+        ORZ_HIP_CHECK(hipStreamEndCapture(stream_, &g));
+        hipGraphExec_t ex = nullptr;
+        hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        graph_exec_[key] = ex;
+        ORZ_HIP_CHECK(hipGraphLaunch(ex, stream_));
+    }
+    void set_graphs(bool on) { graphs_ = on; }
+    // profile mode: HIP-event brackets around the kernels inside the round loop (so no graph replay)
+    void set_profile(bool on) { profile_ = on; }
+    bool profile() const { return profile_; }
+
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
         timed_begin(1);
         hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart);
@@ -392,6 +443,8 @@ class HipBackend {
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     std::vector<int> ev_slot_;
+    std::map<uint64_t, hipGraphExec_t> graph_exec_;
+    bool graphs_ = true, profile_ = false, capturing_ = false;
     size_t ev_used_ = 0;
 };
 

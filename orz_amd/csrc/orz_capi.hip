@@ -65,7 +65,7 @@ struct orz_stream {
     orz::ItemTrace trace;
     bool tracing = false;
     bool fast = false;
-    unsigned ftile = 65536, frounds = 8;
+    unsigned ftile = 65536, frounds = 4;
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
     void rebuild() {
@@ -124,7 +124,8 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         s->win = env_u("ORZ_WIN", 0);
         s->fast = mode_from_env();
         s->ftile = env_u("ORZ_FAST_TILE", 65536);
-        s->frounds = env_u("ORZ_FAST_ROUNDS", 8);
+        s->frounds = env_u("ORZ_FAST_ROUNDS", 4);
+        s->be->set_graphs(env_u("ORZ_GRAPHS", 1) != 0);
         s->rebuild();
         return s.release();
     } catch (const std::exception& e) {
@@ -160,6 +161,11 @@ int orz_stream_set_mode(orz_stream* s, int mode, unsigned tile_bytes, unsigned r
     } catch (const std::exception& e) {
         return fail(ORZ_EINVAL, e.what());
     }
+}
+int orz_stream_set_profile(orz_stream* s, int on) {
+    if (!s) return fail(ORZ_EINVAL, "null stream");
+    s->be->set_profile(on != 0);
+    return ORZ_OK;
 }
 int orz_stream_get_kernel_times(orz_stream* s, double* ms4, uint64_t* launches4) {
     if (!s || !ms4 || !launches4) return fail(ORZ_EINVAL, "null argument");
@@ -405,7 +411,7 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
             e->cfg = *cfg;
             const bool fast = mode_from_env();
             e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, fast ? 64 : window_for(*e->be, *cfg, e->win), fast,
-                                 env_u("ORZ_FAST_TILE", 65536), env_u("ORZ_FAST_ROUNDS", 8)));
+                                 env_u("ORZ_FAST_TILE", 65536), env_u("ORZ_FAST_ROUNDS", 4)));
         } else if (!same_cfg) {
             return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
         }

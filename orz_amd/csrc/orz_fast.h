@@ -225,9 +225,10 @@ struct FastEval {
     FastArgs a;
     uint32_t lo, hi;  // window offsets [lo, hi)
     // The far search (beyond the K tabulated predecessors) is the expensive part and its answer moves little from round
-    // to round: it runs in a tile's first round and again in its last one (when every earlier tile is final); the rounds
-    // in between merge the remembered answer.  far_lo / far_hi: window offsets from which / up to which it runs now.
-    uint32_t far_hi_from, far_lo_until;
+    // to round: it runs in a tile's second round (the first one, against an empty tile, only sketches the path) and
+    // again in its last one (when every earlier tile is final); the other rounds merge the remembered answer.
+    // [fa0, fa1) and [fb0, fb1): the window offsets (two tiles) where it runs in this launch.
+    uint32_t fa0, fa1, fb0, fb1;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
@@ -271,7 +272,7 @@ struct FastEval {
             }
         }
         if (!stop && seen < a.depth && a.rlen[i] > K && a.far) {
-            if (p < far_lo_until || p >= far_hi_from) {
+            if ((p >= fa0 && p < fa1) || (p >= fb0 && p < fb1)) {
                 // a long run whose tabulated K predecessors hold too few item starts (runs of "interior" 4-grams, zero runs):
                 // walk the bitmap further back and take the prefixes from the text records
                 const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];

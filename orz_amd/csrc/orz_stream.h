@@ -217,7 +217,7 @@ class StreamEncoder {
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
     // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
     StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072, bool fast = false,
-                  uint32_t fast_tile = 65536, uint32_t fast_rounds = 8)
+                  uint32_t fast_tile = 65536, uint32_t fast_rounds = 4)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs), fast_(fast), ftile_(fast_tile), frounds_(fast_rounds) {
         if (fast_) {
             if (ftile_ < kSub || ftile_ % kSub) throw std::runtime_error("fast tile must be a multiple of 4096");
@@ -612,16 +612,24 @@ class StreamEncoder {
             { uint32_t e0 = kPre; be_.h2d(ftentry_, &e0, 4); }
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
-            for (uint32_t step = 1; step <= ntile + R - 1; step++) {
+            // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
+            const bool use_graph = be_.graphs_enabled() && n == kNewMax;
+            const uint64_t gkey = ((uint64_t)T << 32) | n;
+            const bool replayed = use_graph && be_.graph_replay(gkey);
+            if (use_graph && !replayed) be_.graph_capture_begin();
+            if (replayed) stats.sweeps += ntile + R - 1;
+            for (uint32_t step = 1; step <= ntile + R - 1 && !replayed; step++) {
                 const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
                 const uint32_t lo = kPre + t_lo * T;
                 const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
                 const uint32_t hi2 = std::min(len, hi + 2);
                 be_.timed_begin();
-                // far searches: the oldest active tile (its last round) and a tile in its first round (+ the halo behind it)
-                const uint32_t far_lo_until = std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_lo + 1) * T);
-                const uint32_t far_hi_from = step <= ntile ? kPre + t_hi * T : hi;
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, far_hi_from, far_lo_until});
+                // far searches: the tile in its last round, and the tile in its second round
+                uint32_t fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;
+                static const int far_sched = getenv("ORZ_FAST_FARSCHED") ? atoi(getenv("ORZ_FAST_FARSCHED")) : 1;  // bit 0: last round, bit 1: second round
+                if ((far_sched & 1) && step >= R && step - R < ntile) { fa0 = kPre + (step - R) * T; fa1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fa0 + T); }
+                if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, fa0, fa1, fb0, fb1});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -637,6 +645,7 @@ class StreamEncoder {
                 be_.launch((size_t)nc * 256, FastPrefix{a, c0, c0 + nc});
                 stats.sweeps++;
             }
+            if (use_graph && !replayed) be_.graph_capture_end(gkey);
             // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes
             uint32_t* ckeys = (uint32_t*)entA_;
             uint32_t* ckeys2 = ckeys + kWLen;
@@ -839,7 +848,7 @@ class StreamEncoder {
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
-    uint32_t ftile_ = 65536, frounds_ = 8, fK_ = 64;
+    uint32_t ftile_ = 65536, frounds_ = 4, fK_ = 64;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
     uint16_t* fkw_ = nullptr;

@@ -33,10 +33,18 @@ struct EmuBackend {
     void select(int) {}
     void record(int) {}
     void wait(int) {}
+    bool graphs_enabled() const { return false; }
+    bool graph_replay(uint64_t) { return false; }
+    void graph_capture_begin() {}
+    void graph_capture_end(uint64_t) {}
     void timed_begin(int = 0) {}
     void timed_end(int = 0) {}
     void set_timing(bool) {}
-    double collect_timed(uint64_t* n) { if (n) *n = 0; return 0.0; }
+    double collect_timed(uint64_t* n, double* ms = nullptr, uint64_t* cnt = nullptr) {
+        if (n) *n = 0;
+        for (int i = 0; i < 4; i++) { if (ms) ms[i] = 0; if (cnt) cnt[i] = 0; }
+        return 0.0;
+    }
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     template <class F> void launch(size_t n, const F& f) {
         for (size_t i = 0; i < n; i++) f(i);
@@ -142,7 +150,7 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
     try {
         EmuBackend be;
         orz::Cfg cfg{depth, lazy1, lazy2};
-        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, tile ? tile : 65536, rounds ? rounds : 8);
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, tile ? tile : 65536, rounds ? rounds : 4);
         std::vector<uint8_t> out;
         orz::encode_stream(enc, be, src, n, false, out);
         *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);

@@ -1,0 +1,31 @@
+// dev tool: times orz_symrank_kernel on a recorded item stream and checks the ranks (tools/dev/make_symrank_case.py)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../orz_amd/csrc/backend_hip.h"
+using namespace orz;
+int main(int argc, char** argv) {
+    FILE* f = fopen(argc > 1 ? argv[1] : "build/symrank_case.bin", "rb");
+    if (!f) { perror("case"); return 1; }
+    uint32_t n; fread(&n, 4, 1, f);
+    std::vector<uint32_t> gsym(n), rstart(513); std::vector<uint16_t> state(512 * kSrWords), want(n), got(n);
+    fread(gsym.data(), 4, n, f); fread(rstart.data(), 4, 513, f); fread(state.data(), 2, state.size(), f); fread(want.data(), 2, n, f);
+    uint32_t *dg, *dr; uint16_t *ds, *dk;
+    hipMalloc(&dg, n * 4); hipMalloc(&dr, 513 * 4); hipMalloc(&ds, state.size() * 2); hipMalloc(&dk, n * 2);
+    hipMemcpy(dg, gsym.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dr, rstart.data(), 513 * 4, hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; rep++) {
+        hipMemcpy(ds, state.data(), state.size() * 2, hipMemcpyHostToDevice);
+        hipEventRecord(a);
+        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, 0, ds, dg, dk, dr);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    hipMemcpy(got.data(), dk, n * 2, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (uint32_t i = 0; i < n; i++) bad += got[i] != want[i];
+    uint32_t hot = 0; for (int c = 0; c < 512; c++) if (rstart[c + 1] - rstart[c] > hot) hot = rstart[c + 1] - rstart[c];
+    printf("items %u hottest %u  kernel %.2f ms  = %.1f ns per item of the hottest context  mismatches %zu\n", n, hot, best, best * 1e6 / hot, bad);
+    return bad != 0;
+}

@@ -48,7 +48,7 @@ def main():
     text = corpus.enwik_like(total)
     ok = run("C2: enwik8-shaped text, %d bytes, -l%d, members of %d bytes, %d encoders on one GPU" % (total, level, member, jobs), text, level, jobs, member)
     del text
-    ok &= run("C4: zeros + 1% noise, %d bytes, -l%d, members of %d bytes, %d encoders on one GPU" % (total, level, member, jobs), corpus.zeros_noise(total), level, jobs, member)
+    ok &= run("C4: zeros + 1 pct noise, %d bytes, -l%d, members of %d bytes, %d encoders on one GPU" % (total, level, member, jobs), corpus.zeros_noise(total), level, jobs, member)
     sys.exit(0 if ok else 1)
 
 
