@@ -65,7 +65,7 @@ struct orz_stream {
     orz::ItemTrace trace;
     bool tracing = false;
     bool fast = false;
-    unsigned ftile = 65536, frounds = 4;
+    unsigned ftile = 131072, frounds = 4;
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
     void rebuild() {
@@ -123,7 +123,7 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
         s->win = env_u("ORZ_WIN", 0);
         s->fast = mode_from_env();
-        s->ftile = env_u("ORZ_FAST_TILE", 65536);
+        s->ftile = env_u("ORZ_FAST_TILE", 131072);
         s->frounds = env_u("ORZ_FAST_ROUNDS", 4);
         s->be->set_graphs(env_u("ORZ_GRAPHS", 1) != 0);
         s->rebuild();
@@ -411,7 +411,7 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
             e->cfg = *cfg;
             const bool fast = mode_from_env();
             e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, fast ? 64 : window_for(*e->be, *cfg, e->win), fast,
-                                 env_u("ORZ_FAST_TILE", 65536), env_u("ORZ_FAST_ROUNDS", 4)));
+                                 env_u("ORZ_FAST_TILE", 131072), env_u("ORZ_FAST_ROUNDS", 4)));
         } else if (!same_cfg) {
             return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
         }

@@ -217,7 +217,7 @@ class StreamEncoder {
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
     // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
     StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072, bool fast = false,
-                  uint32_t fast_tile = 65536, uint32_t fast_rounds = 4)
+                  uint32_t fast_tile = 131072, uint32_t fast_rounds = 4)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs), fast_(fast), ftile_(fast_tile), frounds_(fast_rounds) {
         if (fast_) {
             if (ftile_ < kSub || ftile_ % kSub) throw std::runtime_error("fast tile must be a multiple of 4096");
@@ -592,7 +592,8 @@ class StreamEncoder {
         // a quarter the size (match-dense, highly repetitive data; never seen on text).
         uint32_t T = ftile_;
         {
-            const uint32_t want = ((n / 256 + kSub - 1) / kSub) * kSub;
+            static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
+            const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
         }
         for (;;) {
@@ -848,7 +849,7 @@ class StreamEncoder {
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
-    uint32_t ftile_ = 65536, frounds_ = 4, fK_ = 64;
+    uint32_t ftile_ = 131072, frounds_ = 4, fK_ = 64;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
     uint16_t* fkw_ = nullptr;

@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--skip-others", action="store_true", help="orz rows only")
     ap.add_argument("--other-rounds", type=int, default=0, help="rounds for gzip/bzip2/xz/... (default: --rounds)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--exact-rows", action="store_true", help="also time `orz --mode exact` (one round)")
     args = ap.parse_args()
     if not args.bench_file and not args.corpus:
         ap.error("usage: benchmark_tool.py <bench-file> | --corpus N")
@@ -107,13 +108,16 @@ def main():
 
             path = os.path.join(tmp, "bench_input")
             with open(path, "wb") as f:
-                f.write(corpus.text_corpus(args.corpus))
+                f.write(corpus.enwik_like(args.corpus))
         nbytes = os.path.getsize(path)
         want = md5(path)
         rows = []
-        for lv in (() if args.skip_orz else (0, 1, 2)):
+        for lv in (() if args.skip_orz else (0, 1, 2)):  # the library's default mode (fast unless ORZ_MODE=exact), then the exact one
             rows.append(bench(tmp, path, "**orz -l%d** (MI355X)" % lv, [ORZ, "encode", "-s", "-l%d" % lv], [ORZ, "decode", "-s"],
                               args.rounds, want))
+        for lv in (() if (args.skip_orz or not args.exact_rows) else (0, 1, 2)):
+            rows.append(bench(tmp, path, "orz -l%d --mode exact (MI355X, the reference's parse)" % lv, [ORZ, "encode", "-s", "--mode", "exact", "-l%d" % lv],
+                              [ORZ, "decode", "-s"], 1, want))
         if not args.skip_oracle and os.path.exists(ORACLE):
             for lv in (0, 1, 2):
                 rows.append(bench(tmp, path, "oracle -l%d (CPU restatement, 1 thread)" % lv, [ORACLE, "encode", "-l%d" % lv],
