@@ -286,6 +286,12 @@ class HipBackend {
         ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream_));
         ORZ_HIP_CHECK(hipStreamSynchronize(stream_));  // pageable source may be reused by the caller
     }
+    // host -> device from PINNED host memory (hipHostMalloc / hipHostRegister): asynchronous on the encoder's stream, no
+    // synchronisation here -- the caller must not reuse the source before the stream's next sync (encode_block ends in one)
+    void h2d_pinned(void* d, const void* s, size_t n) {
+        if (!n) return;
+        ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream_));
+    }
     void d2h(void* d, const void* s, size_t n) {
         if (!n) return;
         ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream_));

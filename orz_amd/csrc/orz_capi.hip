@@ -200,7 +200,18 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
         hipEvent_t e0 = ev.a, e1 = ev.b;
         ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
         s->trace.clear();
-        orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out);
+        struct Pin {  // host input: page-lock it for the call so the block uploads are real asynchronous DMA
+            void* p = nullptr;
+            ~Pin() { if (p) (void)hipHostUnregister(p); }
+        } pin;
+        bool pinned = false;
+        if (!src_on_device && n >= (1u << 20) && hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) {
+            pin.p = const_cast<void*>(src);
+            pinned = true;
+        } else {
+            (void)hipGetLastError();  // (registration refused: pageable copies, synchronised per block)
+        }
+        orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out, pinned);
         ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
         be.sync();
         float total = 0;
@@ -549,7 +560,14 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
         Enc& enc = *s->enc;
         orz::HipBackend& be = *s->be;
         enc.reset();
-        std::vector<uint8_t> in(orz::kNewMax), out;
+        struct PinnedBuf {  // the block read buffer, page-locked (pinned hipMemcpyAsync feed)
+            uint8_t* p = nullptr;
+            PinnedBuf() { if (hipHostMalloc((void**)&p, orz::kNewMax, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw std::runtime_error("hipHostMalloc failed"); } }
+            ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+            uint8_t* data() { return p; }
+            size_t size() const { return orz::kNewMax; }
+        } in;
+        std::vector<uint8_t> out;
         size_t in_total = 0, out_total = 0;
         bool first = true;
         for (;;) {
@@ -564,7 +582,7 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
             if (rc != ORZ_OK || got == 0) break;
             if (!first) enc.slide();
             first = false;
-            be.h2d(enc.dwin() + orz::kPre, in.data(), got);
+            be.h2d_pinned(enc.dwin() + orz::kPre, in.data(), got);  // encode_block syncs before `in` is refilled
             out.clear();
             enc.encode_block((uint32_t)got, out);
             if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }

@@ -230,124 +230,121 @@ class StreamEncoder {
         }
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
-        dmax_ = (uint32_t)std::max(cfg.depth, std::max(cfg.lazy1, cfg.lazy2));
-        if (cfg.depth < 1 || dmax_ > 200) throw std::runtime_error("LZCfg depth out of range");
-        nseg_max_ = (kNewMax + seg_ - 1) / seg_;
-        if (wsegs_ > nseg_max_) wsegs_ = nseg_max_;
-        ring_ = wsegs_ + 8;
-        winbuf_ = be_.template alloc<uint8_t>((size_t)kBlock + 2 * kSent + 64);
-        S_ = be_.template alloc<uint8_t>(kWLen);
-        E_ = be_.template alloc<uint8_t>(kWLen);
-        ML_ = be_.template alloc<uint8_t>(kWLen);
-        ORD_ = be_.template alloc<uint32_t>(kWLen);
-        LR_ = be_.template alloc<uint8_t>(kWLen);
-        SRC_ = be_.template alloc<uint32_t>(kWLen);
-        W0_ = be_.template alloc<uint8_t>(kWLen);
-        TY_ = be_.template alloc<uint8_t>(kWLen);
-        LENMIN_ = be_.template alloc<uint8_t>(kWLen);
-        LMV_ = be_.template alloc<uint8_t>(kWLen);
-        idx_ = be_.template alloc<uint32_t>(kWLen);
-        kidx_ = be_.template alloc<uint32_t>(kWLen);
-        // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
-        entA_ = be_.template alloc<uint64_t>((size_t)kWLen);
-        entB_ = be_.template alloc<uint64_t>((size_t)kWLen);
-        symA_ = be_.template alloc<uint64_t>((size_t)kNewMax);
-        symB_ = be_.template alloc<uint64_t>((size_t)kNewMax);
-        epos_ = be_.template alloc<uint32_t>(kWLen);
-        kpos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 8);
-        runstart_ = be_.template alloc<uint32_t>(kNumKeys + 1);
-        krun_ = be_.template alloc<uint32_t>(32768 + 1);
-        krunend_ = be_.template alloc<uint32_t>(32768 + 1);
-        vbits_ = be_.template alloc<uint64_t>(kWLen / 64 + 2);
-        v1_ = be_.template alloc<uint64_t>(kWLen / 4096 + 2);
-        v2_ = be_.template alloc<uint64_t>(kWLen / 262144 + 2);
-        kbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 2);
-        k1_ = be_.template alloc<uint64_t>(kNewMax / 4096 + 2);
-        k2_ = be_.template alloc<uint64_t>(kNewMax / 262144 + 2);
-        if (!fast_) {
-            srec_ = be_.template alloc<SlotRec>(kWLen);
-            exitst_ = be_.template alloc<uint64_t>((size_t)nseg_max_ + 2);
-            hist_ = be_.template alloc<uint8_t>((size_t)ring_ * 256);
-            base_ = be_.template alloc<uint32_t>((size_t)ring_ * 256);
-            ctl_ = be_.template alloc<ParseCtl>(1);
-            partial_ = be_.template alloc<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
-        } else {
-            const size_t nn = (size_t)kNewMax + 512;
-            frows_ = be_.template alloc<uint8_t>((size_t)kNewMax * fK_ + 64);
-            frlen_ = be_.template alloc<uint8_t>(nn);
-            fstext_ = be_.template alloc<uint64_t>((size_t)kWLen * 2);
-            fkw_ = be_.template alloc<uint16_t>(nn);
-            fev_ = be_.template alloc<uint32_t>(nn);
-            fbs_ = be_.template alloc<uint32_t>(nn);
-            fty_ = be_.template alloc<uint8_t>(nn);
-            fnl_ = be_.template alloc<uint8_t>(nn);
-            fpt_ = be_.template alloc<uint8_t>(nn);
-            fmf_ = be_.template alloc<uint8_t>(nn);
-            fef_ = be_.template alloc<uint8_t>(nn);
-            fx0_ = be_.template alloc<uint8_t>(nn);
-            fx1_ = be_.template alloc<uint8_t>((size_t)(kNSub + 2) * kEntries);
-            fx2_ = be_.template alloc<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
-            fsbits_ = be_.template alloc<uint64_t>(kNewMax / 64 + 16);
-            fcentry_ = be_.template alloc<uint32_t>(kNSub + 2);
-            ftentry_ = be_.template alloc<uint32_t>(kNewMax / kSub + 4);
-            fcm_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
-            fcp_ = be_.template alloc<uint32_t>((size_t)(kNSub + 2) * 256);
-            fcut_ = be_.template alloc<uint32_t>(nn);
-            flaste_ = be_.template alloc<uint32_t>(nn);
-            fnchg_ = be_.template alloc<uint32_t>(4);
-            fcstart_ = be_.template alloc<uint32_t>(260);
-            ffarv_ = be_.template alloc<uint32_t>(nn);
-            ffarsrc_ = be_.template alloc<uint32_t>(nn);
+        try {
+            dmax_ = (uint32_t)std::max(cfg.depth, std::max(cfg.lazy1, cfg.lazy2));
+            if (cfg.depth < 1 || dmax_ > 200) throw std::runtime_error("LZCfg depth out of range");
+            nseg_max_ = (kNewMax + seg_ - 1) / seg_;
+            if (wsegs_ > nseg_max_) wsegs_ = nseg_max_;
+            ring_ = wsegs_ + 8;
+            winbuf_ = take<uint8_t>((size_t)kBlock + 2 * kSent + 64);
+            S_ = take<uint8_t>(kWLen);
+            E_ = take<uint8_t>(kWLen);
+            ML_ = take<uint8_t>(kWLen);
+            ORD_ = take<uint32_t>(kWLen);
+            LR_ = take<uint8_t>(kWLen);
+            SRC_ = take<uint32_t>(kWLen);
+            W0_ = take<uint8_t>(kWLen);
+            TY_ = take<uint8_t>(kWLen);
+            LENMIN_ = take<uint8_t>(kWLen);
+            LMV_ = take<uint8_t>(kWLen);
+            idx_ = take<uint32_t>(kWLen);
+            kidx_ = take<uint32_t>(kWLen);
+            // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
+            entA_ = take<uint64_t>((size_t)kWLen);
+            entB_ = take<uint64_t>((size_t)kWLen);
+            symA_ = take<uint64_t>((size_t)kNewMax);
+            symB_ = take<uint64_t>((size_t)kNewMax);
+            epos_ = take<uint32_t>(kWLen);
+            kpos_ = take<uint32_t>((size_t)kNewMax + 8);
+            runstart_ = take<uint32_t>(kNumKeys + 1);
+            krun_ = take<uint32_t>(32768 + 1);
+            krunend_ = take<uint32_t>(32768 + 1);
+            vbits_ = take<uint64_t>(kWLen / 64 + 2);
+            v1_ = take<uint64_t>(kWLen / 4096 + 2);
+            v2_ = take<uint64_t>(kWLen / 262144 + 2);
+            kbits_ = take<uint64_t>(kNewMax / 64 + 2);
+            k1_ = take<uint64_t>(kNewMax / 4096 + 2);
+            k2_ = take<uint64_t>(kNewMax / 262144 + 2);
+            if (!fast_) {
+                srec_ = take<SlotRec>(kWLen);
+                exitst_ = take<uint64_t>((size_t)nseg_max_ + 2);
+                hist_ = take<uint8_t>((size_t)ring_ * 256);
+                base_ = take<uint32_t>((size_t)ring_ * 256);
+                ctl_ = take<ParseCtl>(1);
+                partial_ = take<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
+            } else {
+                const size_t nn = (size_t)kNewMax + 512;
+                frows_ = take<uint8_t>((size_t)kNewMax * fK_ + 64);
+                frlen_ = take<uint8_t>(nn);
+                fstext_ = take<uint64_t>((size_t)kWLen * 2);
+                fkw_ = take<uint16_t>(nn);
+                fev_ = take<uint32_t>(nn);
+                fbs_ = take<uint32_t>(nn);
+                fty_ = take<uint8_t>(nn);
+                fnl_ = take<uint8_t>(nn);
+                fpt_ = take<uint8_t>(nn);
+                fmf_ = take<uint8_t>(nn);
+                fef_ = take<uint8_t>(nn);
+                fx0_ = take<uint8_t>(nn);
+                fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
+                fx2_ = take<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
+                fsbits_ = take<uint64_t>(kNewMax / 64 + 16);
+                fcentry_ = take<uint32_t>(kNSub + 2);
+                ftentry_ = take<uint32_t>(kNewMax / kSub + 4);
+                fcm_ = take<uint32_t>((size_t)(kNSub + 2) * 256);
+                fcp_ = take<uint32_t>((size_t)(kNSub + 2) * 256);
+                fcut_ = take<uint32_t>(nn);
+                flaste_ = take<uint32_t>(nn);
+                fnchg_ = take<uint32_t>(4);
+                fcstart_ = take<uint32_t>(260);
+                ffarv_ = take<uint32_t>(nn);
+                ffarsrc_ = take<uint32_t>(nn);
+            }
+            f32_ = take<uint32_t>(kWLen);
+            sc32_ = take<uint32_t>(kWLen);
+            hpos_ = take<uint32_t>(kPre + 1);
+            ctxcount_ = take<uint32_t>(256);
+            tailkey_ = take<uint32_t>(4);
+            wsnap_ = take<uint8_t>(65536);
+            wlast_ = take<uint32_t>(32768);
+            // items
+            ipos_ = take<uint32_t>((size_t)kNewMax + 1);
+            isym_ = take<uint16_t>(kNewMax);
+            ictx_ = take<uint16_t>(kNewMax);
+            irank_ = take<uint16_t>(kNewMax);
+            irob_ = take<uint16_t>(kNewMax);
+            grank_ = take<uint16_t>(kNewMax);
+            iunl_ = take<uint8_t>(kNewMax);
+            ienc_ = take<uint8_t>(kNewMax);
+            ial_ = take<uint8_t>(kNewMax);
+            gsym_ = take<uint32_t>(kNewMax);
+            blen_ = take<uint32_t>(kNewMax);
+            bscan_ = take<uint32_t>(kNewMax);
+            rstart_ = take<uint32_t>(520);
+            counts_ = take<uint32_t>(kSyms + 3);
+            order_ = take<uint16_t>(kSyms + 3);
+            ncounted_ = take<uint32_t>(4);
+            srstate_ = take<uint16_t>((size_t)512 * kSrWords);
+            hw_ = take<uint32_t>((size_t)kMaxChunks * kHwStride);
+            hl_ = take<uint8_t>((size_t)kMaxChunks * kHwStride);
+            hc_ = take<uint16_t>((size_t)kMaxChunks * kHwStride);
+            hscr_ = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
+            hdrbits_ = take<uint32_t>(kMaxChunks);
+            tot_ = take<uint32_t>(kMaxChunks);
+            outoff_ = take<uint64_t>(kMaxChunks);
+            out_ = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
+            {
+                std::vector<uint64_t> off(kMaxChunks);
+                for (uint32_t i = 0; i < kMaxChunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
+                be_.h2d(outoff_, off.data(), kMaxChunks * 8);
+            }
+            reset();
+        } catch (...) {  // a failed allocation / launch must not leak the earlier ones
+            release_all();
+            throw;
         }
-        f32_ = be_.template alloc<uint32_t>(kWLen);
-        sc32_ = be_.template alloc<uint32_t>(kWLen);
-        hpos_ = be_.template alloc<uint32_t>(kPre + 1);
-        ctxcount_ = be_.template alloc<uint32_t>(256);
-        tailkey_ = be_.template alloc<uint32_t>(4);
-        wsnap_ = be_.template alloc<uint8_t>(65536);
-        wlast_ = be_.template alloc<uint32_t>(32768);
-        // items
-        ipos_ = be_.template alloc<uint32_t>((size_t)kNewMax + 1);
-        isym_ = be_.template alloc<uint16_t>(kNewMax);
-        ictx_ = be_.template alloc<uint16_t>(kNewMax);
-        irank_ = be_.template alloc<uint16_t>(kNewMax);
-        irob_ = be_.template alloc<uint16_t>(kNewMax);
-        grank_ = be_.template alloc<uint16_t>(kNewMax);
-        iunl_ = be_.template alloc<uint8_t>(kNewMax);
-        ienc_ = be_.template alloc<uint8_t>(kNewMax);
-        ial_ = be_.template alloc<uint8_t>(kNewMax);
-        gsym_ = be_.template alloc<uint32_t>(kNewMax);
-        blen_ = be_.template alloc<uint32_t>(kNewMax);
-        bscan_ = be_.template alloc<uint32_t>(kNewMax);
-        rstart_ = be_.template alloc<uint32_t>(520);
-        counts_ = be_.template alloc<uint32_t>(kSyms + 3);
-        order_ = be_.template alloc<uint16_t>(kSyms + 3);
-        ncounted_ = be_.template alloc<uint32_t>(4);
-        srstate_ = be_.template alloc<uint16_t>((size_t)512 * kSrWords);
-        hw_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * kHwStride);
-        hl_ = be_.template alloc<uint8_t>((size_t)kMaxChunks * kHwStride);
-        hc_ = be_.template alloc<uint16_t>((size_t)kMaxChunks * kHwStride);
-        hscr_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
-        hdrbits_ = be_.template alloc<uint32_t>(kMaxChunks);
-        tot_ = be_.template alloc<uint32_t>(kMaxChunks);
-        outoff_ = be_.template alloc<uint64_t>(kMaxChunks);
-        out_ = be_.template alloc<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
-        {
-            std::vector<uint64_t> off(kMaxChunks);
-            for (uint32_t i = 0; i < kMaxChunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
-            be_.h2d(outoff_, off.data(), kMaxChunks * 8);
-        }
-        reset();
     }
-    ~StreamEncoder() {
-        void* ptrs[] = {winbuf_, S_, E_, ML_, ORD_, LR_, SRC_, W0_, TY_, LENMIN_, LMV_, idx_, kidx_, entA_, entB_, symA_, symB_, epos_,
-                        kpos_, runstart_, krun_, krunend_, vbits_, v1_, v2_, kbits_, k1_, k2_, srec_, exitst_, hist_, base_, ctl_, partial_, f32_, sc32_,
-                        hpos_, ctxcount_, tailkey_, wsnap_, wlast_, ipos_, isym_, ictx_, irank_, irob_, grank_, iunl_, ienc_, ial_,
-                        gsym_, blen_, bscan_, rstart_, counts_, order_, ncounted_, srstate_, hw_, hl_, hc_, hscr_,
-                        hdrbits_, tot_, outoff_, out_, frows_, frlen_, fkw_, fev_, fbs_, fty_, fnl_, fpt_, fmf_, fef_, fx0_, fx1_, fx2_,
-                        fsbits_, fcentry_, ftentry_, fcm_, fcp_, fcut_, flaste_, fnchg_, fcstart_, fstext_, ffarv_, ffarsrc_};
-        for (void* p : ptrs) if (p) be_.free(p);
-    }
+    ~StreamEncoder() { release_all(); }
     StreamEncoder(const StreamEncoder&) = delete;
     StreamEncoder& operator=(const StreamEncoder&) = delete;
 
@@ -845,6 +842,17 @@ class StreamEncoder {
     ItemTrace* trace = nullptr;  // when set, every block appends its items
 
    private:
+    template <class T>
+    T* take(size_t n) {  // device allocation owned by this encoder (freed by release_all, also when the constructor throws)
+        T* p = be_.template alloc<T>(n);
+        owned_.push_back(p);
+        return p;
+    }
+    void release_all() {
+        for (void* p : owned_) if (p) be_.free(p);
+        owned_.clear();
+    }
+    std::vector<void*> owned_;
     BE& be_;
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
@@ -894,12 +902,13 @@ class StreamEncoder {
 // fills the window block by block, frames chunks, slides, and appends the EOF chunk.
 template <class BE>
 void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n, bool src_on_device,
-                   std::vector<uint8_t>& out) {
+                   std::vector<uint8_t>& out, bool src_pinned = false) {
     enc.reset();
     size_t off = 0;
     while (off < n) {
         uint32_t take = (uint32_t)std::min<size_t>(n - off, kNewMax);
         if (src_on_device) be.d2d(enc.dwin() + kPre, src + off, take);
+        else if (src_pinned) be.h2d_pinned(enc.dwin() + kPre, src + off, take);  // async: the block's first sync covers it
         else be.h2d(enc.dwin() + kPre, src + off, take);
         enc.encode_block(take, out);
         off += take;

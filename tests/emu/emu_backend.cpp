@@ -22,6 +22,7 @@ struct EmuBackend {
     void free(void* p) { std::free(p); }
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    void h2d_pinned(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
