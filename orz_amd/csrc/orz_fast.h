@@ -30,6 +30,10 @@
 
 namespace orz {
 
+#if !defined(__HIPCC__)
+inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: evaluations, far searches, words walked, members examined)
+#endif
+
 constexpr uint32_t kSub = 4096;                    // positions per ordinal subtile (= path chunk)
 constexpr uint32_t kSeg64 = 64;                    // positions per path segment
 constexpr uint32_t kNSub = kNewMax / kSub + 2;
@@ -234,6 +238,9 @@ struct FastEval {
         if (p >= hi) return;
         const uint8_t* win = a.win;
         const uint32_t i = p - kPre, c = hash1(win, p - 1), K = a.K;
+#if !defined(__HIPCC__)
+        g_far_stats[0]++;
+#endif
         const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
         const uint8_t* row = a.rows + (size_t)i * K;
         const uint32_t sp = i / kSub;
@@ -280,14 +287,23 @@ struct FastEval {
                 const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
                 const uint64_t a0 = ldu64(win + p), a1 = ldu64(win + p + 8);
                 uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
+#if !defined(__HIPCC__)
+                g_far_stats[1]++;
+#endif
                 for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && seen < a.depth; wbase -= 64) {
                     uint64_t mask = bits_at(a.vbits, wbase);
+#if !defined(__HIPCC__)
+                    g_far_stats[2]++;
+#endif
                     if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
                     while (mask && seen < a.depth) {
                         const uint32_t t = 63 - (uint32_t)clz64(mask);
                         mask &= ~(1ull << t);
                         const uint32_t sl = (uint32_t)(wbase + t);
                         const uint32_t l = far_lcp(a, p, a0, a1, sl);
+#if !defined(__HIPCC__)
+                        g_far_stats[3]++;
+#endif
                         if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
                             const uint32_t q = a.epos[sl];
                             uint32_t ro_hi, ro_mid;

@@ -161,6 +161,9 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
             stats5[0] = enc.stats.blocks; stats5[1] = enc.stats.sweeps; stats5[2] = enc.stats.seg_evals;
             stats5[3] = enc.stats.items; stats5[4] = enc.stats.chunks;
         }
+        if (std::getenv("ORZ_FAR_STATS"))
+            std::fprintf(stderr, "far search: %llu evaluations, %llu far searches, %llu bitmap words, %llu members examined\n",
+                         orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2], orz::g_far_stats[3]);
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
