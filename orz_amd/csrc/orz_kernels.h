@@ -303,6 +303,36 @@ struct Hist {
     }
 };
 
+// The same histogram, one wavefront per 4096 items (a chunk holds 2^20 items, so a wavefront stays inside one chunk):
+// bins privatised in LDS, the non-empty ones flushed with one global atomic each.
+struct HistWave {
+    const uint16_t* irank;
+    const uint8_t* ial;
+    const uint8_t* ienc;
+    uint32_t n;
+    uint32_t* hw;  // [nchunks][kHwStride]
+    static size_t lds_bytes() { return kHwStride * 4; }
+    template <class W>
+    ORZ_HD void operator()(W& w) const {
+        uint32_t* bins = (uint32_t*)w.lds();
+        const uint32_t lane = w.lane();
+        for (uint32_t b = lane; b < kHwStride; b += 64) bins[b] = 0;
+        w.sync();
+        const size_t base = (size_t)w.block() * 4096;
+        for (uint32_t k = 0; k < 64; k++) {
+            const size_t tid = base + (size_t)k * 64 + lane;
+            if (tid >= n) break;
+            const uint32_t al = ial[tid] & 1;
+            ORZ_ATOMIC_ADD(&bins[al * kSyms + irank[tid]], 1u);
+            if ((ial[tid] & 2) && ienc[tid] >= 5) ORZ_ATOMIC_ADD(&bins[2 * kSyms + ienc[tid]], 1u);
+        }
+        w.sync();
+        uint32_t* dst = hw + (base >> 20) * kHwStride;
+        for (uint32_t b = lane; b < kHwStride; b += 64)
+            if (bins[b]) ORZ_ATOMIC_ADD(&dst[b], bins[b]);
+    }
+};
+
 // HuffmanTable::new_from_sym_weights (src/huffman.rs:27-111) + canonical codes (:118-141).
 // One thread per (chunk, table).  The heap is a binary min-heap on (weight, index): keys are
 // unique, so the pop order -- hence the tree -- is fully determined.

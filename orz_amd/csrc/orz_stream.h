@@ -748,7 +748,7 @@ class StreamEncoder {
         be_.launch(nitems, SymScatter{sk, grank_, nitems, irank_});
         // static Huffman per chunk
         be_.memset(hw_, 0, (size_t)nchunks * kHwStride * 4);
-        be_.launch(nitems, Hist{irank_, ial_, ienc_, nitems, hw_});
+        be_.launch_waves(((size_t)nitems + 4095) / 4096, HistWave{irank_, ial_, ienc_, nitems, hw_}, HistWave::lds_bytes());
         be_.huffbuild(HuffBuild{hw_, nchunks, hl_, hc_, hscr_});
         be_.launch(nitems, ItemBits{irank_, ial_, ienc_, irob_, hl_, nitems, blen_});
         be_.exclusive_scan_u32(blen_, bscan_, nitems);
