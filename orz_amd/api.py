@@ -48,6 +48,12 @@ class StreamEncoder:
             _check(self._lib.orz_stream_set_mode(self._h, 1 if mode == "fast" else 0, int(tile_bytes), int(rounds)),
                    "orz_stream_set_mode")
 
+    def set_mode(self, mode, tile_bytes=0, rounds=0):
+        """switch the parse mode / fast-mode schedule of this encoder (rebuilds its device state)"""
+        if mode not in ("fast", "exact"):
+            raise ValueError("mode must be 'fast' or 'exact'")
+        _check(self._lib.orz_stream_set_mode(self._h, 1 if mode == "fast" else 0, int(tile_bytes), int(rounds)), "orz_stream_set_mode")
+
     def config(self):
         """What the encoder runs with (orz_stream_get_config)."""
         c = _native.StreamConfig()

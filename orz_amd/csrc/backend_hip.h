@@ -263,6 +263,12 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 v0 = orz_writelane(v0, nv1, i);
                 v0 = orz_writelane(v0, nv2, ni1);
                 v0 = orz_writelane(v0, v, next_i);
+            } else if (i < 128 && next_i >= 64) {  // everything involved sits in the second register
+                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(v1, (int)(ni1 - 64));
+                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(v1, (int)(next_i - 64));
+                v1 = orz_writelane(v1, nv1, i - 64);
+                v1 = orz_writelane(v1, nv2, ni1 - 64);
+                v1 = orz_writelane(v1, v, next_i - 64);
             } else if (i != next_i) {
                 const uint32_t nv1 = get(ni1), nv2 = get(next_i);
                 put(i, nv1);
@@ -515,6 +521,11 @@ class HipBackend {
         ORZ_HIP_CHECK(hipGraphLaunch(ex, stream_));
     }
     void set_graphs(bool on) { graphs_ = on; }
+    // the captured launches hold the encoder's buffer addresses and settings: forget them when the encoder is rebuilt
+    void clear_graphs() {
+        for (auto& kv : graph_exec_) (void)hipGraphExecDestroy(kv.second);
+        graph_exec_.clear();
+    }
     // profile mode: HIP-event brackets around the kernels inside the round loop (so no graph replay)
     void set_profile(bool on) { profile_ = on; }
     bool profile() const { return profile_; }

@@ -70,6 +70,7 @@ struct orz_stream {
     uint64_t kernel_n[4] = {0, 0, 0, 0};
     void rebuild() {
         enc.reset();
+        be->clear_graphs();
         enc.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
         enc->trace = tracing ? &trace : nullptr;
     }

@@ -680,7 +680,9 @@ class StreamEncoder {
                 done = chg == 0;
             }
             if (!done) throw std::runtime_error("fast parse: repairs did not converge");
-            if (T <= kSub || total_repairs * 200 < (uint64_t)nmem_last) break;  // fewer than 0.5 % of the items were repaired
+            // unstable = more than 0.5 % of the items repaired AND more than one repair per 2000 input bytes (sparse item
+            // streams -- long zero runs -- reach the first mark with a handful of repairs that cost nothing)
+            if (T <= kSub || total_repairs * 200 < (uint64_t)nmem_last || total_repairs * 2000 < (uint64_t)n) break;
             T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
             stats.seg_evals -= total_repairs;  // (count the repairs of the parse that is kept)
         }

@@ -153,3 +153,25 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["mode"] == "fast"
+
+
+def test_rebuilt_encoder_does_not_replay_a_stale_graph(oracle):
+    """the round loop of a full block is replayed as a hipGraph that holds buffer addresses and settings: switching the
+    schedule (which rebuilds the encoder) must drop it"""
+    import corpus
+    import orz_amd
+
+    data = corpus.enwik_like(40_000_000)[: (1 << 24) + 50_000]
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        a = enc.encode(data)
+        a2 = enc.encode(data)          # second full block of the same shape: replayed
+        enc.set_mode("fast", tile_bytes=65536, rounds=3)
+        b = enc.encode(data)
+        enc.set_mode("exact")
+        c = enc.encode(data)
+    finally:
+        enc.close()
+    assert a == a2
+    assert oracle.decode(a)[0] == data and oracle.decode(b)[0] == data
+    assert c == oracle.encode(data, 1)

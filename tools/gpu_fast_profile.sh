@@ -13,7 +13,7 @@ import sys, os, json
 repo = "$REPO"
 sys.path.insert(0, repo); sys.path.insert(0, os.path.join(repo, "tools"))
 import corpus, orz_amd
-d = corpus.enwik_like($N)
+d = corpus.zeros_noise($N) if os.environ.get("ORZ_PROFILE_ZEROS") else corpus.enwik_like($N)
 enc = orz_amd.StreamEncoder(device=0, level=$LV, mode="fast")
 enc.encode(d[:1000000])
 out, st = enc.encode(d, stats=True)
