@@ -56,6 +56,7 @@ struct FastArgs {
     uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
+    uint64_t* v1;               // bit per non-zero word of vbits (rebuilt after every path update: V1Build)
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
     uint32_t* bs;               // [n+8] best source (window offset)
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
@@ -224,6 +225,42 @@ ORZ_D uint32_t far_lcp(const FastArgs& a, uint32_t p, uint64_t a0, uint64_t a1, 
     return 16 + lcp240u(a.win + a.epos[s] + 16, a.win + p + 16, kMaxLen - 16);
 }
 
+// Item starts among the slots [lo, top), newest first, through the summary level: visit(slot) returns false to stop.
+template <class V>
+ORZ_D void far_walk(const FastArgs& a, uint32_t lo, uint32_t top, V visit) {
+    if (top <= lo) return;
+    const uint32_t w_hi = (top - 1) >> 6, w_lo = lo >> 6;  // words of vbits that intersect the range
+    for (int64_t g = (int64_t)(w_hi >> 6); g >= (int64_t)(w_lo >> 6); g--) {
+        uint64_t sm = a.v1[g];
+        if ((uint32_t)g == (w_hi >> 6) && (w_hi & 63) != 63) sm &= (2ull << (w_hi & 63)) - 1;
+        if ((uint32_t)g == (w_lo >> 6)) sm &= ~0ull << (w_lo & 63);
+        while (sm) {
+            const uint32_t wb = 63 - (uint32_t)clz64(sm);
+            sm &= ~(1ull << wb);
+            const uint32_t wi = (uint32_t)g * 64 + wb;
+            uint64_t m = a.vbits[wi];
+            if (wi == w_hi && (top & 63)) m &= (1ull << (top & 63)) - 1;
+            if (wi == w_lo) m &= ~0ull << (lo & 63);
+            while (m) {
+                const uint32_t t = 63 - (uint32_t)clz64(m);
+                m &= ~(1ull << t);
+                if (!visit(wi * 64 + t)) return;
+            }
+        }
+    }
+}
+struct V1Build {  // thread per summary word: 64 words of the bitmap
+    const uint64_t* vbits;
+    uint32_t nwords;  // words of vbits
+    uint64_t* v1;
+    ORZ_HD void operator()(size_t g) const {
+        if (g * 64 >= nwords) return;
+        uint64_t m = 0;
+        for (uint32_t k = 0; k < 64 && g * 64 + k < nwords; k++) m |= (uint64_t)(vbits[g * 64 + k] != 0) << k;
+        v1[g] = m;
+    }
+};
+
 // ---- one round: every position of the active range decides from the snapshot --------------------------
 struct FastEval {
     FastArgs a;
@@ -244,8 +281,11 @@ struct FastEval {
         const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
         const uint8_t* row = a.rows + (size_t)i * K;
         const uint32_t sp = i / kSub;
-        const uint32_t op_lo = a.cp[(size_t)sp * 256 + c];
-        const uint32_t op_hi = op_lo + a.cm[(size_t)sp * 256 + c];
+        // ring ordinal of an item starting at p: exact up to the subtile, interpolated inside it (item starts of one
+        // context are spread evenly enough); validity tests add a margin, the final source assignment is exact
+        const uint32_t cmp_ = a.cm[(size_t)sp * 256 + c];
+        const uint32_t op_lo = a.cp[(size_t)sp * 256 + c] + ((cmp_ * (i & (kSub - 1))) >> 12);
+        const uint32_t op_hi = op_lo + (cmp_ >> 3) + 4;
         uint32_t best = 0, bsrc = 0, b510 = 0, m1 = 0, m2 = 0, seen = 0;
         bool stop = false;
         for (uint32_t m = 0; m * 64 < r && !stop && seen < a.depth; m++) {
@@ -262,9 +302,10 @@ struct FastEval {
                     const uint32_t q = a.epos[j - 1 - k];
                     uint32_t ro_hi, ro_mid;
                     if (q >= kPre) {
-                        const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
-                        ro_hi = op_hi - oq;
-                        ro_mid = op_lo - oq;
+                        const uint32_t sq = (q - kPre) / kSub;
+                        const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
+                        ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
+                        ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
                     } else {
                         ro_hi = op_hi - 1 - a.ORD[q];
                         ro_mid = op_lo - 1 - a.ORD[q];
@@ -290,40 +331,32 @@ struct FastEval {
 #if !defined(__HIPCC__)
                 g_far_stats[1]++;
 #endif
-                for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && seen < a.depth; wbase -= 64) {
-                    uint64_t mask = bits_at(a.vbits, wbase);
+                far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
 #if !defined(__HIPCC__)
-                    g_far_stats[2]++;
+                    g_far_stats[3]++;
 #endif
-                    if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
-                    while (mask && seen < a.depth) {
-                        const uint32_t t = 63 - (uint32_t)clz64(mask);
-                        mask &= ~(1ull << t);
-                        const uint32_t sl = (uint32_t)(wbase + t);
-                        const uint32_t l = far_lcp(a, p, a0, a1, sl);
-#if !defined(__HIPCC__)
-                        g_far_stats[3]++;
-#endif
-                        if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
-                            const uint32_t q = a.epos[sl];
-                            uint32_t ro_hi, ro_mid;
-                            if (q >= kPre) {
-                                const uint32_t oq = a.cp[(size_t)((q - kPre) / kSub) * 256 + c];
-                                ro_hi = op_hi - oq;
-                                ro_mid = op_lo - oq;
-                            } else {
-                                ro_hi = op_hi - 1 - a.ORD[q];
-                                ro_mid = op_lo - 1 - a.ORD[q];
-                            }
-                            if (ro_hi > kRing - 1) { stop = true; break; }
-                            if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
-                            if (seen < a.lazy1 && l > fm1) fm1 = l;
-                            if (seen < a.lazy2 && l > fm2) fm2 = l;
+                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                    if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
+                        const uint32_t q = a.epos[sl];
+                        uint32_t ro_hi, ro_mid;
+                        if (q >= kPre) {
+                            const uint32_t sq = (q - kPre) / kSub;
+                            const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
+                            ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
+                            ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
+                        } else {
+                            ro_hi = op_hi - 1 - a.ORD[q];
+                            ro_mid = op_lo - 1 - a.ORD[q];
                         }
-                        seen++;
-                        if (l == kMaxLen) { stop = true; break; }
+                        if (ro_hi > kRing - 1) { stop = true; return false; }
+                        if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
+                        if (seen < a.lazy1 && l > fm1) fm1 = l;
+                        if (seen < a.lazy2 && l > fm2) fm2 = l;
                     }
-                }
+                    seen++;
+                    if (l == kMaxLen) { stop = true; return false; }
+                    return seen < a.depth;
+                });
                 a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
                 a.farsrc[i] = fsrc;
             }
@@ -728,22 +761,16 @@ struct FastSource {
             const uint32_t top = j - K;
             const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
             const uint64_t a0 = ldu64(a.win + p), a1 = ldu64(a.win + p + 8);
-            for (int64_t wbase = (int64_t)top - 64; wbase + 64 > (int64_t)lo2 && !stop && !found; wbase -= 64) {
-                uint64_t mask = bits_at(a.vbits, wbase);
-                if (wbase < (int64_t)lo2) mask &= ~0ull << (uint32_t)((int64_t)lo2 - wbase);
-                while (mask) {
-                    const uint32_t t = 63 - (uint32_t)clz64(mask);
-                    mask &= ~(1ull << t);
-                    const uint32_t sl = (uint32_t)(wbase + t);
-                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
-                    if (l >= kMinLen && (l >= L || l > best)) {
-                        const uint32_t q = a.epos[sl];
-                        if (op - 1 - a.ORD[q] > kRing - 1) { stop = true; break; }
-                        if (l >= L) { found = q; break; }
-                        best = l; bsrc = q;
-                    }
+            far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
+                const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                if (l >= kMinLen && (l >= L || l > best)) {
+                    const uint32_t q = a.epos[sl];
+                    if (op - 1 - a.ORD[q] > kRing - 1) { stop = true; return false; }
+                    if (l >= L) { found = q; return false; }
+                    best = l; bsrc = q;
                 }
-            }
+                return true;
+            });
         }
         if (found) { SRC[p] = found; return; }
         atom_add32(a.nchg, 1);

@@ -565,7 +565,7 @@ class StreamEncoder {
     // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
     void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys) {
         const uint8_t* win = dwin();
-        const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub;
+        const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
         be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
@@ -581,7 +581,7 @@ class StreamEncoder {
         a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_;
         a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
         a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
-        a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 4096; a.vbits = vbits_; a.kbits = kbits_; a.ev = fev_; a.bs = fbs_;
+        a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_; a.bs = fbs_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mf = fmf_; a.ef = fef_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = fnchg_;
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
@@ -598,6 +598,7 @@ class StreamEncoder {
             be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
             be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
             be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
+            be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             const size_t nn = (size_t)n + 264;
             be_.memset(fev_, 0, ((size_t)n + 8) * 4);
             be_.memset(ffarv_, 0, ((size_t)n + 8) * 4);
@@ -624,7 +625,7 @@ class StreamEncoder {
                 be_.timed_begin();
                 // far searches: the tile in its last round, and the tile in its second round
                 uint32_t fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;
-                static const int far_sched = getenv("ORZ_FAST_FARSCHED") ? atoi(getenv("ORZ_FAST_FARSCHED")) : 1;  // bit 0: last round, bit 1: second round
+                static const int far_sched = getenv("ORZ_FAST_FARSCHED") ? atoi(getenv("ORZ_FAST_FARSCHED")) : 3;  // bit 0: last round, bit 1: second round
                 if ((far_sched & 1) && step >= R && step - R < ntile) { fa0 = kPre + (step - R) * T; fa1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fa0 + T); }
                 if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, fa0, fa1, fb0, fb1});
@@ -639,6 +640,7 @@ class StreamEncoder {
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
                 be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1});
+                be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
                 be_.launch_waves(nc, CountWave{a, c0}, CountWave::lds_bytes());
                 be_.launch((size_t)nc * 256, FastPrefix{a, c0, c0 + nc});
                 stats.sweeps++;
@@ -654,6 +656,7 @@ class StreamEncoder {
             uint32_t nmem_last = 0;
             for (int pass = 0; pass < 200 && !done; pass++) {
                 be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
+                be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
                 be_.launch(n, MemberFlags32{fsbits_, n, f32_});
                 be_.exclusive_scan_u32(f32_, sc32_, n);
                 uint32_t x0, x1;
