@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     uint16_t* state = srstate + (size_t)c * kSrWords;
     for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = state[i]; idx[i] = state[kSyms + i]; }
     __syncthreads();
-    int v0 = val[lane], v1 = val[64 + lane];  // ranks 0..63 and 64..127 live in two registers
+    int v0 = val[lane], v1 = val[64 + lane], v2 = val[128 + lane];  // ranks 0..63, 64..127 and 128..191 live in three registers
     uint32_t cnt = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms] | ((uint32_t)state[2 * kSyms + 1] << 16)));
     uint32_t sum = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms + 2] | ((uint32_t)state[2 * kSyms + 3] << 16)));
     // reciprocals of the steady-state counts 327 + lane: floor(n / d) == mulhi(n, floor(2^32 / d) + 1) for n < 2^17
@@ -216,11 +216,13 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     auto get = [&](uint32_t r) -> uint32_t {
         if (r < 64) return (uint32_t)__builtin_amdgcn_readlane(v0, (int)r);
         if (r < 128) return (uint32_t)__builtin_amdgcn_readlane(v1, (int)(r - 64));
+        if (r < 192) return (uint32_t)__builtin_amdgcn_readlane(v2, (int)(r - 128));
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)val[r]);
     };
     auto put = [&](uint32_t r, uint32_t x) {
         if (r < 64) v0 = orz_writelane(v0, x, r);
         else if (r < 128) v1 = orz_writelane(v1, x, r - 64);
+        else if (r < 192) v2 = orz_writelane(v2, x, r - 128);
         else { val[r] = (uint16_t)x; idx[x] = (uint16_t)r; }
     };
     for (uint32_t j0 = a; j0 < e; j0 += 64) {
@@ -235,10 +237,18 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             const bool fast = (int32_t)i >= 0;
             if (__builtin_expect(!fast, 0)) {
                 const uint32_t i1 = orz_ff1(__ballot(v1 == (int)v));
-                i = (int32_t)i1 >= 0 ? 64 + i1 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
+                if ((int32_t)i1 >= 0) i = 64 + i1;
+                else {
+                    const uint32_t i2 = orz_ff1(__ballot(v2 == (int)v));
+                    i = (int32_t)i2 >= 0 ? 128 + i2 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
+                }
                 if ((int32_t)iu < 0) {
                     const uint32_t u1 = orz_ff1(__ballot(v1 == (int)vun));
-                    iu = (int32_t)u1 >= 0 ? 64 + u1 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
+                    if ((int32_t)u1 >= 0) iu = 64 + u1;
+                    else {
+                        const uint32_t u2 = orz_ff1(__ballot(v2 == (int)vun));
+                        iu = (int32_t)u2 >= 0 ? 128 + u2 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
+                    }
                 }
             }
             if (__builtin_expect(cnt > kSyms, 0)) {  // src/symrank.rs:63-66
@@ -280,11 +290,13 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         }
         if (j0 + lane < e) grank[j0 + lane] = (uint16_t)outr;
     }
-    // tables back to HBM: the registers' 128 ranks first
+    // tables back to HBM: the registers' 192 ranks first
     val[lane] = (uint16_t)v0;
     val[64 + lane] = (uint16_t)v1;
+    val[128 + lane] = (uint16_t)v2;
     idx[v0] = (uint16_t)lane;
     idx[v1] = (uint16_t)(64 + lane);
+    idx[v2] = (uint16_t)(128 + lane);
     __syncthreads();
     for (uint32_t i = lane; i < kSyms; i += 64) { state[i] = val[i]; state[kSyms + i] = idx[i]; }
     if (lane == 0) {
