@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the emulation backend with AddressSanitizer + UBSan and runs the kernel bodies under it:
-#   encoder_check.py  a few inputs through the whole encode pipeline (parse waves on the SIMT emulator), vs the oracle
+#   encoder_check.py  a few inputs through the whole encode pipeline in both parse modes (wave kernels on the SIMT emulator), vs the oracle
 #   decoder_fuzz.py   300 corrupted member containers through the device decoder's kernel body
 # Not part of the pytest tiers (slow, needs libasan); run by hand:  bash tests/sanitize/run.sh
 set -e

@@ -175,3 +175,45 @@ def test_rebuilt_encoder_does_not_replay_a_stale_graph(oracle):
     assert a == a2
     assert oracle.decode(a)[0] == data and oracle.decode(b)[0] == data
     assert c == oracle.encode(data, 1)
+
+
+def test_object_level_encoder_and_callbacks_in_fast_mode(oracle):
+    """the drop-in seam in its default (fast) mode: LZEncoder::encode chunk by chunk + forward exactly as orz::encode drives
+    it (src/lib.rs:72-84), and the Read/Write callbacks API -- both streams decode with the oracle's decoder"""
+    import ctypes
+    import io
+
+    import orz_amd
+
+    B, P, SENT = (1 << 25) - 1, ((1 << 25) - 1) // 2, 480
+    data = _data.mixed(17_500_000, seed=31)  # one full block + a short one, more than one chunk in the first
+    cfg = orz_amd.cfg_for_level(0)
+    window = (ctypes.c_uint8 * (B + 2 * SENT))()
+    enc = orz_amd.LZEncoder(device=0)
+    stream = bytearray()
+    off = 0
+    while off < len(data):
+        take = min(B - P, len(data) - off)
+        ctypes.memmove(ctypes.addressof(window) + SENT + P, data[off:off + take], take)
+        spos, sbuf_len = P, P + take
+        while spos < sbuf_len:
+            spos, chunk = enc.encode(cfg, window, sbuf_len, spos)
+            t = len(chunk)
+            while t >= 128:
+                stream.append(128 + t % 128)
+                t //= 128
+            stream.append(t)
+            stream += chunk
+        off += take
+        ctypes.memmove(ctypes.addressof(window) + SENT, ctypes.addressof(window) + SENT + (B - P), P)
+        enc.forward(B - P)
+    stream.append(0)
+    enc.close()
+    assert oracle.decode(bytes(stream))[0] == data
+    ref = len(oracle.encode(data, 0))
+    assert abs(len(stream) - ref) <= 0.03 * ref
+
+    small = _data.text(700_000, seed=71)
+    src, dst = io.BytesIO(small), io.BytesIO()
+    orz_amd.encode(src, dst, orz_amd.cfg_for_level(1))
+    assert oracle.decode(dst.getvalue())[0] == small
