@@ -225,17 +225,159 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         else if (r < 192) v2 = orz_writelane(v2, x, r - 128);
         else { val[r] = (uint16_t)x; idx[x] = (uint16_t)r; }
     };
+    // Per-lane move targets of rank `lane` for the current quotient q = floor(avg rank / 16): the serial chain then
+    // fetches next_i / ni1 with two v_readlane instead of nine dependent scalar ops.  q moves rarely; the straight
+    // loop below leaves to the general code when it does (and for ranks >= 192, the count rescale, the warm-up counts).
+    int nxt0 = 0, n1t0 = 0;
+    uint32_t qtab = 0xffffffffu;  // no quotient reaches this: the first item goes through the general code and builds the tables
+    auto rebuild = [&](uint32_t q) {
+        qtab = q;
+        const uint32_t dec = (lane >> 4) + q, half = lane >> 1;
+        uint32_t nx = lane > dec ? lane - dec : 0;
+        nx = nx > half ? nx : half;
+        nxt0 = (int)nx;
+        n1t0 = (int)(nx + ((lane - nx) >> 1));
+    };
     for (uint32_t j0 = a; j0 < e; j0 += 64) {
         const int items = j0 + lane < e ? (int)gsym[j0 + lane] : 0;
-        const uint32_t nthis = e - j0 < 64 ? e - j0 : 64;
-        int outr = 0;
-        for (uint32_t k = 0; k < nthis; k++) {
-            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane(items, (int)k);
-            const uint32_t v = g & 0xffff, vun = g >> 16;
+        const int itv = items & 0xffff, itu = (int)((uint32_t)items >> 16);
+        const uint32_t nthis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e - j0 < 64 ? e - j0 : 64));
+        int vi = 0, vu = 0;  // lane k: rank of item k's symbol / of its excluded symbol (0xffffffff = behind the symbol's)
+        uint32_t k = 0;
+        while (k < nthis) {
+            {   // items whose symbol sits in the 192 register-resident ranks, with 327 <= count <= 390 and an unchanged quotient:
+                // src/symrank.rs:58-100 as straight lines (ranks 0..63: 35 instructions an item).  Wait states between a
+                // VALU-written SGPR and its use as operand (2) / lane select (4) are covered by the instruction order; the
+                // assembler adds none inside inline asm.  Lane selects above 63 address lane (select & 63).
+                uint32_t g, u, i, j, t, m, s2, q2, x, y, pv, rv;
+#define ORZ_ROT(Ri, Ry, Rx)                                                                                              \
+    "v_readlane_b32 %[pv], %[" Ry "], %[y]\n\tv_readlane_b32 %[rv], %[" Rx "], %[x]\n\ts_mov_b32 m0, %[i]\n\t"                \
+    "v_writelane_b32 %[" Ri "], %[pv], m0\n\ts_mov_b32 m0, %[y]\n\tv_writelane_b32 %[" Ry "], %[rv], m0\n\t"                 \
+    "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[g], m0\n\t"
+#define ORZ_QCHK                                                                                                         \
+    "s_add_u32 %[s2], %[sum], %[i]\n\ts_lshr_b32 %[q2], %[s2], 4\n\ts_mul_hi_u32 %[q2], %[q2], %[m]\n\t"                   \
+    "s_cmp_lg_u32 %[q2], %[q]\n\ts_cbranch_scc1 9f\n\t"
+#define ORZ_COMMIT                                                                                                       \
+    "s_mov_b32 %[sum], %[s2]\n\ts_add_u32 %[cnt], %[cnt], 1\n\ts_mov_b32 m0, %[k]\n\t"                                      \
+    "v_writelane_b32 %[vi], %[i], m0\n\tv_writelane_b32 %[vu], %[j], m0\n\t"
+                asm volatile(
+                    "1:\n\t"
+                    "v_readlane_b32 %[g], %[itv], %[k]\n\t"
+                    "v_readlane_b32 %[u], %[itu], %[k]\n\t"
+                    "s_sub_u32 %[t], %[cnt], 0x146\n\t"
+                    "s_cmp_gt_u32 %[t], 63\n\t"
+                    "s_cbranch_scc1 9f\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[g], %[v0]\n\t"
+                    "s_ff1_i32_b64 %[i], vcc\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[u], %[v0]\n\t"
+                    "s_ff1_i32_b64 %[j], vcc\n\t"
+                    "v_readlane_b32 %[m], %[mreg], %[t]\n\t"
+                    "s_cmp_lt_i32 %[i], 0\n\t"
+                    "s_cbranch_scc1 4f\n\t"
+                    // ranks 0..63: move targets from the per-lane tables
+                    ORZ_QCHK
+                    "v_readlane_b32 %[y], %[n1t], %[i]\n\t"
+                    "v_readlane_b32 %[x], %[nxt], %[i]\n\t"
+                    ORZ_COMMIT
+                    ORZ_ROT("v0", "v0", "v0")
+                    "8:\n\t"
+                    "s_add_u32 %[k], %[k], 1\n\t"
+                    "s_cmp_lt_u32 %[k], %[nthis]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "s_branch 9f\n\t"
+                    // ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register
+                    "4:\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[g], %[v1]\n\t"
+                    "s_ff1_i32_b64 %[i], vcc\n\t"
+                    "s_cmp_lt_i32 %[i], 0\n\t"
+                    "s_cbranch_scc1 5f\n\t"
+                    "s_add_u32 %[i], %[i], 64\n\t"
+                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cbranch_scc0 6f\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[u], %[v1]\n\t"
+                    "s_ff1_i32_b64 %[j], vcc\n\t"
+                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cbranch_scc1 6f\n\t"
+                    "s_add_u32 %[j], %[j], 64\n\t"
+                    "s_branch 6f\n\t"
+                    // ranks 128..191 (beyond: the general code, nothing changed so far)
+                    "5:\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[g], %[v2]\n\t"
+                    "s_ff1_i32_b64 %[i], vcc\n\t"
+                    "s_cmp_lt_i32 %[i], 0\n\t"
+                    "s_cbranch_scc1 9f\n\t"
+                    "s_add_u32 %[i], %[i], 0x80\n\t"
+                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cbranch_scc0 6f\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[u], %[v1]\n\t"
+                    "s_ff1_i32_b64 %[j], vcc\n\t"
+                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cbranch_scc0 7f\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[u], %[v2]\n\t"
+                    "s_ff1_i32_b64 %[j], vcc\n\t"
+                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cbranch_scc1 6f\n\t"
+                    "s_add_u32 %[j], %[j], 0x80\n\t"
+                    "s_branch 6f\n\t"
+                    "7:\n\t"
+                    "s_add_u32 %[j], %[j], 64\n\t"
+                    "6:\n\t"
+                    ORZ_QCHK
+                    // x = max(sat(i - i/16 - q), i/2), y = x + (i - x)/2
+                    "s_lshr_b32 %[x], %[i], 4\n\t"
+                    "s_add_u32 %[x], %[x], %[q2]\n\t"
+                    "s_sub_u32 %[x], %[i], %[x]\n\t"
+                    "s_cselect_b32 %[x], 0, %[x]\n\t"
+                    "s_lshr_b32 %[y], %[i], 1\n\t"
+                    "s_max_u32 %[x], %[x], %[y]\n\t"
+                    "s_sub_u32 %[y], %[i], %[x]\n\t"
+                    "s_lshr_b32 %[y], %[y], 1\n\t"
+                    "s_add_u32 %[y], %[y], %[x]\n\t"
+                    ORZ_COMMIT
+                    "s_cmp_lt_u32 %[i], 0x80\n\t"
+                    "s_cbranch_scc0 20f\n\t"
+                    "s_cmp_lt_u32 %[x], 64\n\t"
+                    "s_cbranch_scc1 11f\n\t"
+                    ORZ_ROT("v1", "v1", "v1")
+                    "s_branch 8b\n\t"
+                    "11:\n\t"
+                    "s_cmp_lt_u32 %[y], 64\n\t"
+                    "s_cbranch_scc1 12f\n\t"
+                    ORZ_ROT("v1", "v1", "v0")
+                    "s_branch 8b\n\t"
+                    "12:\n\t"
+                    ORZ_ROT("v1", "v0", "v0")
+                    "s_branch 8b\n\t"
+                    "20:\n\t"  // i >= 128: x >= i/2 >= 64
+                    "s_cmp_lt_u32 %[x], 0x80\n\t"
+                    "s_cbranch_scc1 21f\n\t"
+                    ORZ_ROT("v2", "v2", "v2")
+                    "s_branch 8b\n\t"
+                    "21:\n\t"
+                    "s_cmp_lt_u32 %[y], 0x80\n\t"
+                    "s_cbranch_scc1 22f\n\t"
+                    ORZ_ROT("v2", "v2", "v1")
+                    "s_branch 8b\n\t"
+                    "22:\n\t"
+                    ORZ_ROT("v2", "v1", "v1")
+                    "s_branch 8b\n\t"
+                    "9:"
+                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [k] "+s"(k), [cnt] "+s"(cnt),
+                      [sum] "+s"(sum), [g] "=&s"(g), [u] "=&s"(u), [i] "=&s"(i), [j] "=&s"(j), [t] "=&s"(t), [m] "=&s"(m),
+                      [s2] "=&s"(s2), [q2] "=&s"(q2), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv)
+                    : [itv] "v"(itv), [itu] "v"(itu), [mreg] "v"(mreg), [n1t] "v"(n1t0), [nxt] "v"(nxt0), [q] "s"(qtab), [nthis] "s"(nthis)
+                    : "vcc", "scc", "m0");
+#undef ORZ_ROT
+#undef ORZ_QCHK
+#undef ORZ_COMMIT
+            }
+            if (k >= nthis) break;
+            // the general item
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(itv, (int)k), vun = (uint32_t)__builtin_amdgcn_readlane(itu, (int)k);
             uint32_t i = orz_ff1(__ballot(v0 == (int)v));
             uint32_t iu = orz_ff1(__ballot(v0 == (int)vun));  // 0xffffffff = not among the first 64: behind any of those
             const bool fast = (int32_t)i >= 0;
-            if (__builtin_expect(!fast, 0)) {
+            if (!fast) {
                 const uint32_t i1 = orz_ff1(__ballot(v1 == (int)v));
                 if ((int32_t)i1 >= 0) i = 64 + i1;
                 else {
@@ -261,13 +403,14 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             uint32_t q;
             if (__builtin_expect(cnt >= 327, 1)) q = __umulhi(n16, (uint32_t)__builtin_amdgcn_readlane(mreg, (int)(cnt - 327)));
             else q = (n16 / cnt) & 0xffff;
+            if (q != qtab) rebuild(q);
             uint32_t next_i = orz_sub_sat(i, (i >> 4) + q);
             const uint32_t half = i >> 1;
             next_i = next_i > half ? next_i : half;
             const uint32_t ni1 = next_i + ((i - next_i) >> 1);
             // value[i] <- value[ni1] <- value[next_i] <- v  (for a one-step move ni1 == next_i and this is the swap;
             // for no move all three coincide and nothing changes: one straight line covers src/symrank.rs:75-96)
-            if (__builtin_expect(fast, 1)) {  // everything involved sits in the first register
+            if (fast) {  // everything involved sits in the first register
                 const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)ni1);
                 const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)next_i);
                 v0 = orz_writelane(v0, nv1, i);
@@ -285,9 +428,13 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 if (ni1 != next_i) put(ni1, nv2);
                 put(next_i, v);
             }
-            const uint32_t r = i == iu ? kSyms - 1 : i - (i > iu);
-            outr = orz_writelane(outr, r, k);
+            vi = orz_writelane(vi, i, k);
+            vu = orz_writelane(vu, iu, k);
+            k++;
         }
+        // src/symrank.rs:98-100: the excluded symbol's rank is skipped; the symbol itself being the excluded one codes as the last rank
+        const uint32_t ri = (uint32_t)vi, ru = (uint32_t)vu;
+        const uint32_t outr = ri == ru ? kSyms - 1 : ri - (ri > ru);
         if (j0 + lane < e) grank[j0 + lane] = (uint16_t)outr;
     }
     // tables back to HBM: the registers' 192 ranks first
