@@ -225,115 +225,149 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         else if (r < 192) v2 = orz_writelane(v2, x, r - 128);
         else { val[r] = (uint16_t)x; idx[x] = (uint16_t)r; }
     };
-    // Per-lane move targets of rank `lane` for the current quotient q = floor(avg rank / 16): the serial chain then
-    // fetches next_i / ni1 with two v_readlane instead of nine dependent scalar ops.  q moves rarely; the straight
-    // loop below leaves to the general code when it does (and for ranks >= 192, the count rescale, the warm-up counts).
-    int nxt0 = 0, n1t0 = 0;
+    // Per-lane move targets of ranks lane, 64 + lane, 128 + lane for the current quotient q = floor(avg rank / 16): the
+    // serial chain then fetches next_i / ni1 with two v_readlane instead of nine dependent scalar ops.  q moves rarely;
+    // the straight loop below leaves to the general code when it does (and for ranks >= 192 and the warm-up counts).
+    int nxt0 = 0, n1t0 = 0, nxt1 = 0, n1t1 = 0, nxt2 = 0, n1t2 = 0;
     uint32_t qtab = 0xffffffffu;  // no quotient reaches this: the first item goes through the general code and builds the tables
+    auto targets = [](uint32_t r, uint32_t q, int& nxt, int& n1t) {
+        const uint32_t dec = (r >> 4) + q, half = r >> 1;
+        uint32_t nx = r > dec ? r - dec : 0;
+        nx = nx > half ? nx : half;
+        nxt = (int)nx;
+        n1t = (int)(nx + ((r - nx) >> 1));
+    };
     auto rebuild = [&](uint32_t q) {
         qtab = q;
-        const uint32_t dec = (lane >> 4) + q, half = lane >> 1;
-        uint32_t nx = lane > dec ? lane - dec : 0;
-        nx = nx > half ? nx : half;
-        nxt0 = (int)nx;
-        n1t0 = (int)(nx + ((lane - nx) >> 1));
+        targets(lane, q, nxt0, n1t0);
+        targets(64 + lane, q, nxt1, n1t1);
+        targets(128 + lane, q, nxt2, n1t2);
     };
+    // a batch = up to 64 items, top-aligned in the lanes: item n of nthis sits in lane 64 - nthis + n, so that the loop
+    // counter kb = n - nthis (mod 2^32) selects its lane with its low six bits and ends the loop with its carry
+    auto load_batch = [&](uint32_t j0) -> int {
+        if (j0 >= e) return 0;
+        const uint32_t off = e - j0 < 64 ? 64 - (e - j0) : 0;
+        return lane >= off ? (int)gsym[j0 + lane - off] : 0;
+    };
+    int items = load_batch(a);
     for (uint32_t j0 = a; j0 < e; j0 += 64) {
-        const int items = j0 + lane < e ? (int)gsym[j0 + lane] : 0;
+        const int items_next = load_batch(j0 + 64);  // in flight while this batch runs
         const int itv = items & 0xffff, itu = (int)((uint32_t)items >> 16);
         const uint32_t nthis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e - j0 < 64 ? e - j0 : 64));
-        int vi = 0, vu = 0;  // lane k: rank of item k's symbol / of its excluded symbol (0xffffffff = behind the symbol's)
-        uint32_t k = 0;
-        while (k < nthis) {
-            {   // items whose symbol sits in the 192 register-resident ranks, with 327 <= count <= 390 and an unchanged quotient:
-                // src/symrank.rs:58-100 as straight lines (ranks 0..63: 35 instructions an item).  Wait states between a
-                // VALU-written SGPR and its use as operand (2) / lane select (4) are covered by the instruction order; the
-                // assembler adds none inside inline asm.  Lane selects above 63 address lane (select & 63).
-                uint32_t g, u, i, j, t, m, s2, q2, x, y, pv, rv;
+        int vi = 0, vu = 0;  // per lane: rank of the item's symbol / of its excluded symbol (0xffffffff = behind the symbol's)
+        uint32_t kb = 0u - nthis;
+        while (kb != 0) {
+            {   // items whose symbol sits in the 192 register-resident ranks, with count >= 326 and an unchanged quotient:
+                // src/symrank.rs:58-100 as straight lines (ranks 0..63: 33 instructions an item).  Wait states between a
+                // VALU-written SGPR and its use as operand (2) / lane select (4) are covered by the instruction order (the
+                // assembler adds none inside inline asm), and independent work sits between a VALU result and the scalar
+                // instruction consuming it (~10 ns each otherwise).  Lane selects above 63 address lane (select & 63).
+                uint32_t g, u, i, j, t, m, q2, x, y, pv, rv;
+                uint64_t ma, mb;
+                kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kb);  // (uniform already; pins it to an SGPR for the asm operand)
 #define ORZ_ROT(Ri, Ry, Rx)                                                                                              \
     "v_readlane_b32 %[pv], %[" Ry "], %[y]\n\tv_readlane_b32 %[rv], %[" Rx "], %[x]\n\ts_mov_b32 m0, %[i]\n\t"                \
     "v_writelane_b32 %[" Ri "], %[pv], m0\n\ts_mov_b32 m0, %[y]\n\tv_writelane_b32 %[" Ry "], %[rv], m0\n\t"                 \
     "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[g], m0\n\t"
-#define ORZ_QCHK                                                                                                         \
-    "s_add_u32 %[s2], %[sum], %[i]\n\ts_lshr_b32 %[q2], %[s2], 4\n\ts_mul_hi_u32 %[q2], %[q2], %[m]\n\t"                   \
-    "s_cmp_lg_u32 %[q2], %[q]\n\ts_cbranch_scc1 9f\n\t"
-#define ORZ_COMMIT                                                                                                       \
-    "s_mov_b32 %[sum], %[s2]\n\ts_add_u32 %[cnt], %[cnt], 1\n\ts_mov_b32 m0, %[k]\n\t"                                      \
-    "v_writelane_b32 %[vi], %[i], m0\n\tv_writelane_b32 %[vu], %[j], m0\n\t"
+#define ORZ_QCHK(L)                                                                                                       \
+    "s_add_u32 %[sum], %[sum], %[i]\n\ts_lshr_b32 %[q2], %[sum], 4\n\ts_mul_hi_u32 %[q2], %[q2], %[m]\n\t"                 \
+    "s_cmp_lg_u32 %[q2], %[q]\n\ts_cbranch_scc1 " L "\n\t"
                 asm volatile(
                     "1:\n\t"
-                    "v_readlane_b32 %[g], %[itv], %[k]\n\t"
-                    "v_readlane_b32 %[u], %[itu], %[k]\n\t"
+                    "v_readlane_b32 %[g], %[itv], %[kb]\n\t"
+                    "v_readlane_b32 %[u], %[itu], %[kb]\n\t"
                     "s_sub_u32 %[t], %[cnt], 0x146\n\t"
-                    "s_cmp_gt_u32 %[t], 63\n\t"
-                    "s_cbranch_scc1 9f\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[g], %[v0]\n\t"
-                    "s_ff1_i32_b64 %[i], vcc\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[u], %[v0]\n\t"
-                    "s_ff1_i32_b64 %[j], vcc\n\t"
+                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v0]\n\t"
+                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v0]\n\t"
                     "v_readlane_b32 %[m], %[mreg], %[t]\n\t"
+                    "s_cmp_gt_u32 %[t], 63\n\t"
+                    "s_cbranch_scc1 30f\n\t"
+                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
+                    "s_ff1_i32_b64 %[j], %[mb]\n\t"
                     "s_cmp_lt_i32 %[i], 0\n\t"
                     "s_cbranch_scc1 4f\n\t"
-                    // ranks 0..63: move targets from the per-lane tables
-                    ORZ_QCHK
-                    "v_readlane_b32 %[y], %[n1t], %[i]\n\t"
-                    "v_readlane_b32 %[x], %[nxt], %[i]\n\t"
-                    ORZ_COMMIT
-                    ORZ_ROT("v0", "v0", "v0")
+                    // ranks 0..63
+                    ORZ_QCHK("31f")
+                    "v_readlane_b32 %[y], %[n1t0], %[i]\n\t"
+                    "v_readlane_b32 %[x], %[nxt0], %[i]\n\t"
+                    "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                    "s_mov_b32 m0, %[kb]\n\t"
+                    "v_writelane_b32 %[vi], %[i], m0\n\t"
+                    "v_readlane_b32 %[pv], %[v0], %[y]\n\t"
+                    "v_readlane_b32 %[rv], %[v0], %[x]\n\t"
+                    "v_writelane_b32 %[vu], %[j], m0\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "v_writelane_b32 %[v0], %[pv], m0\n\t"
+                    "s_mov_b32 m0, %[y]\n\t"
+                    "v_writelane_b32 %[v0], %[rv], m0\n\t"
+                    "s_mov_b32 m0, %[x]\n\t"
+                    "v_writelane_b32 %[v0], %[g], m0\n\t"
                     "8:\n\t"
-                    "s_add_u32 %[k], %[k], 1\n\t"
-                    "s_cmp_lt_u32 %[k], %[nthis]\n\t"
-                    "s_cbranch_scc1 1b\n\t"
+                    "s_add_u32 %[kb], %[kb], 1\n\t"
+                    "s_cbranch_scc0 1b\n\t"
+                    "s_branch 9f\n\t"
+                    // count outside 326..389: rescale (src/symrank.rs:63-66) or, in the warm-up, the general code
+                    "30:\n\t"
+                    "s_cmp_lt_u32 %[cnt], 0x146\n\t"
+                    "s_cbranch_scc1 9f\n\t"
+                    "s_mul_i32 %[cnt], %[cnt], 9\n\t"
+                    "s_mul_hi_u32 %[cnt], %[cnt], 0xcccccccd\n\t"
+                    "s_lshr_b32 %[cnt], %[cnt], 3\n\t"
+                    "s_mul_i32 %[sum], %[sum], 9\n\t"
+                    "s_mul_hi_u32 %[sum], %[sum], 0xcccccccd\n\t"
+                    "s_lshr_b32 %[sum], %[sum], 3\n\t"
+                    "s_branch 1b\n\t"
+                    // the quotient moved: undo, the general code rebuilds the tables
+                    "31:\n\t"
+                    "s_sub_u32 %[sum], %[sum], %[i]\n\t"
                     "s_branch 9f\n\t"
                     // ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register
                     "4:\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[g], %[v1]\n\t"
-                    "s_ff1_i32_b64 %[i], vcc\n\t"
+                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v1]\n\t"
+                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v1]\n\t"
+                    "s_nop 1\n\t"
+                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
+                    "s_ff1_i32_b64 %[t], %[mb]\n\t"
                     "s_cmp_lt_i32 %[i], 0\n\t"
                     "s_cbranch_scc1 5f\n\t"
+                    "v_readlane_b32 %[y], %[n1t1], %[i]\n\t"
+                    "v_readlane_b32 %[x], %[nxt1], %[i]\n\t"
                     "s_add_u32 %[i], %[i], 64\n\t"
                     "s_cmp_lt_i32 %[j], 0\n\t"
                     "s_cbranch_scc0 6f\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[u], %[v1]\n\t"
-                    "s_ff1_i32_b64 %[j], vcc\n\t"
-                    "s_cmp_lt_i32 %[j], 0\n\t"
+                    "s_cmp_lt_i32 %[t], 0\n\t"
                     "s_cbranch_scc1 6f\n\t"
-                    "s_add_u32 %[j], %[j], 64\n\t"
+                    "s_add_u32 %[j], %[t], 64\n\t"
                     "s_branch 6f\n\t"
                     // ranks 128..191 (beyond: the general code, nothing changed so far)
                     "5:\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[g], %[v2]\n\t"
-                    "s_ff1_i32_b64 %[i], vcc\n\t"
+                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v2]\n\t"
+                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v2]\n\t"
+                    "s_nop 1\n\t"
+                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
+                    "s_ff1_i32_b64 %[pv], %[mb]\n\t"
                     "s_cmp_lt_i32 %[i], 0\n\t"
                     "s_cbranch_scc1 9f\n\t"
+                    "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"
+                    "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"
                     "s_add_u32 %[i], %[i], 0x80\n\t"
                     "s_cmp_lt_i32 %[j], 0\n\t"
                     "s_cbranch_scc0 6f\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[u], %[v1]\n\t"
-                    "s_ff1_i32_b64 %[j], vcc\n\t"
-                    "s_cmp_lt_i32 %[j], 0\n\t"
-                    "s_cbranch_scc0 7f\n\t"
-                    "v_cmp_eq_u32_e32 vcc, %[u], %[v2]\n\t"
-                    "s_ff1_i32_b64 %[j], vcc\n\t"
-                    "s_cmp_lt_i32 %[j], 0\n\t"
-                    "s_cbranch_scc1 6f\n\t"
-                    "s_add_u32 %[j], %[j], 0x80\n\t"
+                    "s_cmp_lt_i32 %[t], 0\n\t"
+                    "s_cbranch_scc1 7f\n\t"
+                    "s_add_u32 %[j], %[t], 64\n\t"
                     "s_branch 6f\n\t"
                     "7:\n\t"
-                    "s_add_u32 %[j], %[j], 64\n\t"
+                    "s_cmp_lt_i32 %[pv], 0\n\t"
+                    "s_cbranch_scc1 6f\n\t"
+                    "s_add_u32 %[j], %[pv], 0x80\n\t"
                     "6:\n\t"
-                    ORZ_QCHK
-                    // x = max(sat(i - i/16 - q), i/2), y = x + (i - x)/2
-                    "s_lshr_b32 %[x], %[i], 4\n\t"
-                    "s_add_u32 %[x], %[x], %[q2]\n\t"
-                    "s_sub_u32 %[x], %[i], %[x]\n\t"
-                    "s_cselect_b32 %[x], 0, %[x]\n\t"
-                    "s_lshr_b32 %[y], %[i], 1\n\t"
-                    "s_max_u32 %[x], %[x], %[y]\n\t"
-                    "s_sub_u32 %[y], %[i], %[x]\n\t"
-                    "s_lshr_b32 %[y], %[y], 1\n\t"
-                    "s_add_u32 %[y], %[y], %[x]\n\t"
-                    ORZ_COMMIT
+                    ORZ_QCHK("31b")
+                    "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                    "s_mov_b32 m0, %[kb]\n\t"
+                    "v_writelane_b32 %[vi], %[i], m0\n\t"
+                    "v_writelane_b32 %[vu], %[j], m0\n\t"
                     "s_cmp_lt_u32 %[i], 0x80\n\t"
                     "s_cbranch_scc0 20f\n\t"
                     "s_cmp_lt_u32 %[x], 64\n\t"
@@ -362,17 +396,18 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_ROT("v2", "v1", "v1")
                     "s_branch 8b\n\t"
                     "9:"
-                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [k] "+s"(k), [cnt] "+s"(cnt),
+                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [cnt] "+s"(cnt),
                       [sum] "+s"(sum), [g] "=&s"(g), [u] "=&s"(u), [i] "=&s"(i), [j] "=&s"(j), [t] "=&s"(t), [m] "=&s"(m),
-                      [s2] "=&s"(s2), [q2] "=&s"(q2), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv)
-                    : [itv] "v"(itv), [itu] "v"(itu), [mreg] "v"(mreg), [n1t] "v"(n1t0), [nxt] "v"(nxt0), [q] "s"(qtab), [nthis] "s"(nthis)
-                    : "vcc", "scc", "m0");
+                      [q2] "=&s"(q2), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
+                    : [itv] "v"(itv), [itu] "v"(itu), [mreg] "v"(mreg), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1),
+                      [nxt1] "v"(nxt1), [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [q] "s"(qtab)
+                    : "scc", "m0");
 #undef ORZ_ROT
 #undef ORZ_QCHK
-#undef ORZ_COMMIT
             }
-            if (k >= nthis) break;
+            if (kb == 0) break;
             // the general item
+            const uint32_t k = kb & 63;
             const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(itv, (int)k), vun = (uint32_t)__builtin_amdgcn_readlane(itu, (int)k);
             uint32_t i = orz_ff1(__ballot(v0 == (int)v));
             uint32_t iu = orz_ff1(__ballot(v0 == (int)vun));  // 0xffffffff = not among the first 64: behind any of those
@@ -402,27 +437,15 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             const uint32_t n16 = sum >> 4;
             uint32_t q;
             if (__builtin_expect(cnt >= 327, 1)) q = __umulhi(n16, (uint32_t)__builtin_amdgcn_readlane(mreg, (int)(cnt - 327)));
-            else q = (n16 / cnt) & 0xffff;
+            else q = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n16 / cnt) & 0xffff));  // (the division runs on the vector unit)
             if (q != qtab) rebuild(q);
             uint32_t next_i = orz_sub_sat(i, (i >> 4) + q);
             const uint32_t half = i >> 1;
             next_i = next_i > half ? next_i : half;
             const uint32_t ni1 = next_i + ((i - next_i) >> 1);
             // value[i] <- value[ni1] <- value[next_i] <- v  (for a one-step move ni1 == next_i and this is the swap;
-            // for no move all three coincide and nothing changes: one straight line covers src/symrank.rs:75-96)
-            if (fast) {  // everything involved sits in the first register
-                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)ni1);
-                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(v0, (int)next_i);
-                v0 = orz_writelane(v0, nv1, i);
-                v0 = orz_writelane(v0, nv2, ni1);
-                v0 = orz_writelane(v0, v, next_i);
-            } else if (i < 128 && next_i >= 64) {  // everything involved sits in the second register
-                const uint32_t nv1 = (uint32_t)__builtin_amdgcn_readlane(v1, (int)(ni1 - 64));
-                const uint32_t nv2 = (uint32_t)__builtin_amdgcn_readlane(v1, (int)(next_i - 64));
-                v1 = orz_writelane(v1, nv1, i - 64);
-                v1 = orz_writelane(v1, nv2, ni1 - 64);
-                v1 = orz_writelane(v1, v, next_i - 64);
-            } else if (i != next_i) {
+            // for no move all three coincide and nothing changes: src/symrank.rs:75-96)
+            if (i != next_i) {
                 const uint32_t nv1 = get(ni1), nv2 = get(next_i);
                 put(i, nv1);
                 if (ni1 != next_i) put(ni1, nv2);
@@ -430,12 +453,14 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             }
             vi = orz_writelane(vi, i, k);
             vu = orz_writelane(vu, iu, k);
-            k++;
+            kb++;
         }
         // src/symrank.rs:98-100: the excluded symbol's rank is skipped; the symbol itself being the excluded one codes as the last rank
         const uint32_t ri = (uint32_t)vi, ru = (uint32_t)vu;
         const uint32_t outr = ri == ru ? kSyms - 1 : ri - (ri > ru);
-        if (j0 + lane < e) grank[j0 + lane] = (uint16_t)outr;
+        const uint32_t off = 64 - nthis;
+        if (lane >= off) grank[j0 + lane - off] = (uint16_t)outr;
+        items = items_next;
     }
     // tables back to HBM: the registers' 192 ranks first
     val[lane] = (uint16_t)v0;

@@ -11,6 +11,9 @@ int main(int argc, char** argv) {
     uint32_t n; fread(&n, 4, 1, f);
     std::vector<uint32_t> gsym(n), rstart(513); std::vector<uint16_t> state(512 * kSrWords), want(n), got(n);
     fread(gsym.data(), 4, n, f); fread(rstart.data(), 4, 513, f); fread(state.data(), 2, state.size(), f); fread(want.data(), 2, n, f);
+    // optional: replace every context's items by a cycle over the N most frequent symbols (path timing: N <= 40 stays in ranks 0..63, ~100 in 64..127, ...)
+    const int cyc = argc > 3 && !strcmp(argv[2], "cyc") ? atoi(argv[3]) : 0;
+    if (cyc) for (int c = 0; c < 512; c++) for (uint32_t j = rstart[c]; j < rstart[c + 1]; j++) gsym[j] = state[(size_t)c * kSrWords + (j - rstart[c]) % cyc] | (388u << 16);
     uint32_t *dg, *dr; uint16_t *ds, *dk;
     hipMalloc(&dg, n * 4); hipMalloc(&dr, 513 * 4); hipMalloc(&ds, state.size() * 2); hipMalloc(&dk, n * 2);
     hipMemcpy(dg, gsym.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dr, rstart.data(), 513 * 4, hipMemcpyHostToDevice);
@@ -27,5 +30,5 @@ int main(int argc, char** argv) {
     size_t bad = 0; for (uint32_t i = 0; i < n; i++) bad += got[i] != want[i];
     uint32_t hot = 0; for (int c = 0; c < 512; c++) if (rstart[c + 1] - rstart[c] > hot) hot = rstart[c + 1] - rstart[c];
     printf("items %u hottest %u  kernel %.2f ms  = %.1f ns per item of the hottest context  mismatches %zu\n", n, hot, best, best * 1e6 / hot, bad);
-    return bad != 0;
+    return !cyc && bad != 0;
 }
