@@ -263,26 +263,29 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 // VALU-written SGPR and its use as operand (2) / lane select (4) are covered by the instruction order (the
                 // assembler adds none inside inline asm), and independent work sits between a VALU result and the scalar
                 // instruction consuming it (~10 ns each otherwise).  Lane selects above 63 address lane (select & 63).
-                uint32_t g, u, i, j, t, m, q2, x, y, pv, rv;
+                // The quotient test without a multiply: q stays Q exactly while 16 Q cnt <= sum < 16 (Q + 1) cnt, i.e.
+                // while qa = sum - 16 Q cnt stays below qw = 16 cnt as unsigned numbers; an item adds rank - 16 Q to qa, 16 to qw.
+                uint32_t g, u, i, j, t, x, y, pv, rv;
                 uint64_t ma, mb;
                 kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kb);  // (uniform already; pins it to an SGPR for the asm operand)
+                const uint32_t qc = qtab << 4;
+                uint32_t qw = cnt << 4, qa = sum - qtab * qw;  // (qtab 0xffffffff before the first item: qa >= qw, the test fails)
 #define ORZ_ROT(Ri, Ry, Rx)                                                                                              \
     "v_readlane_b32 %[pv], %[" Ry "], %[y]\n\tv_readlane_b32 %[rv], %[" Rx "], %[x]\n\ts_mov_b32 m0, %[i]\n\t"                \
     "v_writelane_b32 %[" Ri "], %[pv], m0\n\ts_mov_b32 m0, %[y]\n\tv_writelane_b32 %[" Ry "], %[rv], m0\n\t"                 \
     "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[g], m0\n\t"
-#define ORZ_QCHK(L)                                                                                                       \
-    "s_add_u32 %[sum], %[sum], %[i]\n\ts_lshr_b32 %[q2], %[sum], 4\n\ts_mul_hi_u32 %[q2], %[q2], %[m]\n\t"                 \
-    "s_cmp_lg_u32 %[q2], %[q]\n\ts_cbranch_scc1 " L "\n\t"
+#define ORZ_QCHK(L)                                                                                                      \
+    "s_add_u32 %[qa], %[qa], %[i]\n\ts_sub_u32 %[qa], %[qa], %[qc]\n\ts_cmp_ge_u32 %[qa], %[qw]\n\ts_cbranch_scc1 " L "\n\t"
                 asm volatile(
                     "1:\n\t"
                     "v_readlane_b32 %[g], %[itv], %[kb]\n\t"
                     "v_readlane_b32 %[u], %[itu], %[kb]\n\t"
-                    "s_sub_u32 %[t], %[cnt], 0x146\n\t"
+                    "s_cmp_ge_u32 %[qw], 0x1860\n\t"  // count 390: rescale first (src/symrank.rs:63-66)
                     "v_cmp_eq_u32_e64 %[ma], %[g], %[v0]\n\t"
                     "v_cmp_eq_u32_e64 %[mb], %[u], %[v0]\n\t"
-                    "v_readlane_b32 %[m], %[mreg], %[t]\n\t"
-                    "s_cmp_gt_u32 %[t], 63\n\t"
                     "s_cbranch_scc1 30f\n\t"
+                    "s_add_u32 %[qw], %[qw], 16\n\t"
+                    "s_nop 0\n\t"
                     "s_ff1_i32_b64 %[i], %[ma]\n\t"
                     "s_ff1_i32_b64 %[j], %[mb]\n\t"
                     "s_cmp_lt_i32 %[i], 0\n\t"
@@ -291,12 +294,11 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_QCHK("31f")
                     "v_readlane_b32 %[y], %[n1t0], %[i]\n\t"
                     "v_readlane_b32 %[x], %[nxt0], %[i]\n\t"
-                    "s_add_u32 %[cnt], %[cnt], 1\n\t"
                     "s_mov_b32 m0, %[kb]\n\t"
                     "v_writelane_b32 %[vi], %[i], m0\n\t"
+                    "v_writelane_b32 %[vu], %[j], m0\n\t"
                     "v_readlane_b32 %[pv], %[v0], %[y]\n\t"
                     "v_readlane_b32 %[rv], %[v0], %[x]\n\t"
-                    "v_writelane_b32 %[vu], %[j], m0\n\t"
                     "s_mov_b32 m0, %[i]\n\t"
                     "v_writelane_b32 %[v0], %[pv], m0\n\t"
                     "s_mov_b32 m0, %[y]\n\t"
@@ -307,20 +309,27 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     "s_add_u32 %[kb], %[kb], 1\n\t"
                     "s_cbranch_scc0 1b\n\t"
                     "s_branch 9f\n\t"
-                    // count outside 326..389: rescale (src/symrank.rs:63-66) or, in the warm-up, the general code
+                    // count 390: cnt and sum scale by 9/10
                     "30:\n\t"
-                    "s_cmp_lt_u32 %[cnt], 0x146\n\t"
-                    "s_cbranch_scc1 9f\n\t"
-                    "s_mul_i32 %[cnt], %[cnt], 9\n\t"
-                    "s_mul_hi_u32 %[cnt], %[cnt], 0xcccccccd\n\t"
-                    "s_lshr_b32 %[cnt], %[cnt], 3\n\t"
-                    "s_mul_i32 %[sum], %[sum], 9\n\t"
-                    "s_mul_hi_u32 %[sum], %[sum], 0xcccccccd\n\t"
-                    "s_lshr_b32 %[sum], %[sum], 3\n\t"
+                    "s_lshr_b32 %[t], %[qw], 4\n\t"
+                    "s_mul_i32 %[x], %[t], %[qc]\n\t"
+                    "s_add_u32 %[x], %[x], %[qa]\n\t"           // sum
+                    "s_mul_i32 %[t], %[t], 9\n\t"
+                    "s_mul_hi_u32 %[t], %[t], 0xcccccccd\n\t"
+                    "s_lshr_b32 %[t], %[t], 3\n\t"
+                    "s_mul_i32 %[x], %[x], 9\n\t"
+                    "s_mul_hi_u32 %[x], %[x], 0xcccccccd\n\t"
+                    "s_lshr_b32 %[x], %[x], 3\n\t"
+                    "s_lshl_b32 %[qw], %[t], 4\n\t"
+                    "s_mul_i32 %[t], %[t], %[qc]\n\t"
+                    "s_sub_u32 %[qa], %[x], %[t]\n\t"
                     "s_branch 1b\n\t"
-                    // the quotient moved: undo, the general code rebuilds the tables
+                    // the quotient moved, or the rank is not in a register: undo, the general code takes the item
                     "31:\n\t"
-                    "s_sub_u32 %[sum], %[sum], %[i]\n\t"
+                    "s_sub_u32 %[qa], %[qa], %[i]\n\t"
+                    "s_add_u32 %[qa], %[qa], %[qc]\n\t"
+                    "32:\n\t"
+                    "s_sub_u32 %[qw], %[qw], 16\n\t"
                     "s_branch 9f\n\t"
                     // ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register
                     "4:\n\t"
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     "s_ff1_i32_b64 %[i], %[ma]\n\t"
                     "s_ff1_i32_b64 %[pv], %[mb]\n\t"
                     "s_cmp_lt_i32 %[i], 0\n\t"
-                    "s_cbranch_scc1 9f\n\t"
+                    "s_cbranch_scc1 32b\n\t"
                     "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"
                     "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"
                     "s_add_u32 %[i], %[i], 0x80\n\t"
@@ -364,7 +373,6 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     "s_add_u32 %[j], %[pv], 0x80\n\t"
                     "6:\n\t"
                     ORZ_QCHK("31b")
-                    "s_add_u32 %[cnt], %[cnt], 1\n\t"
                     "s_mov_b32 m0, %[kb]\n\t"
                     "v_writelane_b32 %[vi], %[i], m0\n\t"
                     "v_writelane_b32 %[vu], %[j], m0\n\t"
@@ -396,14 +404,16 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_ROT("v2", "v1", "v1")
                     "s_branch 8b\n\t"
                     "9:"
-                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [cnt] "+s"(cnt),
-                      [sum] "+s"(sum), [g] "=&s"(g), [u] "=&s"(u), [i] "=&s"(i), [j] "=&s"(j), [t] "=&s"(t), [m] "=&s"(m),
-                      [q2] "=&s"(q2), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
-                    : [itv] "v"(itv), [itu] "v"(itu), [mreg] "v"(mreg), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1),
-                      [nxt1] "v"(nxt1), [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [q] "s"(qtab)
+                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
+                      [qw] "+s"(qw), [g] "=&s"(g), [u] "=&s"(u), [i] "=&s"(i), [j] "=&s"(j), [t] "=&s"(t), [x] "=&s"(x),
+                      [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
+                    : [itv] "v"(itv), [itu] "v"(itu), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1), [nxt1] "v"(nxt1),
+                      [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [qc] "s"(qc)
                     : "scc", "m0");
 #undef ORZ_ROT
 #undef ORZ_QCHK
+                cnt = qw >> 4;
+                sum = qa + qtab * qw;
             }
             if (kb == 0) break;
             // the general item
