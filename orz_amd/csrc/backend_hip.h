@@ -265,151 +265,169 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 // instruction consuming it (~10 ns each otherwise).  Lane selects above 63 address lane (select & 63).
                 // The quotient test without a multiply: q stays Q exactly while 16 Q cnt <= sum < 16 (Q + 1) cnt, i.e.
                 // while qa = sum - 16 Q cnt stays below qw = 16 cnt as unsigned numbers; an item adds rank - 16 Q to qa, 16 to qw.
-                uint32_t g, u, i, j, t, x, y, pv, rv;
+                uint32_t g, u, g2, u2, i, j, t, x, y, pv, rv;
                 uint64_t ma, mb;
                 kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kb);  // (uniform already; pins it to an SGPR for the asm operand)
                 const uint32_t qc = qtab << 4;
                 uint32_t qw = cnt << 4, qa = sum - qtab * qw;  // (qtab 0xffffffff before the first item: qa >= qw, the test fails)
-#define ORZ_ROT(Ri, Ry, Rx)                                                                                              \
+// value[i] <- value[y] <- value[x] <- the item's symbol G, each rank in the register that holds it
+#define ORZ_ROT(G, Ri, Ry, Rx)                                                                                           \
     "v_readlane_b32 %[pv], %[" Ry "], %[y]\n\tv_readlane_b32 %[rv], %[" Rx "], %[x]\n\ts_mov_b32 m0, %[i]\n\t"                \
     "v_writelane_b32 %[" Ri "], %[pv], m0\n\ts_mov_b32 m0, %[y]\n\tv_writelane_b32 %[" Ry "], %[rv], m0\n\t"                 \
-    "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[g], m0\n\t"
+    "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[" G "], m0\n\t"
 #define ORZ_QCHK(L)                                                                                                      \
     "s_add_u32 %[qa], %[qa], %[i]\n\ts_sub_u32 %[qa], %[qa], %[qc]\n\ts_cmp_ge_u32 %[qa], %[qw]\n\ts_cbranch_scc1 " L "\n\t"
+// One item.  P prefixes its labels; (G, U) hold its symbol / excluded symbol, (G2, U2) receive the next item's while this
+// one's results are in flight: a scalar instruction behind a VALU instruction that writes an SGPR waits ~5 issue slots,
+// so SGPR-writing VALU instructions are clustered and the lane writes (no SGPR result) sit between them and their users.
+#define ORZ_SR_ITEM(P, G, U, G2, U2)                                                                                     \
+    P "01:\n\t"                                                                                                          \
+    "s_cmp_ge_u32 %[qw], 0x1860\n\t" /* count 390: rescale first (src/symrank.rs:63-66) */                               \
+    "s_mov_b32 m0, %[kb]\n\t"                                                                                            \
+    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v0]\n\t"                                                                        \
+    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v0]\n\t"                                                                        \
+    "s_cbranch_scc1 " P "30f\n\t"                                                                                        \
+    "s_add_u32 %[qw], %[qw], 16\n\t"                                                                                     \
+    "s_add_u32 %[kb], %[kb], 1\n\t"                                                                                      \
+    "s_ff1_i32_b64 %[i], %[ma]\n\t"                                                                                      \
+    "s_ff1_i32_b64 %[j], %[mb]\n\t"                                                                                      \
+    "s_cmp_lt_i32 %[i], 0\n\t"                                                                                           \
+    "s_cbranch_scc1 " P "04f\n\t"                                                                                        \
+    /* ranks 0..63 */                                                                                                    \
+    ORZ_QCHK(P "31f")                                                                                                    \
+    "v_readlane_b32 %[y], %[n1t0], %[i]\n\t"                                                                             \
+    "v_readlane_b32 %[x], %[nxt0], %[i]\n\t"                                                                             \
+    "v_writelane_b32 %[vi], %[i], m0\n\t"                                                                                \
+    "v_writelane_b32 %[vu], %[j], m0\n\t"                                                                                \
+    "v_readlane_b32 %[" G2 "], %[itv], %[kb]\n\t"                                                                        \
+    "v_readlane_b32 %[pv], %[v0], %[y]\n\t"                                                                              \
+    "v_readlane_b32 %[rv], %[v0], %[x]\n\t"                                                                              \
+    "v_readlane_b32 %[" U2 "], %[itu], %[kb]\n\t"                                                                        \
+    "s_mov_b32 m0, %[i]\n\t"                                                                                             \
+    "v_writelane_b32 %[v0], %[pv], m0\n\t"                                                                               \
+    "s_mov_b32 m0, %[y]\n\t"                                                                                             \
+    "v_writelane_b32 %[v0], %[rv], m0\n\t"                                                                               \
+    "s_mov_b32 m0, %[x]\n\t"                                                                                             \
+    "v_writelane_b32 %[v0], %[" G "], m0\n\t"                                                                            \
+    P "08:\n\t"                                                                                                          \
+    "s_cmp_lg_u32 %[kb], 0\n\t"
+// The rarer paths of one item (placed behind both straight lines)
+#define ORZ_SR_SIDE(P, G, U, G2, U2)                                                                                     \
+    /* count 390: cnt and sum scale by 9/10 */                                                                           \
+    P "30:\n\t"                                                                                                          \
+    "s_lshr_b32 %[t], %[qw], 4\n\t"                                                                                      \
+    "s_mul_i32 %[x], %[t], %[qc]\n\t"                                                                                    \
+    "s_add_u32 %[x], %[x], %[qa]\n\t"                                                                                    \
+    "s_mul_i32 %[t], %[t], 9\n\t"                                                                                        \
+    "s_mul_hi_u32 %[t], %[t], 0xcccccccd\n\t"                                                                            \
+    "s_lshr_b32 %[t], %[t], 3\n\t"                                                                                       \
+    "s_mul_i32 %[x], %[x], 9\n\t"                                                                                        \
+    "s_mul_hi_u32 %[x], %[x], 0xcccccccd\n\t"                                                                            \
+    "s_lshr_b32 %[x], %[x], 3\n\t"                                                                                       \
+    "s_lshl_b32 %[qw], %[t], 4\n\t"                                                                                      \
+    "s_mul_i32 %[t], %[t], %[qc]\n\t"                                                                                    \
+    "s_sub_u32 %[qa], %[x], %[t]\n\t"                                                                                    \
+    "s_branch " P "01b\n\t"                                                                                              \
+    /* the quotient moved, or the rank is not in a register: undo, the general code takes the item */                    \
+    P "31:\n\t"                                                                                                          \
+    "s_sub_u32 %[qa], %[qa], %[i]\n\t"                                                                                   \
+    "s_add_u32 %[qa], %[qa], %[qc]\n\t"                                                                                  \
+    P "32:\n\t"                                                                                                          \
+    "s_sub_u32 %[qw], %[qw], 16\n\t"                                                                                     \
+    "s_sub_u32 %[kb], %[kb], 1\n\t"                                                                                      \
+    "s_branch 9f\n\t"                                                                                                    \
+    /* ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register */ \
+    P "04:\n\t"                                                                                                          \
+    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v1]\n\t"                                                                        \
+    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v1]\n\t"                                                                        \
+    "s_nop 1\n\t"                                                                                                        \
+    "s_ff1_i32_b64 %[i], %[ma]\n\t"                                                                                      \
+    "s_ff1_i32_b64 %[t], %[mb]\n\t"                                                                                      \
+    "s_cmp_lt_i32 %[i], 0\n\t"                                                                                           \
+    "s_cbranch_scc1 " P "05f\n\t"                                                                                        \
+    "v_readlane_b32 %[y], %[n1t1], %[i]\n\t"                                                                             \
+    "v_readlane_b32 %[x], %[nxt1], %[i]\n\t"                                                                             \
+    "s_add_u32 %[i], %[i], 64\n\t"                                                                                       \
+    "s_cmp_lt_i32 %[j], 0\n\t"                                                                                           \
+    "s_cbranch_scc0 " P "06f\n\t"                                                                                        \
+    "s_cmp_lt_i32 %[t], 0\n\t"                                                                                           \
+    "s_cbranch_scc1 " P "06f\n\t"                                                                                        \
+    "s_add_u32 %[j], %[t], 64\n\t"                                                                                       \
+    "s_branch " P "06f\n\t"                                                                                              \
+    /* ranks 128..191 (beyond: the general code, nothing changed so far) */                                              \
+    P "05:\n\t"                                                                                                          \
+    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v2]\n\t"                                                                        \
+    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v2]\n\t"                                                                        \
+    "s_nop 1\n\t"                                                                                                        \
+    "s_ff1_i32_b64 %[i], %[ma]\n\t"                                                                                      \
+    "s_ff1_i32_b64 %[pv], %[mb]\n\t"                                                                                     \
+    "s_cmp_lt_i32 %[i], 0\n\t"                                                                                           \
+    "s_cbranch_scc1 " P "32b\n\t"                                                                                        \
+    "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"                                                                             \
+    "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"                                                                             \
+    "s_add_u32 %[i], %[i], 0x80\n\t"                                                                                     \
+    "s_cmp_lt_i32 %[j], 0\n\t"                                                                                           \
+    "s_cbranch_scc0 " P "06f\n\t"                                                                                        \
+    "s_cmp_lt_i32 %[t], 0\n\t"                                                                                           \
+    "s_cbranch_scc1 " P "07f\n\t"                                                                                        \
+    "s_add_u32 %[j], %[t], 64\n\t"                                                                                       \
+    "s_branch " P "06f\n\t"                                                                                              \
+    P "07:\n\t"                                                                                                          \
+    "s_cmp_lt_i32 %[pv], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 " P "06f\n\t"                                                                                        \
+    "s_add_u32 %[j], %[pv], 0x80\n\t"                                                                                    \
+    P "06:\n\t"                                                                                                          \
+    ORZ_QCHK(P "31b")                                                                                                    \
+    "v_writelane_b32 %[vi], %[i], m0\n\t" /* (m0: the item's lane, set at the top) */                                  \
+    "v_writelane_b32 %[vu], %[j], m0\n\t"                                                                                \
+    "v_readlane_b32 %[" G2 "], %[itv], %[kb]\n\t"                                                                        \
+    "v_readlane_b32 %[" U2 "], %[itu], %[kb]\n\t"                                                                        \
+    "s_cmp_lt_u32 %[i], 0x80\n\t"                                                                                        \
+    "s_cbranch_scc0 " P "20f\n\t"                                                                                        \
+    "s_cmp_lt_u32 %[x], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 " P "11f\n\t"                                                                                        \
+    ORZ_ROT(G, "v1", "v1", "v1")                                                                                         \
+    "s_branch " P "08b\n\t"                                                                                              \
+    P "11:\n\t"                                                                                                          \
+    "s_cmp_lt_u32 %[y], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 " P "12f\n\t"                                                                                        \
+    ORZ_ROT(G, "v1", "v1", "v0")                                                                                         \
+    "s_branch " P "08b\n\t"                                                                                              \
+    P "12:\n\t"                                                                                                          \
+    ORZ_ROT(G, "v1", "v0", "v0")                                                                                         \
+    "s_branch " P "08b\n\t"                                                                                              \
+    P "20:\n\t" /* i >= 128: x >= i/2 >= 64 */                                                                           \
+    "s_cmp_lt_u32 %[x], 0x80\n\t"                                                                                        \
+    "s_cbranch_scc1 " P "21f\n\t"                                                                                        \
+    ORZ_ROT(G, "v2", "v2", "v2")                                                                                         \
+    "s_branch " P "08b\n\t"                                                                                              \
+    P "21:\n\t"                                                                                                          \
+    "s_cmp_lt_u32 %[y], 0x80\n\t"                                                                                        \
+    "s_cbranch_scc1 " P "22f\n\t"                                                                                        \
+    ORZ_ROT(G, "v2", "v2", "v1")                                                                                         \
+    "s_branch " P "08b\n\t"                                                                                              \
+    P "22:\n\t"                                                                                                          \
+    ORZ_ROT(G, "v2", "v1", "v1")                                                                                         \
+    "s_branch " P "08b\n\t"
                 asm volatile(
-                    "1:\n\t"
                     "v_readlane_b32 %[g], %[itv], %[kb]\n\t"
                     "v_readlane_b32 %[u], %[itu], %[kb]\n\t"
-                    "s_cmp_ge_u32 %[qw], 0x1860\n\t"  // count 390: rescale first (src/symrank.rs:63-66)
-                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v0]\n\t"
-                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v0]\n\t"
-                    "s_cbranch_scc1 30f\n\t"
-                    "s_add_u32 %[qw], %[qw], 16\n\t"
-                    "s_nop 0\n\t"
-                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
-                    "s_ff1_i32_b64 %[j], %[mb]\n\t"
-                    "s_cmp_lt_i32 %[i], 0\n\t"
-                    "s_cbranch_scc1 4f\n\t"
-                    // ranks 0..63
-                    ORZ_QCHK("31f")
-                    "v_readlane_b32 %[y], %[n1t0], %[i]\n\t"
-                    "v_readlane_b32 %[x], %[nxt0], %[i]\n\t"
-                    "s_mov_b32 m0, %[kb]\n\t"
-                    "v_writelane_b32 %[vi], %[i], m0\n\t"
-                    "v_writelane_b32 %[vu], %[j], m0\n\t"
-                    "v_readlane_b32 %[pv], %[v0], %[y]\n\t"
-                    "v_readlane_b32 %[rv], %[v0], %[x]\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
-                    "v_writelane_b32 %[v0], %[pv], m0\n\t"
-                    "s_mov_b32 m0, %[y]\n\t"
-                    "v_writelane_b32 %[v0], %[rv], m0\n\t"
-                    "s_mov_b32 m0, %[x]\n\t"
-                    "v_writelane_b32 %[v0], %[g], m0\n\t"
-                    "8:\n\t"
-                    "s_add_u32 %[kb], %[kb], 1\n\t"
-                    "s_cbranch_scc0 1b\n\t"
+                    ORZ_SR_ITEM("1", "g", "u", "g2", "u2")
+                    "s_cbranch_scc0 9f\n\t"
+                    ORZ_SR_ITEM("2", "g2", "u2", "g", "u")
+                    "s_cbranch_scc1 101b\n\t"
                     "s_branch 9f\n\t"
-                    // count 390: cnt and sum scale by 9/10
-                    "30:\n\t"
-                    "s_lshr_b32 %[t], %[qw], 4\n\t"
-                    "s_mul_i32 %[x], %[t], %[qc]\n\t"
-                    "s_add_u32 %[x], %[x], %[qa]\n\t"           // sum
-                    "s_mul_i32 %[t], %[t], 9\n\t"
-                    "s_mul_hi_u32 %[t], %[t], 0xcccccccd\n\t"
-                    "s_lshr_b32 %[t], %[t], 3\n\t"
-                    "s_mul_i32 %[x], %[x], 9\n\t"
-                    "s_mul_hi_u32 %[x], %[x], 0xcccccccd\n\t"
-                    "s_lshr_b32 %[x], %[x], 3\n\t"
-                    "s_lshl_b32 %[qw], %[t], 4\n\t"
-                    "s_mul_i32 %[t], %[t], %[qc]\n\t"
-                    "s_sub_u32 %[qa], %[x], %[t]\n\t"
-                    "s_branch 1b\n\t"
-                    // the quotient moved, or the rank is not in a register: undo, the general code takes the item
-                    "31:\n\t"
-                    "s_sub_u32 %[qa], %[qa], %[i]\n\t"
-                    "s_add_u32 %[qa], %[qa], %[qc]\n\t"
-                    "32:\n\t"
-                    "s_sub_u32 %[qw], %[qw], 16\n\t"
-                    "s_branch 9f\n\t"
-                    // ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register
-                    "4:\n\t"
-                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v1]\n\t"
-                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v1]\n\t"
-                    "s_nop 1\n\t"
-                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
-                    "s_ff1_i32_b64 %[t], %[mb]\n\t"
-                    "s_cmp_lt_i32 %[i], 0\n\t"
-                    "s_cbranch_scc1 5f\n\t"
-                    "v_readlane_b32 %[y], %[n1t1], %[i]\n\t"
-                    "v_readlane_b32 %[x], %[nxt1], %[i]\n\t"
-                    "s_add_u32 %[i], %[i], 64\n\t"
-                    "s_cmp_lt_i32 %[j], 0\n\t"
-                    "s_cbranch_scc0 6f\n\t"
-                    "s_cmp_lt_i32 %[t], 0\n\t"
-                    "s_cbranch_scc1 6f\n\t"
-                    "s_add_u32 %[j], %[t], 64\n\t"
-                    "s_branch 6f\n\t"
-                    // ranks 128..191 (beyond: the general code, nothing changed so far)
-                    "5:\n\t"
-                    "v_cmp_eq_u32_e64 %[ma], %[g], %[v2]\n\t"
-                    "v_cmp_eq_u32_e64 %[mb], %[u], %[v2]\n\t"
-                    "s_nop 1\n\t"
-                    "s_ff1_i32_b64 %[i], %[ma]\n\t"
-                    "s_ff1_i32_b64 %[pv], %[mb]\n\t"
-                    "s_cmp_lt_i32 %[i], 0\n\t"
-                    "s_cbranch_scc1 32b\n\t"
-                    "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"
-                    "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"
-                    "s_add_u32 %[i], %[i], 0x80\n\t"
-                    "s_cmp_lt_i32 %[j], 0\n\t"
-                    "s_cbranch_scc0 6f\n\t"
-                    "s_cmp_lt_i32 %[t], 0\n\t"
-                    "s_cbranch_scc1 7f\n\t"
-                    "s_add_u32 %[j], %[t], 64\n\t"
-                    "s_branch 6f\n\t"
-                    "7:\n\t"
-                    "s_cmp_lt_i32 %[pv], 0\n\t"
-                    "s_cbranch_scc1 6f\n\t"
-                    "s_add_u32 %[j], %[pv], 0x80\n\t"
-                    "6:\n\t"
-                    ORZ_QCHK("31b")
-                    "s_mov_b32 m0, %[kb]\n\t"
-                    "v_writelane_b32 %[vi], %[i], m0\n\t"
-                    "v_writelane_b32 %[vu], %[j], m0\n\t"
-                    "s_cmp_lt_u32 %[i], 0x80\n\t"
-                    "s_cbranch_scc0 20f\n\t"
-                    "s_cmp_lt_u32 %[x], 64\n\t"
-                    "s_cbranch_scc1 11f\n\t"
-                    ORZ_ROT("v1", "v1", "v1")
-                    "s_branch 8b\n\t"
-                    "11:\n\t"
-                    "s_cmp_lt_u32 %[y], 64\n\t"
-                    "s_cbranch_scc1 12f\n\t"
-                    ORZ_ROT("v1", "v1", "v0")
-                    "s_branch 8b\n\t"
-                    "12:\n\t"
-                    ORZ_ROT("v1", "v0", "v0")
-                    "s_branch 8b\n\t"
-                    "20:\n\t"  // i >= 128: x >= i/2 >= 64
-                    "s_cmp_lt_u32 %[x], 0x80\n\t"
-                    "s_cbranch_scc1 21f\n\t"
-                    ORZ_ROT("v2", "v2", "v2")
-                    "s_branch 8b\n\t"
-                    "21:\n\t"
-                    "s_cmp_lt_u32 %[y], 0x80\n\t"
-                    "s_cbranch_scc1 22f\n\t"
-                    ORZ_ROT("v2", "v2", "v1")
-                    "s_branch 8b\n\t"
-                    "22:\n\t"
-                    ORZ_ROT("v2", "v1", "v1")
-                    "s_branch 8b\n\t"
+                    ORZ_SR_SIDE("1", "g", "u", "g2", "u2")
+                    ORZ_SR_SIDE("2", "g2", "u2", "g", "u")
                     "9:"
                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
-                      [qw] "+s"(qw), [g] "=&s"(g), [u] "=&s"(u), [i] "=&s"(i), [j] "=&s"(j), [t] "=&s"(t), [x] "=&s"(x),
-                      [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
+                      [qw] "+s"(qw), [g] "=&s"(g), [u] "=&s"(u), [g2] "=&s"(g2), [u2] "=&s"(u2), [i] "=&s"(i), [j] "=&s"(j),
+                      [t] "=&s"(t), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
                     : [itv] "v"(itv), [itu] "v"(itu), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1), [nxt1] "v"(nxt1),
                       [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [qc] "s"(qc)
                     : "scc", "m0");
+#undef ORZ_SR_ITEM
+#undef ORZ_SR_SIDE
 #undef ORZ_ROT
 #undef ORZ_QCHK
                 cnt = qw >> 4;
