@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     const uint32_t a = rstart[c], e = rstart[c + 1];
     if (a >= e) return;
+    __builtin_amdgcn_s_setprio(3);  // one serial chain per wave: issue ahead of the parse kernels' waves sharing the SIMD
     uint16_t* state = srstate + (size_t)c * kSrWords;
     for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = state[i]; idx[i] = state[kSyms + i]; }
     __syncthreads();

@@ -370,6 +370,7 @@ class StreamEncoder {
     uint32_t window_segs() const { return wsegs_; }
     bool fast() const { return fast_; }
     uint32_t fast_tile() const { return ftile_; }
+    void set_lead_block(bool on) { lead_block_ = on; }  // the next block leads a multi-block stream (see fast_parse)
     uint32_t fast_rounds() const { return frounds_; }
     uint32_t fast_row() const { return fK_; }
 
@@ -592,6 +593,9 @@ class StreamEncoder {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
+            // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
+            // symbols are ranked): it takes tiles twice the size -- half the steps, ~+0.1 % on that block's output.
+            if (lead_block_ && T == ftile_) T = 2 * ftile_;
         }
         for (;;) {
             a.tile = T;
@@ -863,6 +867,7 @@ class StreamEncoder {
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
     uint32_t ftile_ = 131072, frounds_ = 4, fK_ = 64;
+    bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
     uint16_t* fkw_ = nullptr;
@@ -915,6 +920,7 @@ void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n,
         if (src_on_device) be.d2d(enc.dwin() + kPre, src + off, take);
         else if (src_pinned) be.h2d_pinned(enc.dwin() + kPre, src + off, take);  // async: the block's first sync covers it
         else be.h2d(enc.dwin() + kPre, src + off, take);
+        enc.set_lead_block(off == 0 && n > kNewMax);
         enc.encode_block(take, out);
         off += take;
         if (off < n) enc.slide();
