@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         if (r < 64) v0 = orz_writelane(v0, x, r);
         else if (r < 128) v1 = orz_writelane(v1, x, r - 64);
         else if (r < 192) v2 = orz_writelane(v2, x, r - 128);
-        else { val[r] = (uint16_t)x; idx[x] = (uint16_t)r; }
+        else { val[r] = (uint16_t)x; idx[x & 0xffff] = (uint16_t)r; }
     };
     // Per-lane move targets of ranks lane, 64 + lane, 128 + lane for the current quotient q = floor(avg rank / 16): the
     // serial chain then fetches next_i / ni1 with two v_readlane instead of nine dependent scalar ops.  q moves rarely;
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     int items = load_batch(a);
     for (uint32_t j0 = a; j0 < e; j0 += 64) {
         const int items_next = load_batch(j0 + 64);  // in flight while this batch runs
-        const int itv = items & 0xffff, itu = (int)((uint32_t)items >> 16);
         const uint32_t nthis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e - j0 < 64 ? e - j0 : 64));
         int vi = 0, vu = 0;  // per lane: rank of the item's symbol / of its excluded symbol (0xffffffff = behind the symbol's)
         uint32_t kb = 0u - nthis;
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 // instruction consuming it (~10 ns each otherwise).  Lane selects above 63 address lane (select & 63).
                 // The quotient test without a multiply: q stays Q exactly while 16 Q cnt <= sum < 16 (Q + 1) cnt, i.e.
                 // while qa = sum - 16 Q cnt stays below qw = 16 cnt as unsigned numbers; an item adds rank - 16 Q to qa, 16 to qw.
-                uint32_t g, u, g2, u2, i, j, t, x, y, pv, rv;
+                uint32_t g, g2, i, j, t, x, y, pv, rv;
                 uint64_t ma, mb;
                 kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kb);  // (uniform already; pins it to an SGPR for the asm operand)
                 const uint32_t qc = qtab << 4;
@@ -281,12 +280,12 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
 // One item.  P prefixes its labels; (G, U) hold its symbol / excluded symbol, (G2, U2) receive the next item's while this
 // one's results are in flight: a scalar instruction behind a VALU instruction that writes an SGPR waits ~5 issue slots,
 // so SGPR-writing VALU instructions are clustered and the lane writes (no SGPR result) sit between them and their users.
-#define ORZ_SR_ITEM(P, G, U, G2, U2)                                                                                     \
+#define ORZ_SR_ITEM(P, G, G2)                                                                                            \
     P "01:\n\t"                                                                                                          \
     "s_cmp_ge_u32 %[qw], 0x1860\n\t" /* count 390: rescale first (src/symrank.rs:63-66) */                               \
     "s_mov_b32 m0, %[kb]\n\t"                                                                                            \
-    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v0]\n\t"                                                                        \
-    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v0]\n\t"                                                                        \
+    "v_cmp_eq_u32_sdwa %[ma], %[" G "], %[v0] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                      \
+    "v_cmp_eq_u32_sdwa %[mb], %[" G "], %[v0] src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                      \
     "s_cbranch_scc1 " P "30f\n\t"                                                                                        \
     "s_add_u32 %[qw], %[qw], 16\n\t"                                                                                     \
     "s_add_u32 %[kb], %[kb], 1\n\t"                                                                                      \
@@ -300,10 +299,9 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     "v_readlane_b32 %[x], %[nxt0], %[i]\n\t"                                                                             \
     "v_writelane_b32 %[vi], %[i], m0\n\t"                                                                                \
     "v_writelane_b32 %[vu], %[j], m0\n\t"                                                                                \
-    "v_readlane_b32 %[" G2 "], %[itv], %[kb]\n\t"                                                                        \
+    "v_readlane_b32 %[" G2 "], %[items], %[kb]\n\t"                                                                      \
     "v_readlane_b32 %[pv], %[v0], %[y]\n\t"                                                                              \
     "v_readlane_b32 %[rv], %[v0], %[x]\n\t"                                                                              \
-    "v_readlane_b32 %[" U2 "], %[itu], %[kb]\n\t"                                                                        \
     "s_mov_b32 m0, %[i]\n\t"                                                                                             \
     "v_writelane_b32 %[v0], %[pv], m0\n\t"                                                                               \
     "s_mov_b32 m0, %[y]\n\t"                                                                                             \
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     P "08:\n\t"                                                                                                          \
     "s_cmp_lg_u32 %[kb], 0\n\t"
 // The rarer paths of one item (placed behind both straight lines)
-#define ORZ_SR_SIDE(P, G, U, G2, U2)                                                                                     \
+#define ORZ_SR_SIDE(P, G, G2)                                                                                            \
     /* count 390: cnt and sum scale by 9/10 */                                                                           \
     P "30:\n\t"                                                                                                          \
     "s_lshr_b32 %[t], %[qw], 4\n\t"                                                                                      \
@@ -339,8 +337,8 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     "s_branch 9f\n\t"                                                                                                    \
     /* ranks 64..127; the excluded symbol only matters when it ranks ahead, so its search stops with the symbol's register */ \
     P "04:\n\t"                                                                                                          \
-    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v1]\n\t"                                                                        \
-    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v1]\n\t"                                                                        \
+    "v_cmp_eq_u32_sdwa %[ma], %[" G "], %[v1] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                      \
+    "v_cmp_eq_u32_sdwa %[mb], %[" G "], %[v1] src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                      \
     "s_nop 1\n\t"                                                                                                        \
     "s_ff1_i32_b64 %[i], %[ma]\n\t"                                                                                      \
     "s_ff1_i32_b64 %[t], %[mb]\n\t"                                                                                      \
@@ -357,8 +355,8 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     "s_branch " P "06f\n\t"                                                                                              \
     /* ranks 128..191 (beyond: the general code, nothing changed so far) */                                              \
     P "05:\n\t"                                                                                                          \
-    "v_cmp_eq_u32_e64 %[ma], %[" G "], %[v2]\n\t"                                                                        \
-    "v_cmp_eq_u32_e64 %[mb], %[" U "], %[v2]\n\t"                                                                        \
+    "v_cmp_eq_u32_sdwa %[ma], %[" G "], %[v2] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                      \
+    "v_cmp_eq_u32_sdwa %[mb], %[" G "], %[v2] src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                      \
     "s_nop 1\n\t"                                                                                                        \
     "s_ff1_i32_b64 %[i], %[ma]\n\t"                                                                                      \
     "s_ff1_i32_b64 %[pv], %[mb]\n\t"                                                                                     \
@@ -381,8 +379,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     ORZ_QCHK(P "31b")                                                                                                    \
     "v_writelane_b32 %[vi], %[i], m0\n\t" /* (m0: the item's lane, set at the top) */                                  \
     "v_writelane_b32 %[vu], %[j], m0\n\t"                                                                                \
-    "v_readlane_b32 %[" G2 "], %[itv], %[kb]\n\t"                                                                        \
-    "v_readlane_b32 %[" U2 "], %[itu], %[kb]\n\t"                                                                        \
+    "v_readlane_b32 %[" G2 "], %[items], %[kb]\n\t"                                                                      \
     "s_cmp_lt_u32 %[i], 0x80\n\t"                                                                                        \
     "s_cbranch_scc0 " P "20f\n\t"                                                                                        \
     "s_cmp_lt_u32 %[x], 64\n\t"                                                                                          \
@@ -411,20 +408,20 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     ORZ_ROT(G, "v2", "v1", "v1")                                                                                         \
     "s_branch " P "08b\n\t"
                 asm volatile(
-                    "v_readlane_b32 %[g], %[itv], %[kb]\n\t"
-                    "v_readlane_b32 %[u], %[itu], %[kb]\n\t"
-                    ORZ_SR_ITEM("1", "g", "u", "g2", "u2")
+                    "v_readlane_b32 %[g], %[items], %[kb]\n\t"
+                    "s_nop 0\n\t"
+                    ORZ_SR_ITEM("1", "g", "g2")
                     "s_cbranch_scc0 9f\n\t"
-                    ORZ_SR_ITEM("2", "g2", "u2", "g", "u")
+                    ORZ_SR_ITEM("2", "g2", "g")
                     "s_cbranch_scc1 101b\n\t"
                     "s_branch 9f\n\t"
-                    ORZ_SR_SIDE("1", "g", "u", "g2", "u2")
-                    ORZ_SR_SIDE("2", "g2", "u2", "g", "u")
+                    ORZ_SR_SIDE("1", "g", "g2")
+                    ORZ_SR_SIDE("2", "g2", "g")
                     "9:"
                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
-                      [qw] "+s"(qw), [g] "=&s"(g), [u] "=&s"(u), [g2] "=&s"(g2), [u2] "=&s"(u2), [i] "=&s"(i), [j] "=&s"(j),
+                      [qw] "+s"(qw), [g] "=&s"(g), [g2] "=&s"(g2), [i] "=&s"(i), [j] "=&s"(j),
                       [t] "=&s"(t), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
-                    : [itv] "v"(itv), [itu] "v"(itu), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1), [nxt1] "v"(nxt1),
+                    : [items] "v"(items), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1), [nxt1] "v"(nxt1),
                       [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [qc] "s"(qc)
                     : "scc", "m0");
 #undef ORZ_SR_ITEM
@@ -437,22 +434,24 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
             if (kb == 0) break;
             // the general item
             const uint32_t k = kb & 63;
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(itv, (int)k), vun = (uint32_t)__builtin_amdgcn_readlane(itu, (int)k);
-            uint32_t i = orz_ff1(__ballot(v0 == (int)v));
-            uint32_t iu = orz_ff1(__ballot(v0 == (int)vun));  // 0xffffffff = not among the first 64: behind any of those
+            const uint32_t gk = (uint32_t)__builtin_amdgcn_readlane(items, (int)k), v = gk & 0xffff, vun = gk >> 16;
+            // (a register lane holds its symbol in the low half; the straight loop leaves the item's excluded symbol in the high half)
+            const int w0 = v0 & 0xffff, w1 = v1 & 0xffff, w2 = v2 & 0xffff;
+            uint32_t i = orz_ff1(__ballot(w0 == (int)v));
+            uint32_t iu = orz_ff1(__ballot(w0 == (int)vun));  // 0xffffffff = not among the first 64: behind any of those
             const bool fast = (int32_t)i >= 0;
             if (!fast) {
-                const uint32_t i1 = orz_ff1(__ballot(v1 == (int)v));
+                const uint32_t i1 = orz_ff1(__ballot(w1 == (int)v));
                 if ((int32_t)i1 >= 0) i = 64 + i1;
                 else {
-                    const uint32_t i2 = orz_ff1(__ballot(v2 == (int)v));
+                    const uint32_t i2 = orz_ff1(__ballot(w2 == (int)v));
                     i = (int32_t)i2 >= 0 ? 128 + i2 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[v]);
                 }
                 if ((int32_t)iu < 0) {
-                    const uint32_t u1 = orz_ff1(__ballot(v1 == (int)vun));
+                    const uint32_t u1 = orz_ff1(__ballot(w1 == (int)vun));
                     if ((int32_t)u1 >= 0) iu = 64 + u1;
                     else {
-                        const uint32_t u2 = orz_ff1(__ballot(v2 == (int)vun));
+                        const uint32_t u2 = orz_ff1(__ballot(w2 == (int)vun));
                         iu = (int32_t)u2 >= 0 ? 128 + u2 : (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[vun]);
                     }
                 }
@@ -495,9 +494,9 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     val[lane] = (uint16_t)v0;
     val[64 + lane] = (uint16_t)v1;
     val[128 + lane] = (uint16_t)v2;
-    idx[v0] = (uint16_t)lane;
-    idx[v1] = (uint16_t)(64 + lane);
-    idx[v2] = (uint16_t)(128 + lane);
+    idx[v0 & 0xffff] = (uint16_t)lane;
+    idx[v1 & 0xffff] = (uint16_t)(64 + lane);
+    idx[v2 & 0xffff] = (uint16_t)(128 + lane);
     __syncthreads();
     for (uint32_t i = lane; i < kSyms; i += 64) { state[i] = val[i]; state[kSyms + i] = idx[i]; }
     if (lane == 0) {
