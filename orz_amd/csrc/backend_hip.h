@@ -270,11 +270,14 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                 kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kb);  // (uniform already; pins it to an SGPR for the asm operand)
                 const uint32_t qc = qtab << 4;
                 uint32_t qw = cnt << 4, qa = sum - qtab * qw;  // (qtab 0xffffffff before the first item: qa >= qw, the test fails)
-// value[i] <- value[y] <- value[x] <- the item's symbol G, each rank in the register that holds it
-#define ORZ_ROT(G, Ri, Ry, Rx)                                                                                           \
+// One of the rarer register combinations to its end: the next item's symbols, value[i] <- value[y] <- value[x] <- the
+// item's symbol G (each rank in the register that holds it), then on to the next item (the other half of the loop body)
+#define ORZ_LEAF(G, G2, NEXT, Ri, Ry, Rx)                                                                                \
+    "v_readlane_b32 %[" G2 "], %[items], %[kb]\n\t"                                                                      \
     "v_readlane_b32 %[pv], %[" Ry "], %[y]\n\tv_readlane_b32 %[rv], %[" Rx "], %[x]\n\ts_mov_b32 m0, %[i]\n\t"                \
     "v_writelane_b32 %[" Ri "], %[pv], m0\n\ts_mov_b32 m0, %[y]\n\tv_writelane_b32 %[" Ry "], %[rv], m0\n\t"                 \
-    "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[" G "], m0\n\t"
+    "s_mov_b32 m0, %[x]\n\tv_writelane_b32 %[" Rx "], %[" G "], m0\n\t"                                                     \
+    "s_cmp_lg_u32 %[kb], 0\n\ts_cbranch_scc1 " NEXT "01b\n\ts_branch 9f\n\t"
 #define ORZ_QCHK(L)                                                                                                      \
     "s_add_u32 %[qa], %[qa], %[i]\n\ts_sub_u32 %[qa], %[qa], %[qc]\n\ts_cmp_ge_u32 %[qa], %[qw]\n\ts_cbranch_scc1 " L "\n\t"
 // One item.  P prefixes its labels; (G, U) hold its symbol / excluded symbol, (G2, U2) receive the next item's while this
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     P "08:\n\t"                                                                                                          \
     "s_cmp_lg_u32 %[kb], 0\n\t"
 // The rarer paths of one item (placed behind both straight lines)
-#define ORZ_SR_SIDE(P, G, G2)                                                                                            \
+#define ORZ_SR_SIDE(P, G, G2, NEXT)                                                                                      \
     /* count 390: cnt and sum scale by 9/10 */                                                                           \
     P "30:\n\t"                                                                                                          \
     "s_lshr_b32 %[t], %[qw], 4\n\t"                                                                                      \
@@ -344,15 +347,27 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     "s_ff1_i32_b64 %[t], %[mb]\n\t"                                                                                      \
     "s_cmp_lt_i32 %[i], 0\n\t"                                                                                           \
     "s_cbranch_scc1 " P "05f\n\t"                                                                                        \
-    "v_readlane_b32 %[y], %[n1t1], %[i]\n\t"                                                                             \
-    "v_readlane_b32 %[x], %[nxt1], %[i]\n\t"                                                                             \
     "s_add_u32 %[i], %[i], 64\n\t"                                                                                       \
     "s_cmp_lt_i32 %[j], 0\n\t"                                                                                           \
-    "s_cbranch_scc0 " P "06f\n\t"                                                                                        \
+    "s_cbranch_scc0 " P "41f\n\t"                                                                                        \
     "s_cmp_lt_i32 %[t], 0\n\t"                                                                                           \
-    "s_cbranch_scc1 " P "06f\n\t"                                                                                        \
+    "s_cbranch_scc1 " P "41f\n\t"                                                                                        \
     "s_add_u32 %[j], %[t], 64\n\t"                                                                                       \
-    "s_branch " P "06f\n\t"                                                                                              \
+    P "41:\n\t"                                                                                                          \
+    "v_readlane_b32 %[y], %[n1t1], %[i]\n\t"                                                                             \
+    "v_readlane_b32 %[x], %[nxt1], %[i]\n\t"                                                                             \
+    "v_writelane_b32 %[vi], %[i], m0\n\t" /* (m0: the item's lane, set at the top; the general code overwrites the   */ \
+    "v_writelane_b32 %[vu], %[j], m0\n\t" /*  two if the quotient test sends the item there)                          */ \
+    ORZ_QCHK(P "31b")                                                                                                    \
+    "s_cmp_lt_u32 %[x], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 " P "11f\n\t"                                                                                        \
+    ORZ_LEAF(G, G2, NEXT, "v1", "v1", "v1")                                                                              \
+    P "11:\n\t"                                                                                                          \
+    "s_cmp_lt_u32 %[y], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 " P "12f\n\t"                                                                                        \
+    ORZ_LEAF(G, G2, NEXT, "v1", "v1", "v0")                                                                              \
+    P "12:\n\t"                                                                                                          \
+    ORZ_LEAF(G, G2, NEXT, "v1", "v0", "v0")                                                                              \
     /* ranks 128..191 (beyond: the general code, nothing changed so far) */                                              \
     P "05:\n\t"                                                                                                          \
     "v_cmp_eq_u32_sdwa %[ma], %[" G "], %[v2] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                      \
@@ -362,51 +377,32 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     "s_ff1_i32_b64 %[pv], %[mb]\n\t"                                                                                     \
     "s_cmp_lt_i32 %[i], 0\n\t"                                                                                           \
     "s_cbranch_scc1 " P "32b\n\t"                                                                                        \
-    "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"                                                                             \
-    "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"                                                                             \
     "s_add_u32 %[i], %[i], 0x80\n\t"                                                                                     \
     "s_cmp_lt_i32 %[j], 0\n\t"                                                                                           \
-    "s_cbranch_scc0 " P "06f\n\t"                                                                                        \
+    "s_cbranch_scc0 " P "51f\n\t"                                                                                        \
     "s_cmp_lt_i32 %[t], 0\n\t"                                                                                           \
     "s_cbranch_scc1 " P "07f\n\t"                                                                                        \
     "s_add_u32 %[j], %[t], 64\n\t"                                                                                       \
-    "s_branch " P "06f\n\t"                                                                                              \
+    "s_branch " P "51f\n\t"                                                                                              \
     P "07:\n\t"                                                                                                          \
     "s_cmp_lt_i32 %[pv], 0\n\t"                                                                                          \
-    "s_cbranch_scc1 " P "06f\n\t"                                                                                        \
+    "s_cbranch_scc1 " P "51f\n\t"                                                                                        \
     "s_add_u32 %[j], %[pv], 0x80\n\t"                                                                                    \
-    P "06:\n\t"                                                                                                          \
-    ORZ_QCHK(P "31b")                                                                                                    \
-    "v_writelane_b32 %[vi], %[i], m0\n\t" /* (m0: the item's lane, set at the top) */                                  \
+    P "51:\n\t"                                                                                                          \
+    "v_readlane_b32 %[y], %[n1t2], %[i]\n\t"                                                                             \
+    "v_readlane_b32 %[x], %[nxt2], %[i]\n\t"                                                                             \
+    "v_writelane_b32 %[vi], %[i], m0\n\t"                                                                                \
     "v_writelane_b32 %[vu], %[j], m0\n\t"                                                                                \
-    "v_readlane_b32 %[" G2 "], %[items], %[kb]\n\t"                                                                      \
-    "s_cmp_lt_u32 %[i], 0x80\n\t"                                                                                        \
-    "s_cbranch_scc0 " P "20f\n\t"                                                                                        \
-    "s_cmp_lt_u32 %[x], 64\n\t"                                                                                          \
-    "s_cbranch_scc1 " P "11f\n\t"                                                                                        \
-    ORZ_ROT(G, "v1", "v1", "v1")                                                                                         \
-    "s_branch " P "08b\n\t"                                                                                              \
-    P "11:\n\t"                                                                                                          \
-    "s_cmp_lt_u32 %[y], 64\n\t"                                                                                          \
-    "s_cbranch_scc1 " P "12f\n\t"                                                                                        \
-    ORZ_ROT(G, "v1", "v1", "v0")                                                                                         \
-    "s_branch " P "08b\n\t"                                                                                              \
-    P "12:\n\t"                                                                                                          \
-    ORZ_ROT(G, "v1", "v0", "v0")                                                                                         \
-    "s_branch " P "08b\n\t"                                                                                              \
-    P "20:\n\t" /* i >= 128: x >= i/2 >= 64 */                                                                           \
-    "s_cmp_lt_u32 %[x], 0x80\n\t"                                                                                        \
+    ORZ_QCHK(P "31b")                                                                                                    \
+    "s_cmp_lt_u32 %[x], 0x80\n\t" /* (x >= i/2 >= 64) */                                                                 \
     "s_cbranch_scc1 " P "21f\n\t"                                                                                        \
-    ORZ_ROT(G, "v2", "v2", "v2")                                                                                         \
-    "s_branch " P "08b\n\t"                                                                                              \
+    ORZ_LEAF(G, G2, NEXT, "v2", "v2", "v2")                                                                              \
     P "21:\n\t"                                                                                                          \
     "s_cmp_lt_u32 %[y], 0x80\n\t"                                                                                        \
     "s_cbranch_scc1 " P "22f\n\t"                                                                                        \
-    ORZ_ROT(G, "v2", "v2", "v1")                                                                                         \
-    "s_branch " P "08b\n\t"                                                                                              \
+    ORZ_LEAF(G, G2, NEXT, "v2", "v2", "v1")                                                                              \
     P "22:\n\t"                                                                                                          \
-    ORZ_ROT(G, "v2", "v1", "v1")                                                                                         \
-    "s_branch " P "08b\n\t"
+    ORZ_LEAF(G, G2, NEXT, "v2", "v1", "v1")
                 asm volatile(
                     "v_readlane_b32 %[g], %[items], %[kb]\n\t"
                     "s_nop 0\n\t"
@@ -415,8 +411,8 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_SR_ITEM("2", "g2", "g")
                     "s_cbranch_scc1 101b\n\t"
                     "s_branch 9f\n\t"
-                    ORZ_SR_SIDE("1", "g", "g2")
-                    ORZ_SR_SIDE("2", "g2", "g")
+                    ORZ_SR_SIDE("1", "g", "g2", "2")
+                    ORZ_SR_SIDE("2", "g2", "g", "1")
                     "9:"
                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
                       [qw] "+s"(qw), [g] "=&s"(g), [g2] "=&s"(g2), [i] "=&s"(i), [j] "=&s"(j),
@@ -426,7 +422,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     : "scc", "m0");
 #undef ORZ_SR_ITEM
 #undef ORZ_SR_SIDE
-#undef ORZ_ROT
+#undef ORZ_LEAF
 #undef ORZ_QCHK
                 cnt = qw >> 4;
                 sum = qa + qtab * qw;
