@@ -409,10 +409,16 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_SR_ITEM("1", "g", "g2")
                     "s_cbranch_scc0 9f\n\t"
                     ORZ_SR_ITEM("2", "g2", "g")
+                    "s_cbranch_scc0 9f\n\t"
+                    ORZ_SR_ITEM("3", "g", "g2")
+                    "s_cbranch_scc0 9f\n\t"
+                    ORZ_SR_ITEM("4", "g2", "g")
                     "s_cbranch_scc1 101b\n\t"
                     "s_branch 9f\n\t"
                     ORZ_SR_SIDE("1", "g", "g2", "2")
-                    ORZ_SR_SIDE("2", "g2", "g", "1")
+                    ORZ_SR_SIDE("2", "g2", "g", "3")
+                    ORZ_SR_SIDE("3", "g", "g2", "4")
+                    ORZ_SR_SIDE("4", "g2", "g", "1")
                     "9:"
                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
                       [qw] "+s"(qw), [g] "=&s"(g), [g2] "=&s"(g2), [i] "=&s"(i), [j] "=&s"(j),
