@@ -25,7 +25,9 @@ enum : uint32_t {
     kDecOk = 0,
     kDecBadData = 1,     // InvalidData of the reference (src/lz.rs:413-415, src/lib.rs:111-113)
     kDecTooLarge = 2,    // the member does not fit one block: use the host decoder
-    kDecSizeMismatch = 3 // decoded size differs from what the chunk headers announced
+    kDecSizeMismatch = 3,// decoded size differs from what the chunk headers announced
+    kDecDeepTable = 4    // a 16-bit Huffman table: the reference accepts it, no orz encoder writes it (src/huffman.rs:99-108
+                         // caps at 15) and the lookup tables here hold 2^15 entries: use the host decoder
 };
 
 struct DecodeLayout {  // byte offsets into one member's state blob
@@ -101,6 +103,7 @@ struct DecodeMember {
     ORZ_HD static uint32_t read_table(Bits& br, uint8_t* lens, uint16_t* lut) {
         bool bad = false;
         const uint32_t max_len = br.varint(bad);
+        if (!bad && max_len == 16) return 98;
         if (bad || max_len > 15) return 99;
         uint32_t ns = 0;
         for (;;) {
@@ -205,6 +208,7 @@ struct DecodeMember {
             for (int k = 0; k < 3; k++) {
                 ml[k] = read_table(br, lens, lut + (size_t)k * 32768);
                 if (ml[k] == 99) return kDecBadData;
+                if (ml[k] == 98) return kDecDeepTable;
             }
             for (uint32_t it = 0; it < n_items; it++) {
                 const uint32_t r = sym(br, lut + (after_literal ? 32768 : 0), ml[after_literal ? 1 : 0]);
@@ -358,6 +362,11 @@ inline MemberIndex index_members(const uint8_t* src, size_t n) {
             spos_end = end_field;
             at += t;
         }
+        // A member cannot code more than 4096 bytes per byte of its own: an item is at least one bit behind a non-empty
+        // Huffman table and at most 255 + 127 bytes long.  Streams that announce more (tables of zero-length codes,
+        // which no encoder writes, or plain lies about the size) are not sized on the device on their own word.
+        if ((uint64_t)(spos_end - kPre) > (uint64_t)(at - begin) * 4096 + 4096)
+            throw std::runtime_error("member announces more output than its bits can code: use the host decoder");
         ix.begin.push_back(begin);
         ix.end.push_back(at);
         ix.out_off.push_back(ix.out_total);
@@ -415,6 +424,7 @@ void decode_members_device(BE& be, const uint8_t* src, size_t n, std::vector<uin
     for (uint32_t m = 0; m < M; m++)
         if (status[m] != kDecOk)
             throw std::runtime_error(status[m] == kDecTooLarge ? "member larger than one block: use the host decoder"
+                                     : status[m] == kDecDeepTable ? "member with a 16-bit Huffman table: use the host decoder"
                                                                : "invalid orz data (member " + std::to_string(m) + ", status " + std::to_string(status[m]) + ")");
     stats.total_s = be.now() - t0;
 }

@@ -138,3 +138,12 @@ def test_cli_gpu_decode(oracle, tmp_path):
     r = subprocess.run([CLI, "decode", "-s", "--members", "--gpu", str(src), str(dst)], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert dst.read_bytes() == b"".join(parts)
+
+
+def test_size_claim_cap_leaves_the_most_compressible_members_alone(emu_decode, oracle):
+    """index_members refuses members that announce more than 4096 bytes per byte of their own; runs of one byte are the
+    densest thing an encoder writes (one 255-byte match per item of a few bits) and stay well below that"""
+    for data in (bytes(3_000_000), b"ab" * 1_000_000):
+        enc = oracle.encode(data, 2)
+        assert len(data) < 4096 * len(enc)
+        assert emu_decode(enc) == (data, 1)
