@@ -124,9 +124,9 @@ def main():
     def step():
         out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True)
         if distributed:  # the job's only exchange: gather the finished bitstreams on rank 0
-            got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None)
-            if rank == 0:
-                assert all(g is not None for g in got)
+            got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None, to_host=False)
+            if rank == 0:  # (the members of the other ranks stay in rank 0's HBM: gathered, not copied out again)
+                assert all(g is not None and len(g) > 0 for g in got)
         return out, st
 
     for _ in range(args.warmup):

@@ -19,10 +19,13 @@ def members_of_rank(n_members, rank, world):
     return list(range(rank, n_members, world))
 
 
-def gather_members(local, n_members, rank, world, device=None):
+def gather_members(local, n_members, rank, world, device=None, to_host=True):
     """local: {member index: bytes} encoded on this rank.  Returns the list of all members in member
     order on rank 0 (None elsewhere).  One all-gather of the sizes, then every rank sends exactly its bytes to
-    rank 0 (point-to-point: each peer has its own xGMI link to the root, nothing is padded)."""
+    rank 0 (point-to-point: each peer has its own xGMI link to the root, nothing is padded).
+    to_host=False leaves the members received from other ranks where they arrived (uint8 tensors on `device`): the
+    gather is complete when rank 0 holds the bytes, and a caller that only forwards or sizes them (bench.py) should
+    not pay for world-1 device-to-host copies on rank 0."""
     mine = members_of_rank(n_members, rank, world)
     assert sorted(local) == mine
     dev = device if device is not None else torch.device("cpu")
@@ -45,7 +48,7 @@ def gather_members(local, n_members, rank, world, device=None):
         elif total:
             buf = torch.empty(total, dtype=torch.uint8, device=dev)
             dist.recv(buf, src=r)
-            raw = buf.cpu().numpy().tobytes()
+            raw = buf.cpu().numpy().tobytes() if to_host else buf
         else:
             raw = b""
         at = 0

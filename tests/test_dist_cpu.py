@@ -20,7 +20,10 @@ def _worker(rank, world, port, n_members, q):
         # stand-in payloads: member m is a fake "stream" of m-dependent length ending in the EOF byte
         local = {m: bytes([1 + (m * 7 + i) % 250 for i in range(100 + 37 * m)]) for m in od.members_of_rank(n_members, rank, world)}
         got = od.gather_members(local, n_members, rank, world)
+        kept = od.gather_members(local, n_members, rank, world, to_host=False)  # members of other ranks stay tensors
         if rank == 0:
+            assert [bytes(k) if isinstance(k, bytes) else k.numpy().tobytes() for k in kept] == got
+            assert any(not isinstance(k, bytes) for k in kept)
             q.put([len(x) for x in got] + [sum(x[0] for x in got)])
     finally:
         dist.destroy_process_group()
