@@ -62,6 +62,15 @@ __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {
     k(w);
 }
 
+// two-phase kernels of one workgroup: phase0 by every thread, a barrier, phase1
+template <class K>
+__global__ __launch_bounds__(1024) void orz_group_kernel(K k) {
+    k.phase0(threadIdx.x, blockDim.x);
+    __threadfence_block();
+    __syncthreads();
+    k.phase1(threadIdx.x, blockDim.x);
+}
+
 // ring ordinals after a sweep (orz_parse.h): block = chunk of kRankChunk segments, thread = ctx
 __global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchunks, uint32_t nvblk) {
     __shared__ uint32_t rows[(kRankChunk + 1) * 256];
@@ -513,10 +522,9 @@ class HipBackend {
    public:
     explicit HipBackend(int device) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
-        ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[0], hipStreamNonBlocking));
-        ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[1], hipStreamNonBlocking));
+        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
         stream_ = streams_[0];
-        for (int i = 0; i < 2; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
+        for (int i = 0; i < kEvents; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
         // temp storage big enough for the largest sort / scan of a block
         size_t s1 = 0, s2 = 0;
         uint64_t* k = nullptr;
@@ -530,21 +538,17 @@ class HipBackend {
         ORZ_HIP_CHECK(rocprim::inclusive_scan(nullptr, s4, u, u, (size_t)kWLen, rocprim::maximum<uint32_t>(), stream_));
         if (s4 > s2) s2 = s4;
         tmp_bytes_ = (s1 > s2 ? s1 : s2) + 256;
-        ORZ_HIP_CHECK(hipMalloc(&tmps_[0], tmp_bytes_));
-        ORZ_HIP_CHECK(hipMalloc(&tmps_[1], tmp_bytes_));
+        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipMalloc(&tmps_[i], tmp_bytes_));
         tmp_ = tmps_[0];
     }
     ~HipBackend() {
         (void)hipSetDevice(device_);
-        (void)hipStreamSynchronize(streams_[0]);
-        (void)hipStreamSynchronize(streams_[1]);
-        (void)hipFree(tmps_[0]);
-        (void)hipFree(tmps_[1]);
-        for (int i = 0; i < 2; i++) (void)hipEventDestroy(sev_[i]);
+        for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamSynchronize(streams_[i]);
+        for (int i = 0; i < kStreams; i++) (void)hipFree(tmps_[i]);
+        for (int i = 0; i < kEvents; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         for (auto& kv : graph_exec_) (void)hipGraphExecDestroy(kv.second);
-        (void)hipStreamDestroy(streams_[0]);
-        (void)hipStreamDestroy(streams_[1]);
+        for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamDestroy(streams_[i]);
     }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;
@@ -559,7 +563,7 @@ class HipBackend {
     uint32_t near_blocks() const { return 0; }
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }
-    // second stream: the tail stage of a block overlaps the next block's parse (orz_stream.h)
+    // streams 1 and 2: the tail stage of a block (symbol ranking; Huffman + packing) overlaps the next block's parse (orz_stream.h)
     void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
     void wait(int ev) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, sev_[ev], 0)); }
@@ -638,6 +642,11 @@ class HipBackend {
         hipLaunchKernelGGL(orz_wave_kernel<K>, dim3((unsigned)nblocks), dim3(64), lds_bytes, stream_, k);
         ORZ_HIP_CHECK(hipGetLastError());
     }
+    template <class K>
+    void launch_group(const K& k) {
+        hipLaunchKernelGGL(orz_group_kernel<K>, dim3(1), dim3(1024), 0, stream_, k);
+        ORZ_HIP_CHECK(hipGetLastError());
+    }
     void huffbuild(const HuffBuild& f) {
         if (!f.nchunks) return;
         hipLaunchKernelGGL(orz_huff_kernel, dim3(f.nchunks * 3), dim3(64), 0, stream_, f);
@@ -652,6 +661,12 @@ class HipBackend {
         if (n == 0) return;
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(tmp_, sz, kin, kout, vin, vout, n, 0, (unsigned)bits, stream_));
+    }
+    // stable sort of the item indices 0..n-1 by their 9-bit symbol-ranking context
+    void sort_by_ctx(const uint16_t* ctx, uint16_t* ctx_sorted, uint32_t* perm, size_t n) {
+        if (n == 0) return;
+        size_t sz = tmp_bytes_;
+        ORZ_HIP_CHECK(rocprim::radix_sort_pairs(tmp_, sz, ctx, ctx_sorted, rocprim::counting_iterator<uint32_t>(0), perm, n, 0, 9, stream_));
     }
     const uint64_t* sort_u64(uint64_t* a, uint64_t* b, size_t n, int bits) {
         if (n == 0) return a;
@@ -694,8 +709,7 @@ class HipBackend {
     void set_timing(bool on) { timing_ = on; }
     // sums of the bracketed intervals in ms per slot since the last call, and their counts; returns slot 0's sum
     double collect_timed(uint64_t* launches, double* ms_by_slot = nullptr, uint64_t* n_by_slot = nullptr) {
-        ORZ_HIP_CHECK(hipStreamSynchronize(streams_[0]));
-        ORZ_HIP_CHECK(hipStreamSynchronize(streams_[1]));
+        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipStreamSynchronize(streams_[i]));
         double ms[kTimedSlots] = {0, 0, 0, 0};
         uint64_t cnt[kTimedSlots] = {0, 0, 0, 0};
         for (size_t i = 0; i + 1 < ev_used_; i += 2) {
@@ -754,9 +768,10 @@ class HipBackend {
    private:
     int device_;
     hipStream_t stream_ = nullptr;
-    hipStream_t streams_[2] = {nullptr, nullptr};
-    hipEvent_t sev_[2];
-    void* tmps_[2] = {nullptr, nullptr};
+    static constexpr int kStreams = 3, kEvents = 4;
+    hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t sev_[kEvents];
+    void* tmps_[kStreams] = {nullptr, nullptr, nullptr};
     int cur_ = 0;
     void* tmp_ = nullptr;
     size_t tmp_bytes_ = 0;

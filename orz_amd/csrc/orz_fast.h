@@ -56,7 +56,7 @@ struct FastArgs {
     uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
-    uint64_t* v1;               // bit per non-zero word of vbits (rebuilt after every path update: V1Build)
+    uint64_t* v1;               // bit per non-zero word of vbits (V1Build once per parse, then kept in step by FastFlip)
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
     uint32_t* bs;               // [n+8] best source (window offset)
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
@@ -84,12 +84,27 @@ ORZ_D void atom_xor64(uint64_t* p, uint64_t v) {
     *p ^= v;
 #endif
 }
+ORZ_D uint64_t atom_fetch_xor64(uint64_t* p, uint64_t v) {  // returns the old word
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)atomicXor((unsigned long long*)p, (unsigned long long)v);
+#else
+    const uint64_t o = *p;
+    *p = o ^ v;
+    return o;
+#endif
+}
 ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicSub(p, v);
 #else
     *p -= v;
 #endif
+}
+
+// runs (ctx, hash) that gained an item start in a repair pass: one bit per run key
+ORZ_D void mark_run(const uint8_t* win, uint64_t* rdirty, uint32_t x) {
+    const uint32_t key = bucket_key(win, x);
+    atom_or64(&rdirty[key >> 6], 1ull << (key & 63));
 }
 
 // ---- static per block --------------------------------------------------------------------------------
@@ -382,27 +397,32 @@ struct FastEval {
         a.bs[i] = bsrc;
     }
 };
-struct FastDecide {  // src/lz.rs:139-234 on the snapshot's answers
+// src/lz.rs:139-234 on the snapshot's answers: e = ev of the position, e1 / e2 = ev of the next two (0 past the end);
+// returns type | advance << 8
+ORZ_D uint32_t fast_decide(uint32_t p, uint32_t len, uint32_t e, uint32_t e1, uint32_t e2) {
+    uint32_t L = e & 0xff;
+    if (p + L >= len) L = len - 1 - p;  // an item never reaches the block end (src/matcher.rs:183)
+    if (L < kMinLen) L = 0;
+    const uint32_t lwm = (e >> 24) & 1;
+    uint32_t lazy = 0;
+    if (L > 0 && L < kMaxLen / 2) {
+        const uint32_t l1 = L + 1 + ((e >> 25) & 1), l2 = l1 - lwm;
+        if (((e1 >> 8) & 0xff) >= l1) lazy = 1;
+        else if (((e2 >> 16) & 0xff) >= l2) lazy = 2;
+    }
+    if (L > 0 && lazy == 0) return kTyMatch | (L << 8);
+    if (p + 1 < len && lazy != 1 && lwm) return kTyWord | (2u << 8);
+    return kTyLit | (1u << 8);
+}
+struct FastDecide {  // thread per position (the rounds run it inside PathUpWave)
     FastArgs a;
     uint32_t lo, hi;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
-        const uint32_t i = p - kPre, e = a.ev[i];
-        uint32_t L = e & 0xff;
-        if (p + L >= a.len) L = a.len - 1 - p;  // an item never reaches the block end (src/matcher.rs:183)
-        if (L < kMinLen) L = 0;
-        const uint32_t lwm = (e >> 24) & 1;
-        uint32_t lazy = 0;
-        if (L > 0 && L < kMaxLen / 2) {
-            const uint32_t l1 = L + 1 + ((e >> 25) & 1), l2 = l1 - lwm;
-            const uint32_t e1 = p + 1 < a.len ? a.ev[i + 1] : 0, e2 = p + 2 < a.len ? a.ev[i + 2] : 0;
-            if (((e1 >> 8) & 0xff) >= l1) lazy = 1;
-            else if (((e2 >> 16) & 0xff) >= l2) lazy = 2;
-        }
-        if (L > 0 && lazy == 0) { a.ty[i] = kTyMatch; a.nl[i] = (uint8_t)L; }
-        else if (p + 1 < a.len && lazy != 1 && lwm) { a.ty[i] = kTyWord; a.nl[i] = 2; }
-        else { a.ty[i] = kTyLit; a.nl[i] = 1; }
+        const uint32_t i = p - kPre;
+        const uint32_t d = fast_decide(p, a.len, a.ev[i], p + 1 < a.len ? a.ev[i + 1] : 0, p + 2 < a.len ? a.ev[i + 2] : 0);
+        a.ty[i] = (uint8_t)d; a.nl[i] = (uint8_t)(d >> 8);
     }
 };
 
@@ -450,9 +470,30 @@ struct PathUpWave {
         uint8_t* x0L = nlL + 64 * 68 + 32;
         const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
+        // the round's decisions (FastDecide) are made here, from the answers FastEval left: every wavefront of the chunk
+        // needs all 4096 advances in its LDS anyway; the first one also stores types and advances for the later kernels
         for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
             const uint32_t wi = k * 64 + lane, x = wi * 8;
-            uint64_t v = x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0;
+            uint64_t v = 0, ty = 0;
+            if (x < clen) {
+                const uint32_t* ep = a.ev + (cs - kPre) + x;  // (ev holds 8 entries past the block: zeros)
+                uint32_t e[10];
+                for (uint32_t b = 0; b < 10; b++) e[b] = ep[b];
+                for (uint32_t b = 0; b < 8 && x + b < clen; b++) {
+                    const uint32_t p = cs + x + b;
+                    const uint32_t d = fast_decide(p, a.len, e[b], p + 1 < a.len ? e[b + 1] : 0, p + 2 < a.len ? e[b + 2] : 0);
+                    ty |= (uint64_t)(d & 0xff) << (8 * b);
+                    v |= (uint64_t)(d >> 8) << (8 * b);
+                }
+                if (part == 0) {
+                    uint64_t keep = 0;  // bytes past the chunk's end keep what they hold (x + 8 > clen only in the block's last word)
+                    if (x + 8 > clen) keep = ~0ull << (8 * (clen - x));
+                    uint64_t* tp = reinterpret_cast<uint64_t*>(a.ty + (cs - kPre) + x);
+                    uint64_t* np = reinterpret_cast<uint64_t*>(a.nl + (cs - kPre) + x);
+                    *tp = (*tp & keep) | ty;
+                    *np = (*np & keep) | v;
+                }
+            }
             for (uint32_t b = 0; b < 8; b++) nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
         }
         w.sync();
@@ -482,17 +523,19 @@ struct PathUpWave {
         }
     }
 };
-struct PathMarkWave {  // one wavefront per chunk, lane = segment
+struct PathMarkWave {  // one wavefront per chunk, lane = segment; also the chunk's item starts per ctx (what CountWave counts)
     FastArgs a;
     uint32_t c0;
-    static size_t lds_bytes() { return 3 * (64 * 68 + 32); }
+    static size_t lds_bytes() { return 3 * (64 * 68 + 32) + 256 * 4; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint8_t* nlL = w.lds();
         uint8_t* x0L = nlL + 64 * 68 + 32;
         uint8_t* tyL = x0L + 64 * 68 + 32;
+        uint32_t* cnt = (uint32_t*)(tyL + 64 * 68 + 32);
         const uint32_t c = c0 + w.block(), lane = w.lane();
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
+        for (uint32_t k = lane; k < 256; k += 64) cnt[k] = 0;
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t wi = k * 64 + lane, x = wi * 8;
             uint64_t v = 0, u = 0, t = 0;
@@ -509,23 +552,28 @@ struct PathMarkWave {  // one wavefront per chunk, lane = segment
         }
         w.sync();
         const uint32_t s0 = lane * 64;
-        if (s0 >= clen) return;
-        const uint32_t s1 = fast_min(s0 + 64, clen);
-        const uint32_t ce = a.centry[c];
-        uint32_t x = ce >= cs ? ce - cs : 0;
-        while (x < s0) {
-            const uint32_t e1 = fast_min(((x >> 6) + 1) * 64, clen);
-            x = e1 + x0L[pad68(x)];
+        if (s0 < clen) {
+            const uint32_t s1 = fast_min(s0 + 64, clen);
+            const uint32_t ce = a.centry[c];
+            uint32_t x = ce >= cs ? ce - cs : 0;
+            while (x < s0) {
+                const uint32_t e1 = fast_min(((x >> 6) + 1) * 64, clen);
+                x = e1 + x0L[pad68(x)];
+            }
+            uint64_t m = 0;
+            const uint8_t* b = a.win + cs + s0;
+            while (x < s1) {
+                m |= 1ull << (x - s0);
+                atom_add32(&cnt[(uint32_t)(b[(int)(x - s0) - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)(x - s0) - 2]) << 7)], 1);
+                const uint32_t d = nlL[pad68(x)];
+                const uint32_t e = x + (d ? d : 1);
+                a.pt[(cs - kPre) + e] = tyL[pad68(x)];
+                x = e;
+            }
+            a.sbits[(cs - kPre) / 64 + lane] = m;
         }
-        uint64_t m = 0;
-        while (x < s1) {
-            m |= 1ull << (x - s0);
-            const uint32_t d = nlL[pad68(x)];
-            const uint32_t e = x + (d ? d : 1);
-            a.pt[(cs - kPre) + e] = tyL[pad68(x)];
-            x = e;
-        }
-        a.sbits[(cs - kPre) / 64 + lane] = m;
+        w.sync();
+        for (uint32_t k = lane; k < 256; k += 64) a.cm[(size_t)c * 256 + k] = cnt[k];
     }
 };
 ORZ_D uint32_t tile_end(uint32_t t, uint32_t tile, uint32_t len) { return fast_min(len, kPre + (t + 1) * tile); }
@@ -566,6 +614,20 @@ struct PathDown {  // thread per chunk of the range (+1 for the entry of the til
             if (x < end) x = end + a.x1[(size_t)cc * kEntries + (x - kPre - cc * kSub)];
         }
         a.centry[c] = x;
+    }
+};
+// PathTile then PathDown in one launch: a single workgroup, a barrier between the two (backend launch_group)
+struct PathTileDown {
+    FastArgs a;
+    uint32_t t0, nt;
+    ORZ_HD void phase0(uint32_t tid, uint32_t nth) const {
+        const PathTile f{a, t0, nt};
+        for (uint32_t e = tid; e < nt * kEntries; e += nth) f(e);
+    }
+    ORZ_HD void phase1(uint32_t tid, uint32_t nth) const {
+        const PathDown f{a, t0, nt};
+        const uint32_t cpt = a.tile / kSub;
+        for (uint32_t c = tid; c <= nt * cpt; c += nth) f(c);  // (PathDown drops the indices past the range's last chunk + 1)
     }
 };
 struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the type of every item at its end
@@ -614,8 +676,12 @@ struct FastFlip {
                 s |= (sb >> k) & 1;
                 if (s != ((mfw >> (8 * k)) & 0xff)) {
                     mfw = (mfw & ~(0xffull << (8 * k))) | ((uint64_t)s << (8 * k));
+                    // the summary level follows: every zero <-> non-zero transition of a word toggles its bit (the atomics on
+                    // a word are totally ordered and each transition is seen by exactly the operation that makes it, so the
+                    // toggles commute and the bit ends as "word non-zero" however they interleave)
                     const uint32_t j = a.idx[y];
-                    atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+                    const uint64_t bit = 1ull << (j & 63), old = atom_fetch_xor64(&a.vbits[j >> 6], bit);
+                    if ((old == 0) != ((old ^ bit) == 0)) atom_xor64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
                 }
             }
             if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
@@ -731,10 +797,20 @@ struct FastSource {
     FastArgs a;
     uint32_t* SRC;
     uint32_t* cutend;  // [n] old end of an item that lost part of its length in this pass (0 = none)
+    // Later passes (rdirty != nullptr) walk again only where the answer can have changed: the newest covering item start of
+    // a run is still the newest unless the run gained an item start in the previous pass (rdirty, set by FastRecut /
+    // FastWordCheck -- a new item's own run is marked, so new items are walked too), and it is still a ring member unless
+    // the ordinals between it and the item grew past the ring (checked here with the fresh ordinals).
+    const uint64_t* rdirty;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
         const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], K = a.K;
-        const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]), op = a.ORD[p];
+        const uint32_t op = a.ORD[p];
+        if (rdirty) {
+            const uint32_t key = bucket_key(a.win, p);
+            if (!((rdirty[key >> 6] >> (key & 63)) & 1) && op - 1 - a.ORD[SRC[p]] <= kRing - 1) return;
+        }
+        const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
         const uint8_t* row = a.rows + (size_t)i * K;
         uint32_t best = 0, bsrc = 0, seen = 0, found = 0;
         bool stop = false;
@@ -782,6 +858,7 @@ struct FastSource {
 struct FastRecut {  // the rest of a shortened item's span, from the last round's decisions, cut at the old end
     FastArgs a;
     uint32_t* cutend;
+    uint64_t* rdirty;  // runs that gain an item start here (read by the next pass's FastSource)
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || !cutend[i]) return;
         const uint32_t end = cutend[i];
@@ -798,6 +875,7 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
             }
             a.ty[xi] = (uint8_t)t; a.nl[xi] = (uint8_t)L;
             atom_or64(&a.sbits[xi / 64], 1ull << (xi & 63));
+            mark_run(a.win, rdirty, x);
             x += L;
             a.pt[x - kPre] = (uint8_t)t;
         }
@@ -824,6 +902,7 @@ ORZ_D uint32_t fast_word_at(const FastArgs& a, const uint32_t* laste, uint32_t p
 struct FastWordCheck {  // a WORD item whose prediction the exact state does not make becomes two literals
     FastArgs a;
     const uint32_t* laste;
+    uint64_t* rdirty;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
         const uint32_t p = kPre + (uint32_t)i;
@@ -833,6 +912,7 @@ struct FastWordCheck {  // a WORD item whose prediction the exact state does not
         a.ty[i] = kTyLit; a.nl[i] = 1;
         a.ty[i + 1] = kTyLit; a.nl[i + 1] = 1;
         atom_or64(&a.sbits[(i + 1) / 64], 1ull << ((i + 1) & 63));
+        mark_run(a.win, rdirty, p + 1);
         a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
     }
 };

@@ -224,37 +224,30 @@ ORZ_HD uint16_t symrank_encode(uint16_t* value, uint16_t* index, uint32_t& cnt, 
     return i - (i > iu);
 }
 
-struct SymKeys {  // key = ctx << 24 | item index
-    const uint16_t* ictx;
-    uint32_t n;
-    uint64_t* keys;
-    ORZ_HD void operator()(size_t tid) const {
-        if (tid < n) keys[tid] = ((uint64_t)ictx[tid] << 24) | tid;
-    }
-};
+// The items of each context side by side: a stable sort of the item indices by context (9 key bits; the backend's
+// sort_by_ctx) gives `perm` (sorted slot -> item) and `skey` (the sorted contexts).
 struct SymGather {  // contiguous (symbol | unlikely << 16) stream per context
-    const uint64_t* keys;
+    const uint32_t* perm;
     const uint16_t* isym;
     const uint8_t* iunl;
     uint32_t n;
     uint32_t* gsym;
     ORZ_HD void operator()(size_t tid) const {
         if (tid >= n) return;
-        uint32_t i = (uint32_t)(keys[tid] & 0xffffff);
+        const uint32_t i = perm[tid];
         gsym[tid] = isym[i] | ((uint32_t)iunl[i] << 16);
     }
 };
 struct SymRunStart {  // rstart[c] = first sorted slot with ctx >= c (binary search), c in [0,512]
-    const uint64_t* keys;
+    const uint16_t* skey;
     uint32_t n;
     uint32_t* rstart;
     ORZ_HD void operator()(size_t tid) const {
         if (tid > 512) return;
-        uint64_t want = (uint64_t)tid << 24;
         uint32_t lo = 0, hi = n;
         while (lo < hi) {
             uint32_t mid = (lo + hi) / 2;
-            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+            if (skey[mid] < tid) lo = mid + 1; else hi = mid;
         }
         rstart[tid] = lo;
     }
@@ -275,12 +268,12 @@ ORZ_HD void symrank_run(uint16_t* value, uint16_t* index, uint16_t* state, const
     state[2 * kSyms + 2] = (uint16_t)sum; state[2 * kSyms + 3] = (uint16_t)(sum >> 16);
 }
 struct SymScatter {
-    const uint64_t* keys;
+    const uint32_t* perm;
     const uint16_t* grank;
     uint32_t n;
     uint16_t* irank;
     ORZ_HD void operator()(size_t tid) const {
-        if (tid < n) irank[(uint32_t)(keys[tid] & 0xffffff)] = grank[tid];
+        if (tid < n) irank[perm[tid]] = grank[tid];
     }
 };
 

@@ -213,6 +213,7 @@ class StreamEncoder {
     static constexpr size_t kChunkCapWords = (size_t)kChunkItems * 40 / 32 + 8192;  // payload words per chunk
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
+    static constexpr uint32_t kDirtyWords = kNumKeys / 64 + 1;  // one bit per (ctx, hash) run
 
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
     // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
@@ -252,8 +253,6 @@ class StreamEncoder {
             // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
             entA_ = take<uint64_t>((size_t)kWLen);
             entB_ = take<uint64_t>((size_t)kWLen);
-            symA_ = take<uint64_t>((size_t)kNewMax);
-            symB_ = take<uint64_t>((size_t)kNewMax);
             epos_ = take<uint32_t>(kWLen);
             kpos_ = take<uint32_t>((size_t)kNewMax + 8);
             runstart_ = take<uint32_t>(kNumKeys + 1);
@@ -294,6 +293,7 @@ class StreamEncoder {
                 fcm_ = take<uint32_t>((size_t)(kNSub + 2) * 256);
                 fcp_ = take<uint32_t>((size_t)(kNSub + 2) * 256);
                 fcut_ = take<uint32_t>(nn);
+                frdirty_ = take<uint64_t>((size_t)2 * kDirtyWords);
                 flaste_ = take<uint32_t>(nn);
                 fnchg_ = take<uint32_t>(4);
                 fcstart_ = take<uint32_t>(260);
@@ -307,32 +307,36 @@ class StreamEncoder {
             tailkey_ = take<uint32_t>(4);
             wsnap_ = take<uint8_t>(65536);
             wlast_ = take<uint32_t>(32768);
-            // items
-            ipos_ = take<uint32_t>((size_t)kNewMax + 1);
-            isym_ = take<uint16_t>(kNewMax);
-            ictx_ = take<uint16_t>(kNewMax);
-            irank_ = take<uint16_t>(kNewMax);
-            irob_ = take<uint16_t>(kNewMax);
-            grank_ = take<uint16_t>(kNewMax);
-            iunl_ = take<uint8_t>(kNewMax);
-            ienc_ = take<uint8_t>(kNewMax);
-            ial_ = take<uint8_t>(kNewMax);
-            gsym_ = take<uint32_t>(kNewMax);
-            blen_ = take<uint32_t>(kNewMax);
-            bscan_ = take<uint32_t>(kNewMax);
-            rstart_ = take<uint32_t>(520);
+            // items and tail-stage buffers: two sets, taken by the blocks alternately (see post_stage)
+            for (TailSet& t : ts_) {
+                t.ipos = take<uint32_t>((size_t)kNewMax + 1);
+                t.isym = take<uint16_t>(kNewMax);
+                t.ictx = take<uint16_t>(kNewMax);
+                t.irank = take<uint16_t>(kNewMax);
+                t.irob = take<uint16_t>(kNewMax);
+                t.grank = take<uint16_t>(kNewMax);
+                t.skey = take<uint16_t>(kNewMax);
+                t.iunl = take<uint8_t>(kNewMax);
+                t.ienc = take<uint8_t>(kNewMax);
+                t.ial = take<uint8_t>(kNewMax);
+                t.gsym = take<uint32_t>(kNewMax);
+                t.sperm = take<uint32_t>(kNewMax);
+                t.blen = take<uint32_t>(kNewMax);
+                t.bscan = take<uint32_t>(kNewMax);
+                t.rstart = take<uint32_t>(520);
+                t.hw = take<uint32_t>((size_t)kMaxChunks * kHwStride);
+                t.hl = take<uint8_t>((size_t)kMaxChunks * kHwStride);
+                t.hc = take<uint16_t>((size_t)kMaxChunks * kHwStride);
+                t.hscr = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
+                t.hdrbits = take<uint32_t>(kMaxChunks);
+                t.tot = take<uint32_t>(kMaxChunks);
+                t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
+            }
             counts_ = take<uint32_t>(kSyms + 3);
             order_ = take<uint16_t>(kSyms + 3);
             ncounted_ = take<uint32_t>(4);
             srstate_ = take<uint16_t>((size_t)512 * kSrWords);
-            hw_ = take<uint32_t>((size_t)kMaxChunks * kHwStride);
-            hl_ = take<uint8_t>((size_t)kMaxChunks * kHwStride);
-            hc_ = take<uint16_t>((size_t)kMaxChunks * kHwStride);
-            hscr_ = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
-            hdrbits_ = take<uint32_t>(kMaxChunks);
-            tot_ = take<uint32_t>(kMaxChunks);
             outoff_ = take<uint64_t>(kMaxChunks);
-            out_ = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
             {
                 std::vector<uint64_t> off(kMaxChunks);
                 for (uint32_t i = 0; i < kMaxChunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
@@ -357,8 +361,10 @@ class StreamEncoder {
         be_.memset(LENMIN_, 0, kWLen);
         be_.memset(ctxcount_, 0, 256 * 4);
         be_.memset(wsnap_, 0, 65536);
-        be_.select(1); be_.sync(); be_.select(0);
-        pending_ = false;
+        be_.select(1); be_.sync(); be_.select(2); be_.sync(); be_.select(0);
+        for (TailSet& t : ts_) t.pending = false;
+        pend_order_.clear();
+        cur_set_ = 0;
         lt_carry_ = kTyLit;
         stream_start_ = true;
         stats = EncodeStats();
@@ -634,18 +640,14 @@ class StreamEncoder {
                 if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, fa0, fa1, fb0, fb1});
                 be_.timed_end();
-                be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
                 be_.launch_waves((size_t)nc * 4, PathUpWave{a, c0}, PathUpWave::lds_bytes());
                 be_.timed_end(3);
-                be_.launch((size_t)nt * kEntries, PathTile{a, t_lo, nt});
-                be_.launch((size_t)nc + 1, PathDown{a, t_lo, nt});
+                be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
                 be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1});
-                be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
-                be_.launch_waves(nc, CountWave{a, c0}, CountWave::lds_bytes());
                 be_.launch((size_t)nc * 256, FastPrefix{a, c0, c0 + nc});
                 stats.sweeps++;
             }
@@ -656,11 +658,11 @@ class StreamEncoder {
             uint32_t* cvals = (uint32_t*)entB_;
             uint32_t* fipos = cvals + kWLen;
             bool done = false;
+            static const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (experiments: every pass walks for every match)
             uint64_t total_repairs = 0;
             uint32_t nmem_last = 0;
             for (int pass = 0; pass < 200 && !done; pass++) {
                 be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
-                be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
                 be_.launch(n, MemberFlags32{fsbits_, n, f32_});
                 be_.exclusive_scan_u32(f32_, sc32_, n);
                 uint32_t x0, x1;
@@ -673,12 +675,16 @@ class StreamEncoder {
                 be_.launch(257, CtxStarts{ckeys2, nmem, fcstart_});
                 be_.launch(nmem, OrdAssign{ckeys2, cvals, fcstart_, ctxcount_, nmem, ORD_});
                 be_.memset(fnchg_, 0, 4);
-                be_.launch(n, FastSource{a, SRC_, fcut_});
-                be_.launch(n, FastRecut{a, fcut_});
+                // the first pass walks for every match; later ones only where the previous pass added item starts
+                uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
+                uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
+                be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
+                be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr});
+                be_.launch(n, FastRecut{a, fcut_, rd_out});
                 be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
                 be_.launch(nk, KbitVals{kbits_, nk, f32_});
                 be_.inclusive_max_scan_u32(f32_, flaste_, nk);
-                be_.launch(n, FastWordCheck{a, flaste_});
+                be_.launch(n, FastWordCheck{a, flaste_, rd_out});
                 uint32_t chg = 0;
                 be_.d2h(&chg, fnchg_, 4);
                 stats.seg_evals += chg;  // (fast mode: repairs made)
@@ -704,30 +710,39 @@ class StreamEncoder {
         lt_carry_ = last_ty;
     }
 
-    // Second half of a block: items -> len_min -> symbols -> symrank -> Huffman -> bit pack (shared by both parse modes)
+    // Second half of a block: items -> len_min -> symbols -> symrank -> Huffman -> bit pack (shared by both parse modes).
+    // Three streams: the item stage and the per-context gather run on the main stream behind the parse; the symbol-ranking
+    // launches of consecutive blocks follow each other on stream 1 (the per-context chains never reset, so that stream IS
+    // the serial chain of a stream: nothing else sits on it); histograms, Huffman and bit packing of block k run on stream 2
+    // beside the ranking of block k+1.  Blocks take the two buffer sets alternately: block k+2 reuses the set of block k
+    // after its output was collected.
     void post_stage(uint32_t n, uint32_t len, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends, double t2) {
         const uint8_t* win = dwin();
-        // ---- items (the item arrays are shared with the previous block's tail stage: let it finish)
-        if (pending_) be_.wait(1);
+        const int b = cur_set_;
+        cur_set_ ^= 1;
+        TailSet& t = ts_[b];
+        // ---- the block that used this set two blocks ago has long finished: take its output (in block order)
+        if (t.pending) collect_one(out, nullptr);
+        // ---- items
         be_.launch(n, Flags32{S_, n, f32_});
         be_.exclusive_scan_u32(f32_, sc32_, n);
         uint32_t a, b2;
         be_.d2h(&a, sc32_ + (n - 1), 4);
         be_.d2h(&b2, f32_ + (n - 1), 4);
         const uint32_t nitems = a + b2;
-        be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, ipos_});
+        be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
         // len_min of each reference (keys reuse the sort buffers)
-        be_.launch(nitems, LenMinKeys{ipos_, TY_, SRC_, nitems, entA_});
+        be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
         const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
         be_.launch(nitems, LenMinEval{lk, nitems, ML_, LENMIN_, LMV_});
         be_.launch(nitems, LenMinCommit{lk, nitems, ML_, LMV_, LENMIN_});
-        be_.launch(nitems, ItemSyms{win, ipos_, nitems, TY_, ML_, W0_, LMV_, SRC_, ORD_, isym_, ictx_, iunl_, ienc_, irob_,
-                                    ial_});
+        be_.launch(nitems, ItemSyms{win, t.ipos, nitems, TY_, ML_, W0_, LMV_, SRC_, ORD_, t.isym, t.ictx, t.iunl, t.ienc, t.irob,
+                                    t.ial});
         const uint32_t nchunks = (nitems + kChunkItems - 1) / kChunkItems;
         if (nchunks > kMaxChunks) throw std::runtime_error("too many chunks in a block");
         if (stream_start_) {  // src/lz.rs:238-265
             be_.memset(counts_, 0, (kSyms + 3) * 4);
-            be_.launch(std::min(nitems, kChunkItems), CensusCount{isym_, std::min(nitems, kChunkItems), counts_});
+            be_.launch(std::min(nitems, kChunkItems), CensusCount{t.isym, std::min(nitems, kChunkItems), counts_});
             be_.launch(kSyms, CensusOrder{counts_, order_, ncounted_});
             be_.launch((size_t)512 * kSyms, CensusFill{order_, srstate_});
         }
@@ -742,35 +757,34 @@ class StreamEncoder {
             be_.launch(32768, WordsApply{win, wlast_, len, (uint32_t)ltf, wsnap_});
             lt_carry_ = ltf;
         }  // (the fast mode carried its state at the end of fast_parse)
-
-        // ---- the previous block's tail has long finished: take its output, then start this block's tail
-        collect(out, nullptr);
-        be_.record(0);   // items of this block are ready on the main stream
+        // ---- the items of each context side by side (stable sort by context: 9 key bits), still on the main stream
+        be_.sort_by_ctx(t.ictx, t.skey, t.sperm, nitems);
+        be_.launch(nitems, SymGather{t.sperm, t.isym, t.iunl, nitems, t.gsym});
+        be_.launch(513, SymRunStart{t.skey, nitems, t.rstart});
+        be_.record(kEvItems + b);  // items of this block are ready
+        // ---- symbol ranking: 512 independent serial chains, launch after launch on stream 1
         be_.select(1);
-        be_.wait(0);
-        // symbol ranking: 512 independent serial chains
-        be_.launch(nitems, SymKeys{ictx_, nitems, symA_});
-        const uint64_t* sk = be_.sort_u64(symA_, symB_, nitems, 33);
-        be_.launch(nitems, SymGather{sk, isym_, iunl_, nitems, gsym_});
-        be_.launch(513, SymRunStart{sk, nitems, rstart_});
-        be_.symrank(srstate_, gsym_, grank_, rstart_);
-        be_.launch(nitems, SymScatter{sk, grank_, nitems, irank_});
-        // static Huffman per chunk
-        be_.memset(hw_, 0, (size_t)nchunks * kHwStride * 4);
-        be_.launch_waves(((size_t)nitems + 4095) / 4096, HistWave{irank_, ial_, ienc_, nitems, hw_}, HistWave::lds_bytes());
-        be_.huffbuild(HuffBuild{hw_, nchunks, hl_, hc_, hscr_});
-        be_.launch(nitems, ItemBits{irank_, ial_, ienc_, irob_, hl_, nitems, blen_});
-        be_.exclusive_scan_u32(blen_, bscan_, nitems);
-        // bit packing
-        be_.memset(out_, 0, (size_t)nchunks * kChunkCapWords * 4);
-        be_.launch(nchunks, ChunkHeader{hl_, nchunks, nitems, len, ipos_, order_, ncounted_, stream_start_ ? 1 : 0, out_,
-                                        outoff_, hdrbits_});
-        be_.launch(nitems, Pack{irank_, ial_, ienc_, irob_, hl_, hc_, bscan_, hdrbits_, outoff_, nitems, out_});
-        be_.launch(nchunks, ChunkTotals{bscan_, blen_, hdrbits_, nitems, nchunks, tot_});
-        be_.record(1);  // tail of this block done (the next block's item stage waits for it)
+        be_.wait(kEvItems + b);
+        be_.symrank(srstate_, t.gsym, t.grank, t.rstart);
+        be_.record(kEvRank + b);
+        // ---- static Huffman per chunk and bit packing on stream 2
+        be_.select(2);
+        be_.wait(kEvRank + b);
+        be_.launch(nitems, SymScatter{t.sperm, t.grank, nitems, t.irank});
+        be_.memset(t.hw, 0, (size_t)nchunks * kHwStride * 4);
+        be_.launch_waves(((size_t)nitems + 4095) / 4096, HistWave{t.irank, t.ial, t.ienc, nitems, t.hw}, HistWave::lds_bytes());
+        be_.huffbuild(HuffBuild{t.hw, nchunks, t.hl, t.hc, t.hscr});
+        be_.launch(nitems, ItemBits{t.irank, t.ial, t.ienc, t.irob, t.hl, nitems, t.blen});
+        be_.exclusive_scan_u32(t.blen, t.bscan, nitems);
+        be_.memset(t.out, 0, (size_t)nchunks * kChunkCapWords * 4);
+        be_.launch(nchunks, ChunkHeader{t.hl, nchunks, nitems, len, t.ipos, order_, ncounted_, stream_start_ ? 1 : 0, t.out,
+                                        outoff_, t.hdrbits});
+        be_.launch(nitems, Pack{t.irank, t.ial, t.ienc, t.irob, t.hl, t.hc, t.bscan, t.hdrbits, outoff_, nitems, t.out});
+        be_.launch(nchunks, ChunkTotals{t.bscan, t.blen, t.hdrbits, nitems, nchunks, t.tot});
         be_.select(0);
-        pending_ = true;
-        pend_nitems_ = nitems; pend_nchunks_ = nchunks; pend_len_ = len;
+        t.pending = true;
+        t.nitems = nitems; t.nchunks = nchunks; t.len = len; t.block = (uint32_t)stats.blocks;
+        pend_order_.push_back(b);
         stream_start_ = false;
         stats.t_post += be_.now() - t2;
         stats.blocks++;
@@ -780,44 +794,51 @@ class StreamEncoder {
         if (chunk_ends || trace) collect(out, chunk_ends);  // callers that need this block's bytes now
     }
 
-    // Append the output of the block whose tail stage is in flight (if any).
+    // Append the output of every block whose tail stage is in flight, oldest first.
     void collect(std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends) {
-        if (!pending_) return;
-        pending_ = false;
-        const uint32_t nitems = pend_nitems_, nchunks = pend_nchunks_, len = pend_len_;
-        be_.select(1);
+        while (!pend_order_.empty()) collect_one(out, pend_order_.size() == 1 ? chunk_ends : nullptr);
+    }
+    // ... of the oldest one
+    void collect_one(std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends) {
+        if (pend_order_.empty()) return;
+        TailSet& t = ts_[pend_order_.front()];
+        pend_order_.erase(pend_order_.begin());
+        t.pending = false;
+        const uint32_t nitems = t.nitems, nchunks = t.nchunks, len = t.len;
+        be_.select(2);
         std::vector<uint32_t> tot(nchunks);
-        be_.d2h(tot.data(), tot_, nchunks * 4);
+        be_.d2h(tot.data(), t.tot, nchunks * 4);
         for (uint32_t i = 0; i < nchunks; i++) {
-            size_t t = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
-            if (t / 4 > kChunkCapWords) throw std::runtime_error("chunk payload overflow");
-            size_t v = t;  // write_len, src/ioutil.rs:79-88
+            size_t tb = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
+            if (tb / 4 > kChunkCapWords) throw std::runtime_error("chunk payload overflow");
+            size_t v = tb;  // write_len, src/ioutil.rs:79-88
             while (v >= 128) { out.push_back((uint8_t)(128 + v % 128)); v /= 128; }
             out.push_back((uint8_t)v);
             size_t at = out.size();
-            out.resize(at + t);
-            be_.d2h(out.data() + at, out_ + (uint64_t)i * kChunkCapWords, t);
+            out.resize(at + tb);
+            be_.d2h(out.data() + at, t.out + (uint64_t)i * kChunkCapWords, tb);
             if (chunk_ends) {  // end_spos of the chunk, src/lz.rs:268
                 uint32_t i1 = (i + 1) << 20, e = len;
-                if (i1 < nitems) be_.d2h(&e, ipos_ + i1, 4);
+                if (i1 < nitems) be_.d2h(&e, t.ipos + i1, 4);
                 chunk_ends->push_back(e);
             }
         }
         if (trace) {
             const size_t at = trace->pos.size();
-            trace->block.resize(at + nitems, (uint32_t)(stats.blocks - 1));
+            trace->block.resize(at + nitems, t.block);
             trace->pos.resize(at + nitems); trace->sym.resize(at + nitems); trace->ctx.resize(at + nitems);
             trace->rank.resize(at + nitems); trace->rob.resize(at + nitems); trace->unl.resize(at + nitems);
             trace->enc.resize(at + nitems); trace->al.resize(at + nitems);
-            be_.d2h(trace->pos.data() + at, ipos_, (size_t)nitems * 4);
-            be_.d2h(trace->sym.data() + at, isym_, (size_t)nitems * 2);
-            be_.d2h(trace->ctx.data() + at, ictx_, (size_t)nitems * 2);
-            be_.d2h(trace->rank.data() + at, irank_, (size_t)nitems * 2);
-            be_.d2h(trace->rob.data() + at, irob_, (size_t)nitems * 2);
-            be_.d2h(trace->unl.data() + at, iunl_, nitems);
-            be_.d2h(trace->enc.data() + at, ienc_, nitems);
-            be_.d2h(trace->al.data() + at, ial_, nitems);
+            be_.d2h(trace->pos.data() + at, t.ipos, (size_t)nitems * 4);
+            be_.d2h(trace->sym.data() + at, t.isym, (size_t)nitems * 2);
+            be_.d2h(trace->ctx.data() + at, t.ictx, (size_t)nitems * 2);
+            be_.d2h(trace->rank.data() + at, t.irank, (size_t)nitems * 2);
+            be_.d2h(trace->rob.data() + at, t.irob, (size_t)nitems * 2);
+            be_.d2h(trace->unl.data() + at, t.iunl, nitems);
+            be_.d2h(trace->enc.data() + at, t.ienc, nitems);
+            be_.d2h(trace->al.data() + at, t.ial, nitems);
             // match source and length of each item (window offsets), gathered on the host: diagnostics only
+            // (callers that trace collect every block at once, so the per-position arrays still describe this block)
             std::vector<uint32_t> hsrc(len);
             std::vector<uint8_t> hml(len);
             be_.d2h(hsrc.data() + kPre, SRC_ + kPre, (size_t)(len - kPre) * 4);
@@ -873,12 +894,26 @@ class StreamEncoder {
     uint16_t* fkw_ = nullptr;
     uint32_t *fev_ = nullptr, *fbs_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
              *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
-    uint64_t *fsbits_ = nullptr, *fstext_ = nullptr;
+    uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
-    bool pending_ = false;
-    uint32_t pend_nitems_ = 0, pend_nchunks_ = 0, pend_len_ = 0;
-    uint64_t *symA_, *symB_;
+    // buffers of the item stage and the tail stage, two sets (block parity)
+    struct TailSet {
+        uint32_t* ipos = nullptr;
+        uint16_t *isym = nullptr, *ictx = nullptr, *irank = nullptr, *irob = nullptr, *grank = nullptr, *skey = nullptr;
+        uint8_t *iunl = nullptr, *ienc = nullptr, *ial = nullptr;
+        uint32_t *gsym = nullptr, *sperm = nullptr, *blen = nullptr, *bscan = nullptr, *rstart = nullptr;
+        uint32_t* hw = nullptr;
+        uint8_t* hl = nullptr;
+        uint16_t* hc = nullptr;
+        uint32_t *hscr = nullptr, *hdrbits = nullptr, *tot = nullptr, *out = nullptr;
+        bool pending = false;
+        uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
+    };
+    static constexpr int kEvItems = 0, kEvRank = 2;  // event numbers (+ set index)
+    TailSet ts_[2];
+    int cur_set_ = 0;
+    std::vector<int> pend_order_;  // sets whose output is still on the device, oldest first
     uint8_t* winbuf_;
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
     uint32_t *ORD_, *SRC_;
@@ -893,19 +928,11 @@ class StreamEncoder {
     uint32_t *f32_, *sc32_, *hpos_, *ctxcount_, *tailkey_;
     uint8_t* wsnap_;
     uint32_t* wlast_;
-    uint32_t* ipos_;
-    uint16_t *isym_, *ictx_, *irank_, *irob_, *grank_;
-    uint8_t *iunl_, *ienc_, *ial_;
-    uint32_t *gsym_, *blen_, *bscan_, *rstart_, *counts_;
+    uint32_t* counts_;
     uint16_t* order_;
     uint32_t* ncounted_;
     uint16_t* srstate_;
-    uint32_t* hw_;
-    uint8_t* hl_;
-    uint16_t* hc_;
-    uint32_t *hscr_, *hdrbits_, *tot_;
     uint64_t* outoff_;
-    uint32_t* out_;
 };
 
 // orz::encode (src/lib.rs:58-92) over a memory buffer that the backend can read with h2d():

@@ -53,6 +53,10 @@ struct EmuBackend {
     template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
     }
+    template <class K> void launch_group(const K& k) {
+        for (uint32_t t = 0; t < 1024; t++) k.phase0(t, 1024);
+        for (uint32_t t = 0; t < 1024; t++) k.phase1(t, 1024);
+    }
     void huffbuild(const orz::HuffBuild& f) { launch((size_t)f.nchunks * 3, f); }
     void rank(const orz::RankArgs& a, uint32_t nchunks) {
         // one block per chunk, 256 threads around one barrier: run each block as two thread loops
@@ -97,6 +101,11 @@ struct EmuBackend {
         uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
         std::stable_sort(a, a + n, [mask](uint64_t x, uint64_t y) { return (x & mask) < (y & mask); });
         return a;
+    }
+    void sort_by_ctx(const uint16_t* ctx, uint16_t* ctx_sorted, uint32_t* perm, size_t n) {
+        std::iota(perm, perm + n, 0u);
+        std::stable_sort(perm, perm + n, [&](uint32_t x, uint32_t y) { return ctx[x] < ctx[y]; });
+        for (size_t i = 0; i < n; i++) ctx_sorted[i] = ctx[perm[i]];
     }
     void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits) {
         uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1);
