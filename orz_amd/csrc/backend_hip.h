@@ -62,13 +62,17 @@ __global__ __launch_bounds__(64) void orz_wave_kernel(K k) {
     k(w);
 }
 
-// two-phase kernels of one workgroup: phase0 by every thread, a barrier, phase1
+// kernels of ONE workgroup that run K::kPhases phases with a barrier between them, dynamic LDS
 template <class K>
-__global__ __launch_bounds__(1024) void orz_group_kernel(K k) {
-    k.phase0(threadIdx.x, blockDim.x);
-    __threadfence_block();
-    __syncthreads();
-    k.phase1(threadIdx.x, blockDim.x);
+__global__ __launch_bounds__(1024) void orz_group_kernel(K k, bool use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t orz_dyn_lds[];
+    for (uint32_t ph = 0; ph < K::kPhases; ph++) {
+        if (ph) {
+            __threadfence_block();
+            __syncthreads();
+        }
+        k.phase(ph, threadIdx.x, blockDim.x, orz_dyn_lds, use_lds);
+    }
 }
 
 // ring ordinals after a sweep (orz_parse.h): block = chunk of kRankChunk segments, thread = ctx
@@ -644,7 +648,8 @@ class HipBackend {
     }
     template <class K>
     void launch_group(const K& k) {
-        hipLaunchKernelGGL(orz_group_kernel<K>, dim3(1), dim3(1024), 0, stream_, k);
+        const size_t lds = k.lds_bytes();
+        hipLaunchKernelGGL(orz_group_kernel<K>, dim3(1), dim3(1024), lds, stream_, k, lds != 0);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void huffbuild(const HuffBuild& f) {

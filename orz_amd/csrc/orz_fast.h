@@ -414,7 +414,7 @@ ORZ_D uint32_t fast_decide(uint32_t p, uint32_t len, uint32_t e, uint32_t e1, ui
     if (p + 1 < len && lazy != 1 && lwm) return kTyWord | (2u << 8);
     return kTyLit | (1u << 8);
 }
-struct FastDecide {  // thread per position (the rounds run it inside PathUpWave)
+struct FastDecide {  // thread per position (measured: inside PathUpWave the four wavefronts of a chunk each pay for it, +20 us a step)
     FastArgs a;
     uint32_t lo, hi;
     ORZ_HD void operator()(size_t tid) const {
@@ -470,30 +470,9 @@ struct PathUpWave {
         uint8_t* x0L = nlL + 64 * 68 + 32;
         const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
-        // the round's decisions (FastDecide) are made here, from the answers FastEval left: every wavefront of the chunk
-        // needs all 4096 advances in its LDS anyway; the first one also stores types and advances for the later kernels
         for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
             const uint32_t wi = k * 64 + lane, x = wi * 8;
-            uint64_t v = 0, ty = 0;
-            if (x < clen) {
-                const uint32_t* ep = a.ev + (cs - kPre) + x;  // (ev holds 8 entries past the block: zeros)
-                uint32_t e[10];
-                for (uint32_t b = 0; b < 10; b++) e[b] = ep[b];
-                for (uint32_t b = 0; b < 8 && x + b < clen; b++) {
-                    const uint32_t p = cs + x + b;
-                    const uint32_t d = fast_decide(p, a.len, e[b], p + 1 < a.len ? e[b + 1] : 0, p + 2 < a.len ? e[b + 2] : 0);
-                    ty |= (uint64_t)(d & 0xff) << (8 * b);
-                    v |= (uint64_t)(d >> 8) << (8 * b);
-                }
-                if (part == 0) {
-                    uint64_t keep = 0;  // bytes past the chunk's end keep what they hold (x + 8 > clen only in the block's last word)
-                    if (x + 8 > clen) keep = ~0ull << (8 * (clen - x));
-                    uint64_t* tp = reinterpret_cast<uint64_t*>(a.ty + (cs - kPre) + x);
-                    uint64_t* np = reinterpret_cast<uint64_t*>(a.nl + (cs - kPre) + x);
-                    *tp = (*tp & keep) | ty;
-                    *np = (*np & keep) | v;
-                }
-            }
+            uint64_t v = x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0;
             for (uint32_t b = 0; b < 8; b++) nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
         }
         w.sync();
@@ -577,57 +556,66 @@ struct PathMarkWave {  // one wavefront per chunk, lane = segment; also the chun
     }
 };
 ORZ_D uint32_t tile_end(uint32_t t, uint32_t tile, uint32_t len) { return fast_min(len, kPre + (t + 1) * tile); }
-struct PathTile {
-    FastArgs a;
-    uint32_t t0, nt;
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t t = t0 + (uint32_t)(tid / kEntries), e = (uint32_t)(tid % kEntries);
-        if (t >= t0 + nt) return;
-        const uint32_t end = tile_end(t, a.tile, a.len);
-        uint32_t x = kPre + t * a.tile + e;
-        while (x < end) {
-            const uint32_t c = (x - kPre) / kSub;
-            x = chunk_end(c, a.len) + a.x1[(size_t)c * kEntries + (x - kPre - c * kSub)];
-        }
-        a.x2[(size_t)t * kEntries + e] = (uint8_t)(x >= end ? x - end : 0);
-    }
-};
-struct PathDown {  // thread per chunk of the range (+1 for the entry of the tile after the range)
-    FastArgs a;
-    uint32_t t0, nt;  // tiles of the range
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t cpt = a.tile / kSub;
-        const uint32_t c0 = t0 * cpt;
-        const uint32_t nchunks = (fast_min(a.len, kPre + (t0 + nt) * a.tile) - (kPre + c0 * kSub) + kSub - 1) / kSub;
-        if (tid > nchunks) return;
-        const bool tail = tid == nchunks;
-        const uint32_t c = c0 + (uint32_t)tid, t = tail ? t0 + nt : c / cpt;
-        uint32_t x = a.tentry[t0];
-        for (uint32_t tt = t0; tt < t; tt++) {
-            const uint32_t end = tile_end(tt, a.tile, a.len);
-            if (x < end) x = end + a.x2[(size_t)tt * kEntries + (x - kPre - tt * a.tile)];
-        }
-        if (tail) { a.tentry[t] = x; return; }
-        if (c == t * cpt && t > t0) a.tentry[t] = x;
-        for (uint32_t cc = t * cpt; cc < c; cc++) {
-            const uint32_t end = chunk_end(cc, a.len);
-            if (x < end) x = end + a.x1[(size_t)cc * kEntries + (x - kPre - cc * kSub)];
-        }
-        a.centry[c] = x;
-    }
-};
-// PathTile then PathDown in one launch: a single workgroup, a barrier between the two (backend launch_group)
+// Per (tile, entry) exits, then the entries top-down (tile -> chunk), in ONE launch of one workgroup: the chunk maps of the
+// range are staged in LDS first (a walk is a chain of dependent loads: ~32 per tile entry, ~35 per chunk entry), the
+// tile maps stay there too.  Three phases around two barriers (backend launch_group).
 struct PathTileDown {
     FastArgs a;
     uint32_t t0, nt;
-    ORZ_HD void phase0(uint32_t tid, uint32_t nth) const {
-        const PathTile f{a, t0, nt};
-        for (uint32_t e = tid; e < nt * kEntries; e += nth) f(e);
+    static constexpr uint32_t kPhases = 3;
+    static constexpr size_t kLdsMax = 64 * 1024;
+    ORZ_HD uint32_t range_chunks() const {
+        const uint32_t cpt = a.tile / kSub, c0 = t0 * cpt;
+        const uint32_t end = kPre + (t0 + nt) * a.tile;
+        return ((a.len < end ? a.len : end) - (kPre + c0 * kSub) + kSub - 1) / kSub;
     }
-    ORZ_HD void phase1(uint32_t tid, uint32_t nth) const {
-        const PathDown f{a, t0, nt};
-        const uint32_t cpt = a.tile / kSub;
-        for (uint32_t c = tid; c <= nt * cpt; c += nth) f(c);  // (PathDown drops the indices past the range's last chunk + 1)
+    size_t lds_bytes() const {  // 0 = the range's maps do not fit: walk them in global memory
+        const size_t need = ((size_t)range_chunks() + nt) * kEntries + 16;
+        return need <= kLdsMax ? need : 0;
+    }
+    ORZ_HD void phase(uint32_t ph, uint32_t tid, uint32_t nth, uint8_t* lds, bool use_lds) const {
+        const uint32_t cpt = a.tile / kSub, c0 = t0 * cpt, nch = range_chunks();
+        uint8_t* x2L = lds + (((size_t)nch * kEntries + 15) & ~(size_t)15);
+        // maps of chunk c0 / tile t0 onwards: the staged copies or the arrays themselves (indexed relative to c0 / t0; a
+        // biased LDS pointer would leave the LDS aperture as a flat address)
+        const uint8_t* x1p = use_lds ? lds : a.x1 + (size_t)c0 * kEntries;
+        uint8_t* x2p = use_lds ? x2L : a.x2 + (size_t)t0 * kEntries;
+        if (ph == 0) {
+            if (!use_lds) return;
+            const uint8_t* src = a.x1 + (size_t)c0 * kEntries;  // (c0 * 240 is a multiple of 16)
+            const uint32_t nw = nch * kEntries / 4;
+            for (uint32_t k = tid; k < nw; k += nth) reinterpret_cast<uint32_t*>(lds)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+        } else if (ph == 1) {
+            for (uint32_t k = tid; k < nt * kEntries; k += nth) {
+                const uint32_t t = t0 + k / kEntries, e = k % kEntries;
+                const uint32_t end = tile_end(t, a.tile, a.len);
+                uint32_t x = kPre + t * a.tile + e;
+                while (x < end) {
+                    const uint32_t c = (x - kPre) / kSub;
+                    x = chunk_end(c, a.len) + x1p[(size_t)(c - c0) * kEntries + (x - kPre - c * kSub)];
+                }
+                const uint8_t v = (uint8_t)(x >= end ? x - end : 0);
+                a.x2[(size_t)t * kEntries + e] = v;
+                if (use_lds) x2p[(size_t)(t - t0) * kEntries + e] = v;
+            }
+        } else {
+            for (uint32_t k = tid; k <= nch; k += nth) {  // chunk k of the range; k == nch: the entry of the tile after the range
+                const bool tail = k == nch;
+                const uint32_t c = c0 + k, t = tail ? t0 + nt : c / cpt;
+                uint32_t x = a.tentry[t0];
+                for (uint32_t tt = t0; tt < t; tt++) {
+                    const uint32_t end = tile_end(tt, a.tile, a.len);
+                    if (x < end) x = end + x2p[(size_t)(tt - t0) * kEntries + (x - kPre - tt * a.tile)];
+                }
+                if (tail) { a.tentry[t] = x; continue; }
+                if (c == t * cpt && t > t0) a.tentry[t] = x;
+                for (uint32_t cc = t * cpt; cc < c; cc++) {
+                    const uint32_t end = chunk_end(cc, a.len);
+                    if (x < end) x = end + x1p[(size_t)(cc - c0) * kEntries + (x - kPre - cc * kSub)];
+                }
+                a.centry[c] = x;
+            }
+        }
     }
 };
 struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the type of every item at its end
@@ -740,13 +728,19 @@ struct FastPrefix {  // cp[s][c] = cp[s0][c] + sum of cm[s0 .. s)[c] for s in (s
     }
 };
 
-struct FastPrefixSerial {  // whole block, thread per ctx (the loads do not depend on each other, only the adds chain)
+struct FastPrefixSerial {  // whole block, thread per ctx: sixteen independent loads in flight, then the chain of adds
     FastArgs a;
     uint32_t s0, s1;
     ORZ_HD void operator()(size_t c) const {
         if (c >= 256) return;
         uint32_t v = a.cp[(size_t)s0 * 256 + c];
-        for (uint32_t s = s0; s < s1; s++) {
+        uint32_t s = s0;
+        for (; s + 16 <= s1; s += 16) {
+            uint32_t m[16];
+            for (uint32_t k = 0; k < 16; k++) m[k] = a.cm[(size_t)(s + k) * 256 + c];
+            for (uint32_t k = 0; k < 16; k++) { v += m[k]; a.cp[(size_t)(s + k + 1) * 256 + c] = v; }
+        }
+        for (; s < s1; s++) {
             v += a.cm[(size_t)s * 256 + c];
             a.cp[(size_t)(s + 1) * 256 + c] = v;
         }
@@ -802,6 +796,7 @@ struct FastSource {
     // FastWordCheck -- a new item's own run is marked, so new items are walked too), and it is still a ring member unless
     // the ordinals between it and the item grew past the ring (checked here with the fresh ordinals).
     const uint64_t* rdirty;
+    uint32_t cap;  // item starts examined beyond the tabulated window before the search gives up (the item is cut then)
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
         const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], K = a.K;
@@ -837,6 +832,7 @@ struct FastSource {
             const uint32_t top = j - K;
             const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
             const uint64_t a0 = ldu64(a.win + p), a1 = ldu64(a.win + p + 8);
+            uint32_t left = cap;
             far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
                 const uint32_t l = far_lcp(a, p, a0, a1, sl);
                 if (l >= kMinLen && (l >= L || l > best)) {
@@ -845,7 +841,7 @@ struct FastSource {
                     if (l >= L) { found = q; return false; }
                     best = l; bsrc = q;
                 }
-                return true;
+                return --left != 0;
             });
         }
         if (found) { SRC[p] = found; return; }

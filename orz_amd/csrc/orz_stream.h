@@ -640,6 +640,7 @@ class StreamEncoder {
                 if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, fa0, fa1, fb0, fb1});
                 be_.timed_end();
+                be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
                 be_.launch_waves((size_t)nc * 4, PathUpWave{a, c0}, PathUpWave::lds_bytes());
@@ -659,6 +660,7 @@ class StreamEncoder {
             uint32_t* fipos = cvals + kWLen;
             bool done = false;
             static const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (experiments: every pass walks for every match)
+            static const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 256;  // (0 = no limit)
             uint64_t total_repairs = 0;
             uint32_t nmem_last = 0;
             for (int pass = 0; pass < 200 && !done; pass++) {
@@ -679,7 +681,7 @@ class StreamEncoder {
                 uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
                 uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
                 be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
-                be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr});
+                be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap});
                 be_.launch(n, FastRecut{a, fcut_, rd_out});
                 be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
                 be_.launch(nk, KbitVals{kbits_, nk, f32_});

@@ -54,8 +54,10 @@ struct EmuBackend {
         simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
     }
     template <class K> void launch_group(const K& k) {
-        for (uint32_t t = 0; t < 1024; t++) k.phase0(t, 1024);
-        for (uint32_t t = 0; t < 1024; t++) k.phase1(t, 1024);
+        const size_t lds = k.lds_bytes();
+        std::vector<uint8_t> mem(lds + 64);
+        for (uint32_t ph = 0; ph < K::kPhases; ph++)
+            for (uint32_t t = 0; t < 1024; t++) k.phase(ph, t, 1024, mem.data(), lds != 0);
     }
     void huffbuild(const orz::HuffBuild& f) { launch((size_t)f.nchunks * 3, f); }
     void rank(const orz::RankArgs& a, uint32_t nchunks) {
