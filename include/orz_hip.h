@@ -108,6 +108,7 @@ typedef struct {
     int mode;
     unsigned segment_bytes, window_segments;               /* exact mode: speculative segment / sweep window */
     unsigned fast_tile_bytes, fast_rounds, fast_row_entries; /* fast mode: Gauss-Seidel tile, rounds, candidates tabulated per position */
+    unsigned unit_bytes;  /* bytes of a 16 MiB block encoded per pipeline unit (the whole block unless ORZ_FAST_UNIT says otherwise; a unit closes its last chunk) */
 } orz_stream_config;
 /* what the encoder actually runs with (bench.py reports these instead of literals) */
 int orz_stream_get_config(orz_stream*, orz_stream_config* out);

@@ -45,6 +45,7 @@ class StreamConfig(ctypes.Structure):  # orz_stream_config
     _fields_ = [
         ("mode", ctypes.c_int), ("segment_bytes", ctypes.c_uint), ("window_segments", ctypes.c_uint),
         ("fast_tile_bytes", ctypes.c_uint), ("fast_rounds", ctypes.c_uint), ("fast_row_entries", ctypes.c_uint),
+        ("unit_bytes", ctypes.c_uint),
     ]
 
     def as_dict(self):

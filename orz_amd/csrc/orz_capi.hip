@@ -181,6 +181,7 @@ int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
     out->fast_tile_bytes = s->enc->fast_tile();
     out->fast_rounds = s->enc->fast_rounds();
     out->fast_row_entries = s->enc->fast_row();
+    out->unit_bytes = s->enc->unit_bytes();
     return ORZ_OK;
 }
 int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
@@ -585,7 +586,7 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
             first = false;
             be.h2d_pinned(enc.dwin() + orz::kPre, in.data(), got);  // encode_block syncs before `in` is refilled
             out.clear();
-            enc.encode_block((uint32_t)got, out);
+            enc.encode_block_units((uint32_t)got, in_total == 0 && got == in.size(), out);
             if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }
             in_total += got;
             out_total += out.size();

@@ -506,6 +506,7 @@ ORZ_HD uint64_t put_table(uint32_t* out, uint64_t bitpos, const uint8_t* lens, u
 struct ChunkHeader {
     const uint8_t* hl;
     uint32_t nchunks, nitems, len;
+    uint32_t pos_base;         // bytes of the decoder's block that precede this encoder window's new region (units of a block)
     const uint32_t* ipos;
     const uint16_t* order;     // census order (first chunk of the stream only)
     const uint32_t* ncounted;
@@ -525,7 +526,7 @@ struct ChunkHeader {
         uint32_t i0 = (uint32_t)tid << 20;
         uint32_t i1 = i0 + kChunkItems < nitems ? i0 + kChunkItems : nitems;
         uint32_t end_spos = i1 < nitems ? ipos[i1] : len;  // src/lz.rs:268
-        bp = put_varint(o, bp, end_spos);
+        bp = put_varint(o, bp, end_spos + pos_base);  // (the position in the DECODER's window)
         bp = put_varint(o, bp, i1 - i0);
         const uint8_t* l = hl + (size_t)tid * kHwStride;
         bp = put_table(o, bp, l, kSyms);
@@ -587,14 +588,16 @@ struct WordsApply {
     }
 };
 
-// window slide for per-position arrays: dst[x] = src[x + 2^24] for x in [0,P), slot 0 invalid
+// window slide by `sh` positions for per-position arrays, in place: a[x] = a[x + sh] for x in [off, off + sh) -- the
+// caller walks off upwards so that a launch never reads what it writes; slot 0 is invalid
 template <class T>
 struct SlideArray {
-    const T* src;
-    T* dst;
+    T* a;
+    uint32_t off, sh, end;  // end: first position not to write (kPre)
     ORZ_HD void operator()(size_t tid) const {
-        if (tid >= kPre) return;
-        dst[tid] = tid == 0 ? (T)0 : src[tid + kNewMax];
+        const uint32_t x = off + (uint32_t)tid;
+        if (tid >= sh || x >= end) return;
+        a[x] = x == 0 ? (T)0 : a[x + sh];
     }
 };
 }  // namespace orz

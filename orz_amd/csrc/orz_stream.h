@@ -228,6 +228,8 @@ class StreamEncoder {
             fK_ = 64;  // (deeper runs are searched through the bitmap + the text records: FastEval's far search)
             if (const char* k = getenv("ORZ_FAST_K")) fK_ = (uint32_t)atoi(k);  // experiments
             if (fK_ < 64 || fK_ > 192 || fK_ % 64) throw std::runtime_error("ORZ_FAST_K must be 64, 128 or 192");
+            if (const char* u = getenv("ORZ_FAST_UNIT")) unit_ = (uint32_t)atoi(u);
+            if (unit_ < (1u << 20) || unit_ > kNewMax || unit_ % kSub) throw std::runtime_error("ORZ_FAST_UNIT must be a multiple of 4096 in [1 MiB, 16 MiB]");
         }
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
@@ -378,6 +380,7 @@ class StreamEncoder {
     uint32_t fast_tile() const { return ftile_; }
     void set_lead_block(bool on) { lead_block_ = on; }  // the next block leads a multi-block stream (see fast_parse)
     uint32_t fast_rounds() const { return frounds_; }
+    uint32_t unit_bytes() const { return fast_ ? unit_ : kNewMax; }
     uint32_t fast_row() const { return fK_; }
 
     // Encode the block whose n new bytes sit at dwin()[kPre, kPre+n).  Appends
@@ -387,6 +390,7 @@ class StreamEncoder {
     // overlaps the next block's prep + parse; its output is appended by the next call, or by finish().
     void encode_block(uint32_t n, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
+        last_n_ = n;
         double t0 = be_.now();
         const uint8_t* win = dwin();
         const uint32_t len = kPre + n;
@@ -599,6 +603,7 @@ class StreamEncoder {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
+            if (n >= unit_) T = ftile_;  // (a full unit is not a short input)
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it takes tiles twice the size -- half the steps, ~+0.1 % on that block's output.
             if (lead_block_ && T == ftile_) T = 2 * ftile_;
@@ -622,7 +627,7 @@ class StreamEncoder {
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
-            const bool use_graph = be_.graphs_enabled() && n == kNewMax;
+            const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
             const bool replayed = use_graph && be_.graph_replay(gkey);
             if (use_graph && !replayed) be_.graph_capture_begin();
@@ -779,7 +784,7 @@ class StreamEncoder {
         be_.launch(nitems, ItemBits{t.irank, t.ial, t.ienc, t.irob, t.hl, nitems, t.blen});
         be_.exclusive_scan_u32(t.blen, t.bscan, nitems);
         be_.memset(t.out, 0, (size_t)nchunks * kChunkCapWords * 4);
-        be_.launch(nchunks, ChunkHeader{t.hl, nchunks, nitems, len, t.ipos, order_, ncounted_, stream_start_ ? 1 : 0, t.out,
+        be_.launch(nchunks, ChunkHeader{t.hl, nchunks, nitems, len, unit_base_, t.ipos, order_, ncounted_, stream_start_ ? 1 : 0, t.out,
                                         outoff_, t.hdrbits});
         be_.launch(nitems, Pack{t.irank, t.ial, t.ienc, t.irob, t.hl, t.hc, t.bscan, t.hdrbits, outoff_, nitems, t.out});
         be_.launch(nchunks, ChunkTotals{t.bscan, t.blen, t.hdrbits, nitems, nchunks, t.tot});
@@ -860,14 +865,39 @@ class StreamEncoder {
     // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
     // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.
     // `slide_window` false = the caller re-uploads the whole window itself (object-level API).
-    void slide(bool slide_window = true) {
-        be_.launch(3, TailKeys{dwin(), kBlock, tailkey_});  // only full blocks are ever slid (src/lib.rs:72-84)
-        if (slide_window) be_.d2d(dwin(), dwin() + kNewMax, kPre);
-        be_.launch(kPre, SlideArray<uint8_t>{S_, S_});
-        be_.launch(kPre, SlideArray<uint8_t>{ML_, ML_});
-        be_.launch(kPre, SlideArray<uint32_t>{ORD_, ORD_});
-        be_.launch(kPre, SlideArray<uint8_t>{LENMIN_, LENMIN_});
+    // When the fast mode encodes a block in units (encode_block_units) it slides by one unit at a time: after the
+    // block's last unit the slides add up to the reference's 2^24.
+    void slide(bool slide_window = true) { slide_by(last_n_, 0, slide_window); }
+    // slide by `sh` positions; `extra` bytes behind the encoded region (the block's later units) move along
+    void slide_by(uint32_t sh, uint32_t extra, bool slide_window = true) {
+        be_.launch(3, TailKeys{dwin(), kPre + sh, tailkey_});
+        if (slide_window) be_.d2d(dwin(), dwin() + sh, (size_t)kPre + extra);
+        for (uint32_t off = 0; off < kPre; off += sh) {
+            be_.launch(sh, SlideArray<uint8_t>{S_, off, sh, kPre});
+            be_.launch(sh, SlideArray<uint8_t>{ML_, off, sh, kPre});
+            be_.launch(sh, SlideArray<uint32_t>{ORD_, off, sh, kPre});
+            be_.launch(sh, SlideArray<uint8_t>{LENMIN_, off, sh, kPre});
+        }
         be_.sync();
+    }
+    // Encode the `take` new bytes at dwin()[kPre, kPre + take) -- one block of the stream loop (src/lib.rs:72-84).  The exact
+    // mode takes them as one block, like the reference.  The fast mode can cut the block into units (ORZ_FAST_UNIT; off by
+    // default, see unit_): the decoder accepts any chunk ends inside a block (it slides when the block is full,
+    // src/lib.rs:119-124), so each unit closes its last chunk early, and the symbol ranking of unit k runs beside the
+    // parse of unit k+1; a unit's parse sees the 16 MiB before it (the reference sees up to 16 MiB more).
+    void encode_block_units(uint32_t take, bool lead, std::vector<uint8_t>& out) {
+        const uint32_t unit = fast_ ? unit_ : kNewMax;
+        uint32_t done = 0;
+        while (done < take) {
+            uint32_t n = std::min(unit, take - done);
+            if (take - done - n < unit / 8) n = take - done;  // no crumbs: a short rest joins the unit before it
+            set_lead_block(lead && done == 0);
+            unit_base_ = done;
+            encode_block(n, out);
+            done += n;
+            if (done < take) slide_by(n, take - done);
+        }
+        unit_base_ = 0;
     }
 
     EncodeStats stats;
@@ -915,6 +945,12 @@ class StreamEncoder {
     static constexpr int kEvItems = 0, kEvRank = 2;  // event numbers (+ set index)
     TailSet ts_[2];
     int cur_set_ = 0;
+    uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)
+    uint32_t unit_base_ = 0;     // bytes of the current block encoded by earlier units (chunk headers carry decoder positions)
+    // fast mode: bytes per unit of a block (ORZ_FAST_UNIT; a multiple of 4096).  Measured on the 100 MB workload: 8 MiB units
+    // fill the pipeline 18 ms sooner but cost 28 ms of parse (the history is sorted once per unit, the round pipeline and
+    // the repair passes start once per unit): 353 vs 350 ms, 4 MiB units 377 ms -- so a unit is the whole block by default.
+    uint32_t unit_ = kNewMax;
     std::vector<int> pend_order_;  // sets whose output is still on the device, oldest first
     uint8_t* winbuf_;
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
@@ -949,8 +985,7 @@ void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n,
         if (src_on_device) be.d2d(enc.dwin() + kPre, src + off, take);
         else if (src_pinned) be.h2d_pinned(enc.dwin() + kPre, src + off, take);  // async: the block's first sync covers it
         else be.h2d(enc.dwin() + kPre, src + off, take);
-        enc.set_lead_block(off == 0 && n > kNewMax);
-        enc.encode_block(take, out);
+        enc.encode_block_units(take, off == 0 && n > enc.unit_bytes(), out);
         off += take;
         if (off < n) enc.slide();
     }

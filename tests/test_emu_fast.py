@@ -76,3 +76,19 @@ def test_plan_encoder_accepts_what_it_wrote(oracle):
             plan[i].type = 0 if it.symbol == 388 else 1
         ring.append(pos)
     assert oracle.encode_plan(data, (plan, len(tr))) == ref
+
+
+def test_units_of_a_block(emu, oracle, monkeypatch):
+    """the fast mode encodes a block in units that each close their last chunk early and slide the window by their own
+    size (orz_stream.h, encode_block_units): the oracle's decoder -- the reference's loop, which slides only when the block
+    is full -- must reproduce the input, and the size stays next to the single-unit encoding"""
+    import corpus
+
+    data = corpus.enwik_like(3_200_000)
+    whole, _ = emu.fast(data, cfg=LEVELS[1])
+    monkeypatch.setenv("ORZ_FAST_UNIT", str(1 << 20))
+    out, st = emu.fast(data, cfg=LEVELS[1])
+    assert st[0] == 3  # units encoded (the short rest joins the last one)
+    back, used = oracle.decode(out)
+    assert used == len(out) and back == data
+    assert abs(len(out) - len(whole)) <= 0.004 * len(whole)
