@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# an encoder drives three HIP streams; the runtime's default of 4 hardware queues makes streams share queues (the library
+# sets the same default when it is loaded first -- here torch initialises HIP before it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -165,6 +165,8 @@ def load():
         raise RuntimeError(
             "liborz_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH
         )
+    # (the library sets the same default when it is loaded; a host that initialised HIP earlier -- torch -- has to export it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart

@@ -19,6 +19,16 @@
 #include "orz_stream.h"
 
 namespace {
+// An encoder drives three HIP streams (parse; symbol ranking; Huffman + packing) and the members interface runs several
+// encoders side by side.  The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues
+// (4 by default): streams that share a queue run their kernels one after another, so another member's 50 ms
+// symbol-ranking launch stalls a parse behind it.  Measured on MI355X, 8 encoders, 64 MiB members, -l1: 4 queues
+// 344 MB/s, 8: 385, 16: 443, 32: 437.  The variable is read when the HIP runtime initialises, so it is set here, when
+// the library is loaded, unless the host process has chosen a value itself.
+struct HwQueueDefault {
+    HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queue_default;
+
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {

@@ -56,6 +56,7 @@ int usage() {
 }  // namespace
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);  // (before the HIP runtime starts: see orz_capi.hip)
     if (argc < 2) return usage();
     const std::string cmd = argv[1];
     if (cmd != "encode" && cmd != "decode") return usage();

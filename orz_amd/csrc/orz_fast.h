@@ -346,32 +346,58 @@ struct FastEval {
 #if !defined(__HIPCC__)
                 g_far_stats[1]++;
 #endif
-                far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
-#if !defined(__HIPCC__)
-                    g_far_stats[3]++;
-#endif
-                    const uint32_t l = far_lcp(a, p, a0, a1, sl);
-                    if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
-                        const uint32_t q = a.epos[sl];
-                        uint32_t ro_hi, ro_mid;
-                        if (q >= kPre) {
-                            const uint32_t sq = (q - kPre) / kSub;
-                            const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
-                            ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
-                            ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
-                        } else {
-                            ro_hi = op_hi - 1 - a.ORD[q];
-                            ro_mid = op_lo - 1 - a.ORD[q];
-                        }
-                        if (ro_hi > kRing - 1) { stop = true; return false; }
-                        if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
-                        if (seen < a.lazy1 && l > fm1) fm1 = l;
-                        if (seen < a.lazy2 && l > fm2) fm2 = l;
+                // item starts of the range, newest first, four at a time: the slots are collected from the bitmap first, their
+                // text records are fetched together (independent loads), then they are examined in order -- the walk was a
+                // chain of dependent loads, one member after the other, and FastEval lasts as long as its longest chain
+                constexpr uint32_t kBatch = 4;
+                uint32_t cur_top = top;
+                bool more = true;
+                while (more) {
+                    uint32_t sl[kBatch], nb = 0;
+                    far_walk(a, lo2, cur_top, [&](uint32_t s2) -> bool { sl[nb++] = s2; return nb < kBatch; });
+                    if (nb == 0) break;
+                    uint64_t x0[kBatch], x1[kBatch];
+#pragma unroll
+                    for (uint32_t k = 0; k < kBatch; k++) {
+                        const uint32_t s2 = k < nb ? sl[k] : sl[0];
+                        x0[k] = a.stext[2 * (size_t)s2] ^ a0;
+                        x1[k] = a.stext[2 * (size_t)s2 + 1] ^ a1;
                     }
-                    seen++;
-                    if (l == kMaxLen) { stop = true; return false; }
-                    return seen < a.depth;
-                });
+#pragma unroll
+                    for (uint32_t k = 0; k < kBatch; k++) {
+                        if (k >= nb || !more) break;
+#if !defined(__HIPCC__)
+                        g_far_stats[3]++;
+#endif
+                        const uint32_t s2 = sl[k];
+                        uint32_t l;
+                        if (x0[k]) l = (uint32_t)ctz64(x0[k]) >> 3;
+                        else if (x1[k]) l = 8 + ((uint32_t)ctz64(x1[k]) >> 3);
+                        else l = 16 + lcp240u(win + a.epos[s2] + 16, win + p + 16, kMaxLen - 16);
+                        if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
+                            const uint32_t q = a.epos[s2];
+                            uint32_t ro_hi, ro_mid;
+                            if (q >= kPre) {
+                                const uint32_t sq = (q - kPre) / kSub;
+                                const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
+                                ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
+                                ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
+                            } else {
+                                ro_hi = op_hi - 1 - a.ORD[q];
+                                ro_mid = op_lo - 1 - a.ORD[q];
+                            }
+                            if (ro_hi > kRing - 1) { stop = true; more = false; break; }
+                            if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
+                            if (seen < a.lazy1 && l > fm1) fm1 = l;
+                            if (seen < a.lazy2 && l > fm2) fm2 = l;
+                        }
+                        seen++;
+                        if (l == kMaxLen) { stop = true; more = false; break; }
+                        if (seen >= a.depth) { more = false; break; }
+                    }
+                    if (nb < kBatch) break;  // the range is exhausted
+                    cur_top = sl[nb - 1];
+                }
                 a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
                 a.farsrc[i] = fsrc;
             }

@@ -536,6 +536,123 @@ struct ChunkHeader {
     }
 };
 
+// The same header, one wavefront per chunk (src/coder.rs:27-67, src/lz.rs:253-270, 311-318).  A table is written by
+// all lanes: lane L owns the symbols [7 L, 7 L + 7) -- it needs the last coded symbol before its range (a running
+// maximum over the lanes) and the bits written before its range (a running sum), both scanned through LDS; a varint takes
+// two bits per payload bit.
+ORZ_HD uint32_t varint_bits(uint32_t v) {
+    uint32_t g = 1;
+    while (v > 1) { v >>= 1; g++; }
+    return 2 * g;
+}
+struct ChunkHeaderWave {
+    const uint8_t* hl;
+    uint32_t nchunks, nitems, len;
+    uint32_t pos_base;
+    const uint32_t* ipos;
+    const uint16_t* order;
+    const uint32_t* ncounted;
+    int stream_start;
+    uint32_t* out;
+    const uint64_t* outoff;
+    uint32_t* hdrbits;
+    static constexpr uint32_t kPer = 7;  // symbols per lane: 64 * 7 >= 389
+    static size_t lds_bytes() { return 64 * 4 * 2 + 16; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* sBits = (uint32_t*)w.lds();  // per lane: bits of its symbols -> bits before its range
+        uint32_t* sLast = sBits + 64;          // per lane: its last coded symbol + 1 (0 = none) -> the last one before its range
+        const uint32_t ch = w.block(), lane = w.lane();
+        if (ch >= nchunks) return;
+        uint32_t* o = out + outoff[ch];
+        uint64_t bp = 0;
+        if (ch == 0 && stream_start) {  // src/lz.rs:253-256
+            const uint32_t k = *ncounted;
+            if (lane == 0) put_varint(o, 0, k);
+            bp = varint_bits(k);
+            for (uint32_t i = lane; i < k; i += 64) put_bits(o, bp + 9ull * i, order[i], 9);
+            bp += 9ull * k;
+        }
+        const uint32_t i0 = ch << 20;
+        const uint32_t i1 = i0 + kChunkItems < nitems ? i0 + kChunkItems : nitems;
+        const uint32_t end_spos = (i1 < nitems ? ipos[i1] : len) + pos_base;  // src/lz.rs:268 (the position in the DECODER's window)
+        if (lane == 0) { const uint64_t b2 = put_varint(o, bp, end_spos); put_varint(o, b2, i1 - i0); }
+        bp += varint_bits(end_spos) + varint_bits(i1 - i0);
+        for (uint32_t tb = 0; tb < 3; tb++) {
+            const uint32_t n = tb < 2 ? kSyms : kLenSyms;
+            const uint8_t* lens = hl + (size_t)ch * kHwStride + (tb == 0 ? 0 : tb == 1 ? kSyms : 2 * kSyms);
+            // longest code of the table (every lane reads its seven lengths)
+            uint8_t mine[kPer];
+            uint32_t mx = 0, lastc = 0;
+            for (uint32_t k = 0; k < kPer; k++) {
+                const uint32_t sy = lane * kPer + k;
+                mine[k] = sy < n ? lens[sy] : 0;
+                if (mine[k] > mx) mx = mine[k];
+                if (mine[k]) lastc = sy + 1;
+            }
+            sBits[lane] = mx;
+            sLast[lane] = lastc;
+            w.sync();
+            uint32_t maxlen = 0;
+            for (uint32_t k = 0; k < 64; k++) if (sBits[k] > maxlen) maxlen = sBits[k];
+            uint32_t prev = 0;  // last coded symbol before this lane's range, + 1
+            for (uint32_t k = 0; k < lane; k++) if (sLast[k]) prev = sLast[k];
+            w.sync();
+            // bits of this lane's symbols
+            uint32_t nb = 0, pl = prev;
+            for (uint32_t k = 0; k < kPer; k++)
+                if (mine[k]) {
+                    const uint32_t sy = lane * kPer + k;
+                    nb += varint_bits(pl ? sy + 1 - pl : sy + 1) + varint_bits(maxlen - mine[k]);
+                    pl = sy + 1;
+                }
+            sBits[lane] = nb;
+            w.sync();
+            uint32_t before = 0, total = 0;
+            for (uint32_t k = 0; k < 64; k++) { if (k < lane) before += sBits[k]; total += sBits[k]; }
+            w.sync();
+            if (lane == 0) put_varint(o, bp, maxlen);
+            const uint64_t tbase = bp + varint_bits(maxlen);
+            uint64_t at = tbase + before;
+            pl = prev;
+            for (uint32_t k = 0; k < kPer; k++)
+                if (mine[k]) {
+                    const uint32_t sy = lane * kPer + k;
+                    at = put_varint(o, at, pl ? sy + 1 - pl : sy + 1);
+                    at = put_varint(o, at, maxlen - mine[k]);
+                    pl = sy + 1;
+                }
+            if (lane == 0) put_varint(o, tbase + total, 0);
+            bp = tbase + total + 2;
+        }
+        if (lane == 0) hdrbits[ch] = (uint32_t)bp;
+    }
+};
+
+// The census of the stream's first chunk (src/lz.rs:240-246), one wavefront per 4096 items: bins privatised in LDS
+struct CensusCountWave {
+    const uint16_t* isym;
+    uint32_t n;
+    uint32_t* counts;
+    static size_t lds_bytes() { return (kSyms + 3) * 4; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* bins = (uint32_t*)w.lds();
+        const uint32_t lane = w.lane();
+        for (uint32_t b = lane; b < kSyms; b += 64) bins[b] = 0;
+        w.sync();
+        const size_t base = (size_t)w.block() * 4096;
+        for (uint32_t k = 0; k < 64; k++) {
+            const size_t tid = base + (size_t)k * 64 + lane;
+            if (tid >= n) break;
+            ORZ_ATOMIC_ADD(&bins[isym[tid]], 1u);
+        }
+        w.sync();
+        for (uint32_t b = lane; b < kSyms; b += 64)
+            if (bins[b]) ORZ_ATOMIC_ADD(&counts[b], bins[b]);
+    }
+};
+
 struct Pack {  // src/lz.rs:320-342
     const uint16_t* irank;
     const uint8_t* ial;

@@ -749,7 +749,8 @@ class StreamEncoder {
         if (nchunks > kMaxChunks) throw std::runtime_error("too many chunks in a block");
         if (stream_start_) {  // src/lz.rs:238-265
             be_.memset(counts_, 0, (kSyms + 3) * 4);
-            be_.launch(std::min(nitems, kChunkItems), CensusCount{t.isym, std::min(nitems, kChunkItems), counts_});
+            be_.launch_waves(((size_t)std::min(nitems, kChunkItems) + 4095) / 4096, CensusCountWave{t.isym, std::min(nitems, kChunkItems), counts_},
+                             CensusCountWave::lds_bytes());
             be_.launch(kSyms, CensusOrder{counts_, order_, ncounted_});
             be_.launch((size_t)512 * kSyms, CensusFill{order_, srstate_});
         }
@@ -784,8 +785,8 @@ class StreamEncoder {
         be_.launch(nitems, ItemBits{t.irank, t.ial, t.ienc, t.irob, t.hl, nitems, t.blen});
         be_.exclusive_scan_u32(t.blen, t.bscan, nitems);
         be_.memset(t.out, 0, (size_t)nchunks * kChunkCapWords * 4);
-        be_.launch(nchunks, ChunkHeader{t.hl, nchunks, nitems, len, unit_base_, t.ipos, order_, ncounted_, stream_start_ ? 1 : 0, t.out,
-                                        outoff_, t.hdrbits});
+        be_.launch_waves(nchunks, ChunkHeaderWave{t.hl, nchunks, nitems, len, unit_base_, t.ipos, order_, ncounted_, stream_start_ ? 1 : 0,
+                                                  t.out, outoff_, t.hdrbits}, ChunkHeaderWave::lds_bytes());
         be_.launch(nitems, Pack{t.irank, t.ial, t.ienc, t.irob, t.hl, t.hc, t.bscan, t.hdrbits, outoff_, nitems, t.out});
         be_.launch(nchunks, ChunkTotals{t.bscan, t.blen, t.hdrbits, nitems, nchunks, t.tot});
         be_.select(0);

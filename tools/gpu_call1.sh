@@ -9,7 +9,7 @@ cat $OUT/c1_pytest.log
 grep -q passed $OUT/c1_pytest.log && ! grep -q failed $OUT/c1_pytest.log || exit 1
 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>$OUT/c1_bench.err | tail -1 > $OUT/c1_bench.json
 cat $OUT/c1_bench.json
-for u in 4194304 16777216; do echo unit $u; ORZ_FAST_UNIT=$u timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; b=json.loads(sys.stdin.read()); print(b['value'], b['ms_per_step'], b['compressed_bytes'], b['stage_seconds_per_step'])"; done 2>&1 | tee $OUT/c1_units.log
+timeout 120 python tools/dev/members_scale.py 8 2>&1 | tail -1 | tee $OUT/c1_members.log
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/c1_trace -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/c1_trace_bench.json 2>$OUT/c1_trace.err
 DB=$(find $OUT/c1_trace -name '*_results.db' | head -1)
