@@ -29,6 +29,34 @@ def cfg_for_level(level):
     return cfg
 
 
+class OrzBuffer:
+    """A stream the library returned (malloc'ed by orz_stream_encode), held without copying; freed with orz_free."""
+
+    def __init__(self, lib, ptr, n):
+        self._lib, self._ptr, self._n = lib, ptr, int(n)
+
+    def __len__(self):
+        return self._n
+
+    def __bytes__(self):
+        return ctypes.string_at(self._ptr, self._n)
+
+    def view(self):
+        """memoryview over the buffer (valid while this object lives)"""
+        return memoryview((ctypes.c_uint8 * self._n).from_address(ctypes.addressof(self._ptr.contents))).cast("B") if self._n else memoryview(b"")
+
+    def close(self):
+        if self._ptr is not None:
+            self._lib.orz_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class StreamEncoder:
     """One orz stream encoder bound to one GPU; reusable across inputs."""
 
@@ -74,7 +102,7 @@ class StreamEncoder:
     def set_tuning(self, seg_bytes=0, window_segs=0):
         _check(self._lib.orz_stream_set_tuning(self._h, seg_bytes, window_segs), "orz_stream_set_tuning")
 
-    def _encode(self, ptr, n, on_device, want_stats):
+    def _encode(self, ptr, n, on_device, want_stats, raw=False):
         dst = ctypes.POINTER(ctypes.c_uint8)()
         dlen = ctypes.c_size_t()
         st = EncodeStats()
@@ -83,6 +111,8 @@ class StreamEncoder:
             ctypes.byref(st) if want_stats else None,
         )
         _check(rc, "orz_stream_encode")
+        if raw:  # the library's buffer itself, no copy (released with the object)
+            return OrzBuffer(self._lib, dst, dlen.value), (st.as_dict() if want_stats else None)
         try:
             out = ctypes.string_at(dst, dlen.value)
         finally:
@@ -96,9 +126,10 @@ class StreamEncoder:
         out, st = self._encode(ctypes.cast(buf, ctypes.c_void_p), len(data), False, stats)
         return (out, st) if stats else out
 
-    def encode_device(self, dev_ptr, nbytes, stats=False):
-        """Encode `nbytes` already resident in this GPU's HBM at address `dev_ptr`."""
-        out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats)
+    def encode_device(self, dev_ptr, nbytes, stats=False, raw=False):
+        """Encode `nbytes` already resident in this GPU's HBM at address `dev_ptr`.  raw=True returns the library's own
+        host buffer (an OrzBuffer: len(), bytes(), buffer protocol) instead of a bytes copy of it."""
+        out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats, raw)
         return (out, st) if stats else out
 
     def set_item_trace(self, on=True):

@@ -198,7 +198,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
                       orz_encode_stats* stats) {
     if (!s || !dst || !dst_len || (!src && n)) return fail(ORZ_EINVAL, "null argument");
     try {
-        std::vector<uint8_t> out;
+        orz::ByteBuf out;
         out.reserve(n / 3 + 4096);
         orz::HipBackend& be = *s->be;
         be.set_timing(stats != nullptr);
@@ -237,12 +237,11 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
             stats->total_ms = total;
         }
-        uint8_t* p = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
-        if (!p) return fail(ORZ_ENOMEM, "malloc failed");
-        std::memcpy(p, out.data(), out.size());
-        *dst = p;
         *dst_len = out.size();
+        *dst = out.release();
         return ORZ_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(ORZ_ENOMEM, "out of host memory");
     } catch (const std::exception& e) {
         return fail(ORZ_ENODEV, e.what());
     }

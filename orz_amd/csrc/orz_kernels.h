@@ -559,7 +559,7 @@ struct ChunkHeaderWave {
     static constexpr uint32_t kPer = 7;  // symbols per lane: 64 * 7 >= 389
     static size_t lds_bytes() { return 64 * 4 * 2 + 16; }
     template <class W>
-    ORZ_D void operator()(W& w) const {
+    ORZ_HD void operator()(W& w) const {
         uint32_t* sBits = (uint32_t*)w.lds();  // per lane: bits of its symbols -> bits before its range
         uint32_t* sLast = sBits + 64;          // per lane: its last coded symbol + 1 (0 = none) -> the last one before its range
         const uint32_t ch = w.block(), lane = w.lane();
@@ -636,7 +636,7 @@ struct CensusCountWave {
     uint32_t* counts;
     static size_t lds_bytes() { return (kSyms + 3) * 4; }
     template <class W>
-    ORZ_D void operator()(W& w) const {
+    ORZ_HD void operator()(W& w) const {
         uint32_t* bins = (uint32_t*)w.lds();
         const uint32_t lane = w.lane();
         for (uint32_t b = lane; b < kSyms; b += 64) bins[b] = 0;

@@ -207,6 +207,47 @@ struct ChunkTotals {  // total payload bits of each chunk = header + items
     }
 };
 
+// Output bytes of an encode call: grows like a vector but does not zero what it is about to receive from the device, and
+// hands its malloc'ed buffer to the caller (the C ABI returns it; orz_free releases it) instead of copying it.
+class ByteBuf {
+   public:
+    ByteBuf() = default;
+    ~ByteBuf() { std::free(p_); }
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    void reserve(size_t c) {
+        if (c <= cap_) return;
+        void* q = std::realloc(p_, c);
+        if (!q) throw std::bad_alloc();
+        p_ = (uint8_t*)q;
+        cap_ = c;
+    }
+    void resize(size_t m) {
+        if (m > cap_) reserve(std::max(m, cap_ * 2));
+        n_ = m;
+    }
+    void push_back(uint8_t b) {
+        if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 4096);
+        p_[n_++] = b;
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    void clear() { n_ = 0; }
+    uint8_t* release() {  // (never null: an empty result still owns one byte)
+        if (!p_) reserve(1);
+        uint8_t* q = p_;
+        p_ = nullptr;
+        n_ = cap_ = 0;
+        return q;
+    }
+
+   private:
+    uint8_t* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 template <class BE>
 class StreamEncoder {
    public:
@@ -388,7 +429,8 @@ class StreamEncoder {
     // each chunk's end position (the value LZEncoder::encode returns, src/lz.rs:268,346).
     // The last stage of a block (symrank -> Huffman -> bit pack) runs on the backend's second stream and
     // overlaps the next block's prep + parse; its output is appended by the next call, or by finish().
-    void encode_block(uint32_t n, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends = nullptr) {
+    template <class OutT>
+    void encode_block(uint32_t n, OutT& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
         last_n_ = n;
         double t0 = be_.now();
@@ -723,7 +765,8 @@ class StreamEncoder {
     // the serial chain of a stream: nothing else sits on it); histograms, Huffman and bit packing of block k run on stream 2
     // beside the ranking of block k+1.  Blocks take the two buffer sets alternately: block k+2 reuses the set of block k
     // after its output was collected.
-    void post_stage(uint32_t n, uint32_t len, std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends, double t2) {
+    template <class OutT>
+    void post_stage(uint32_t n, uint32_t len, OutT& out, std::vector<size_t>* chunk_ends, double t2) {
         const uint8_t* win = dwin();
         const int b = cur_set_;
         cur_set_ ^= 1;
@@ -803,11 +846,13 @@ class StreamEncoder {
     }
 
     // Append the output of every block whose tail stage is in flight, oldest first.
-    void collect(std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends) {
+    template <class OutT>
+    void collect(OutT& out, std::vector<size_t>* chunk_ends) {
         while (!pend_order_.empty()) collect_one(out, pend_order_.size() == 1 ? chunk_ends : nullptr);
     }
     // ... of the oldest one
-    void collect_one(std::vector<uint8_t>& out, std::vector<size_t>* chunk_ends) {
+    template <class OutT>
+    void collect_one(OutT& out, std::vector<size_t>* chunk_ends) {
         if (pend_order_.empty()) return;
         TailSet& t = ts_[pend_order_.front()];
         pend_order_.erase(pend_order_.begin());
@@ -861,7 +906,8 @@ class StreamEncoder {
         }
         be_.select(0);
     }
-    void finish(std::vector<uint8_t>& out) { collect(out, nullptr); }
+    template <class OutT>
+    void finish(OutT& out) { collect(out, nullptr); }
 
     // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
     // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.
@@ -886,7 +932,8 @@ class StreamEncoder {
     // default, see unit_): the decoder accepts any chunk ends inside a block (it slides when the block is full,
     // src/lib.rs:119-124), so each unit closes its last chunk early, and the symbol ranking of unit k runs beside the
     // parse of unit k+1; a unit's parse sees the 16 MiB before it (the reference sees up to 16 MiB more).
-    void encode_block_units(uint32_t take, bool lead, std::vector<uint8_t>& out) {
+    template <class OutT>
+    void encode_block_units(uint32_t take, bool lead, OutT& out) {
         const uint32_t unit = fast_ ? unit_ : kNewMax;
         uint32_t done = 0;
         while (done < take) {
@@ -976,9 +1023,9 @@ class StreamEncoder {
 
 // orz::encode (src/lib.rs:58-92) over a memory buffer that the backend can read with h2d():
 // fills the window block by block, frames chunks, slides, and appends the EOF chunk.
-template <class BE>
+template <class BE, class OutT>
 void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n, bool src_on_device,
-                   std::vector<uint8_t>& out, bool src_pinned = false) {
+                   OutT& out, bool src_pinned = false) {
     enc.reset();
     size_t off = 0;
     while (off < n) {
