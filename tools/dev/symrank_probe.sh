@@ -1,7 +1,7 @@
 #!/bin/bash
-# dev: symrank kernel variants on the recorded block (build/symrank_bench_*), real stream and an all-ranks<64 synthetic one
-for b in build/symrank_bench_old build/symrank_bench_trips*; do
+# dev: every symrank kernel variant built as build/symrank_bench_* (tools/dev/symrank_bench.hip against a copy of
+# backend_hip.h) on the recorded block (tools/dev/make_symrank_case.py); optional: "cyc N" = items cycle over N symbols
+for b in build/symrank_bench_*; do
   [ -x $b ] || continue
-  echo "== $b"; timeout 25 $b build/symrank_case.bin | tail -1
-  echo "   cyc60:"; timeout 25 $b build/symrank_case.bin cyc 60 | tail -1
+  echo "== $b"; timeout 25 $b build/symrank_case.bin "$@" | tail -1
 done
