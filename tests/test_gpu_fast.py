@@ -217,3 +217,28 @@ def test_object_level_encoder_and_callbacks_in_fast_mode(oracle):
     src, dst = io.BytesIO(small), io.BytesIO()
     orz_amd.encode(src, dst, orz_amd.cfg_for_level(1))
     assert oracle.decode(dst.getvalue())[0] == small
+
+
+def test_units_of_a_block_decode_with_the_reference_loop(oracle, monkeypatch):
+    """a block encoded in units (ORZ_FAST_UNIT: each unit closes its last chunk early, the window slides by the unit's
+    size) is still the reference's format: the oracle's decoder, which slides only when its block is full
+    (src/lib.rs:119-124), reproduces the input, and the size stays next to the whole-block encoding"""
+    import corpus
+    import orz_amd
+
+    data = corpus.enwik_like(100_000_000)[: (1 << 24) + 3_500_000]
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        whole = enc.encode(data)
+    finally:
+        enc.close()
+    monkeypatch.setenv("ORZ_FAST_UNIT", str(4 << 20))
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        assert enc.config()["unit_bytes"] == 4 << 20
+        out = enc.encode(data)
+    finally:
+        enc.close()
+    back, used = oracle.decode(out)
+    assert used == len(out) and back == data
+    assert abs(len(out) - len(whole)) <= 0.002 * len(whole)
