@@ -648,7 +648,8 @@ class StreamEncoder {
             if (n >= unit_) T = ftile_;  // (a full unit is not a short input)
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it takes tiles twice the size -- half the steps, ~+0.1 % on that block's output.
-            if (lead_block_ && T == ftile_) T = 2 * ftile_;
+            static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 2;
+            if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = lead_mul * ftile_;
         }
         for (;;) {
             a.tile = T;
@@ -706,7 +707,7 @@ class StreamEncoder {
             uint32_t* cvals = (uint32_t*)entB_;
             uint32_t* fipos = cvals + kWLen;
             bool done = false;
-            static const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (experiments: every pass walks for every match)
+            const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (tests, experiments: every pass walks for every match)
             static const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 256;  // (0 = no limit)
             uint64_t total_repairs = 0;
             uint32_t nmem_last = 0;

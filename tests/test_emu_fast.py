@@ -92,3 +92,19 @@ def test_units_of_a_block(emu, oracle, monkeypatch):
     back, used = oracle.decode(out)
     assert used == len(out) and back == data
     assert abs(len(out) - len(whole)) <= 0.004 * len(whole)
+
+
+def test_incremental_repair_passes_change_nothing(emu, oracle, monkeypatch):
+    """after the first repair pass only the matches of runs that gained an item start are walked again (FastSource,
+    orz_fast.h): the stream must be the very same as with every pass walking for every match -- on data and settings that
+    need many repairs (one round, coarse tiles)"""
+    import corpus
+
+    cases = [(corpus.enwik_like(1_500_000), dict(tile=262144, rounds=1)), (_data.mixed(400_000, seed=7), dict(tile=131072, rounds=1))]
+    for data, kw in cases:
+        out, st = emu.fast(data, cfg=LEVELS[1], **kw)
+        assert st[2] > 100  # repairs made
+        monkeypatch.setenv("ORZ_FAST_FULLPASS", "1")
+        full, st2 = emu.fast(data, cfg=LEVELS[1], **kw)
+        monkeypatch.delenv("ORZ_FAST_FULLPASS")
+        assert out == full and st[2] == st2[2]
