@@ -7,10 +7,12 @@
 //   EmuBackend  (tests/emu)      -- host emulation of the same kernel bodies, tests only
 //
 // Per block:  prep   (candidate lists: radix sort by (ctx, hash) / by hash2, slot state)
-//             parse  (speculative sweeps of ParseWave + RankScan + RankApply until the front
-//                     reaches the end of the block; the sweep loop is enqueued in batches, the
-//                     front lives on the device)
-//             post   (items -> len_min -> symbols -> symrank -> histograms -> Huffman -> bit pack)
+//             parse  fast mode (default): pipelined Gauss-Seidel rounds over tiles, replayed as a hipGraph, then
+//                     source assignment + repairs with the item boundaries frozen (orz_fast.h, fast_parse below);
+//                     exact mode: speculative sweeps of ParseWave + rank kernel until the front reaches the end
+//                     of the block (orz_parse.h)
+//             post   (items -> len_min -> symbols on the main stream; symbol ranking on stream 1, launch after
+//                     launch; histograms -> Huffman -> bit pack on stream 2 -- post_stage below)
 #pragma once
 #include <algorithm>
 #include <cstdio>
@@ -427,8 +429,8 @@ class StreamEncoder {
     // Encode the block whose n new bytes sit at dwin()[kPre, kPre+n).  Appends
     // { LEB128(t) chunk[t] }* (src/lib.rs:76-82, src/ioutil.rs:79-88) to `out`; optionally reports
     // each chunk's end position (the value LZEncoder::encode returns, src/lz.rs:268,346).
-    // The last stage of a block (symrank -> Huffman -> bit pack) runs on the backend's second stream and
-    // overlaps the next block's prep + parse; its output is appended by the next call, or by finish().
+    // The last stages of a block (symbol ranking; Huffman + bit pack) run on the backend's streams 1 and 2 and overlap
+    // the next blocks' prep + parse; a block's output is appended two calls later, or by finish().
     template <class OutT>
     void encode_block(uint32_t n, OutT& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
