@@ -817,6 +817,7 @@ class StreamEncoder {
         be_.launch(513, SymRunStart{t.skey, nitems, t.rstart});
         be_.record(kEvItems + b);  // items of this block are ready
         // ---- symbol ranking: 512 independent serial chains, launch after launch on stream 1
+        MainStreamGuard back_to_main{be_};
         be_.select(1);
         be_.wait(kEvItems + b);
         be_.symrank(srstate_, t.gsym, t.grank, t.rstart);
@@ -861,6 +862,7 @@ class StreamEncoder {
         pend_order_.erase(pend_order_.begin());
         t.pending = false;
         const uint32_t nitems = t.nitems, nchunks = t.nchunks, len = t.len;
+        MainStreamGuard back_to_main{be_};
         be_.select(2);
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
@@ -994,6 +996,10 @@ class StreamEncoder {
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
     static constexpr int kEvItems = 0, kEvRank = 2;  // event numbers (+ set index)
+    struct MainStreamGuard {  // whatever happens while a side stream is selected, the backend goes back to the main one
+        BE& be;
+        ~MainStreamGuard() { be.select(0); }
+    };
     TailSet ts_[2];
     int cur_set_ = 0;
     uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)
