@@ -126,8 +126,8 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        # (single rank: the stream stays in the buffer the library returned; the gather below wants bytes)
-        out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True, raw=not distributed)
+        # (the stream stays in the buffer the library returned; the gather below sends it from there)
+        out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True, raw=True)
         if distributed:  # the job's only exchange: gather the finished bitstreams on rank 0
             got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None, to_host=False)
             if rank == 0:  # (the members of the other ranks stay in rank 0's HBM: gathered, not copied out again)

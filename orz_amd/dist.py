@@ -35,10 +35,17 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
         sizes[i] = len(local[m])
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    blob = b"".join(local[m] for m in mine)
+    # one payload held in the library's own buffer (api.OrzBuffer: bench.py's case, one member per rank) is sent from
+    # where it lies; several members, or plain bytes, are joined first
+    if len(mine) == 1 and hasattr(local[mine[0]], "view"):
+        blob = local[mine[0]]
+        flat = torch.frombuffer(blob.view(), dtype=torch.uint8) if len(blob) else None
+    else:
+        blob = b"".join(bytes(local[m]) for m in mine)
+        flat = torch.frombuffer(bytearray(blob), dtype=torch.uint8) if blob else None
     if rank != 0:
-        if blob:
-            dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst=0)
+        if flat is not None:
+            dist.send(flat.to(dev), dst=0)
         return None
     out = [None] * n_members
     for r in range(world):
@@ -52,7 +59,11 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
         else:
             raw = b""
         at = 0
-        for i, m in enumerate(members_of_rank(n_members, r, world)):
+        ms = members_of_rank(n_members, r, world)
+        if len(ms) == 1 and hasattr(raw, "view"):  # a single payload in a buffer object (rank 0's own, or a received tensor): as it is
+            out[ms[0]] = raw
+            continue
+        for i, m in enumerate(ms):
             ln = int(all_sizes[r][i])
             out[m] = raw[at:at + ln]
             at += ln

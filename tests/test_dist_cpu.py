@@ -45,6 +45,52 @@ def test_member_gather_world2():
     assert res[-1] == sum(1 + (m * 7) % 250 for m in range(n_members))
 
 
+def _library_buffer(payload):
+    """an api.OrzBuffer like the one orz_stream_encode's output arrives in: malloc'ed memory, released by orz_free"""
+    import ctypes
+
+    from orz_amd import _native, api
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    p = libc.malloc(len(payload))
+    ctypes.memmove(p, payload, len(payload))
+    return api.OrzBuffer(_native.load(), ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), len(payload))
+
+
+def _worker_held(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from orz_amd import dist as od
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        payload = _library_buffer(bytes([3 + rank]) * (1000 + 17 * rank))
+        got = od.gather_members({rank: payload}, world, rank, world, to_host=False)
+        if rank == 0:
+            q.put([bytes(g) if not hasattr(g, "numpy") else g.numpy().tobytes() for g in got])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_of_library_held_buffers_world2():
+    """bench.py's flow: one member per rank, each held in the buffer the library returned (no bytes copy)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_held, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == [bytes([3]) * 1000, bytes([4]) * 1017]
+
+
 def _worker_real(rank, world, port, n_members, q):
     """every rank encodes ITS members with the oracle (standing in for its GPU), then the real gather"""
     sys.path.insert(0, ROOT)
