@@ -108,3 +108,16 @@ def test_incremental_repair_passes_change_nothing(emu, oracle, monkeypatch):
         full, st2 = emu.fast(data, cfg=LEVELS[1], **kw)
         monkeypatch.delenv("ORZ_FAST_FULLPASS")
         assert out == full and st[2] == st2[2]
+
+
+def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle):
+    """PathTileDown stages the chunk maps of the active range in LDS when they fit (64 KiB); eight rounds of 256 KiB
+    tiles do not: the same walks through global memory must give a valid stream of about the same size"""
+    import corpus
+
+    data = corpus.enwik_like(3_000_000)
+    big, _ = emu.fast(data, cfg=LEVELS[1], tile=262144, rounds=8)
+    ref, _ = emu.fast(data, cfg=LEVELS[1])
+    back, used = oracle.decode(big)
+    assert used == len(big) and back == data
+    assert abs(len(big) - len(ref)) <= 0.003 * len(ref)
