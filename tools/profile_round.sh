@@ -31,6 +31,8 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace_bench.json 2>$OUT/${TAG}_trace.err
 DB=$(find $OUT/${TAG}_trace -name '*_results.db' | head -1)
 [ -n "$DB" ] && python $REPO/tools/rocpd_summary.py $DB > $OUT/${TAG}_bench_100MB_l1_kernel_stats.csv
+# where the wall time goes: lead before the first ranking launch, gaps between the launches, time after the last one
+[ -n "$DB" ] && python $REPO/tools/rocpd_timeline.py $DB > $OUT/${TAG}_bench_timeline.jsonl
 # keep the merged output small: the databases stay on the box
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 ls -la $OUT | tail -12
