@@ -65,7 +65,39 @@ def cpu_baseline(data, level):
         "kind": "port",
         "sample": "full workload (%d bytes), -l%d, min of up to 3 passes, compressed %d bytes" % (len(data), level, out_len),
         "host_cores_available": os.cpu_count(),
+        "compressed_bytes": out_len,
     }
+
+
+def oracle_check(data, stream):
+    """outside the timed region: the stream the timed passes produced goes through the ORACLE's decoder"""
+    import _oracle
+
+    _oracle.lib()
+    t0 = time.time()
+    try:
+        back, used = _oracle.decode(stream)
+        ok = used == len(stream) and back == data
+    except Exception:
+        ok = False
+    return ok, round(time.time() - t0, 2)
+
+
+def newest_pmc_profile():
+    """HBM bytes per launch from the builder's PMC passes (tools/profile_round.sh; FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 runs): the newest profiles/rNN_pmc_hbm_traffic_16MiB_l1.json"""
+    d = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(d) if n.endswith("_pmc_hbm_traffic_16MiB_l1.json"))
+    except OSError:
+        return None, {}
+    for name in reversed(names):
+        try:
+            with open(os.path.join(d, name)) as f:
+                return "profiles/" + name, json.load(f).get("by_name", {})
+        except Exception:
+            continue
+    return None, {}
 
 
 def main():
@@ -129,14 +161,18 @@ def main():
         # (the stream stays in the buffer the library returned; the gather below sends it from there)
         out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True, raw=True)
         if distributed:  # the job's only exchange: gather the finished bitstreams on rank 0
+            tg = time.time()
             got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None, to_host=False)
             if rank == 0:  # (the members of the other ranks stay in rank 0's HBM: gathered, not copied out again)
                 assert all(g is not None and len(g) > 0 for g in got)
+            gather_s[0] += time.time() - tg
         return out, st
 
+    gather_s = [0.0]
     for _ in range(args.warmup):
         step()
     barrier()
+    gather_s[0] = 0.0
     t0 = time.time()
     agg = {"sweeps": 0, "seg_evals": 0, "items": 0, "t_prep_s": 0.0, "t_parse_s": 0.0, "t_post_s": 0.0}
     kt = [[0.0, 0] for _ in range(4)]
@@ -145,8 +181,10 @@ def main():
         out, st = step()
         for k in agg:
             agg[k] += st[k]
+    dt_own = time.time() - t0  # this rank's own clock up to its last stream (before the closing barrier)
     barrier()
     dt = time.time() - t0
+    gather_ms = gather_s[0] / max(1, args.steps) * 1e3
     # roofline leg, outside the timed region: one more pass in profile mode (HIP-event brackets around the kernels of
     # the round loop, which the timed passes replay as a hipGraph), scaled to `steps` passes below
     enc.set_profile(True)
@@ -159,19 +197,23 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank figures for reading the scaling line: each rank's own MB/s and its share of the gather
+        mine = torch.tensor([len(data) * args.steps / dt_own / 1e6, gather_ms], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(x[0]), 1), round(float(x[1]), 2)] for x in allr]
+    else:
+        per_rank = [[round(len(data) * args.steps / dt_own / 1e6, 1), 0.0]]
 
     if rank == 0:
         total_bytes = len(data) * world * args.steps
         value = total_bytes / dt / 1e6
         names = ["orz_wave_kernel<ParseWave>" if args.mode == "exact" else "orz_thread_kernel<FastEval>", "orz_symrank_kernel",
                  "orz_wave_kernel<FastRowsWave>", "orz_wave_kernel<PathUpWave>"]
-        # HBM bytes per launch from this round's PMC passes (tools/profile_round.sh), only if it is about the same kernel
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_16MiB_l1.json")) as f:
-                pmc = json.load(f).get("by_name", {})
-        except Exception:
-            pmc = {}
+        # HBM bytes per launch from the builder's PMC passes (NOT this run: rocprofv3 counters need their own passes), only if
+        # the file names the same kernel; labelled as such in `traffic_source`
+        pmc_file, pmc = newest_pmc_profile()
 
         def roof(i):
             ms, n = kt[i]
@@ -180,8 +222,14 @@ def main():
             avg_s = ms / 1e3 / n
             bpl = ALGO_BYTES_PER_INPUT_BYTE * len(data) * args.steps / n
             ach = bpl / avg_s / 1e9
+            tr = pmc.get(names[i])
             return {"bound": "hbm", "kernel": names[i], "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 8), "traffic": pmc.get(names[i]), "launches_per_step": n // args.steps,
+                    "frac": round(ach / HBM_PEAK_GBS, 8), "traffic": tr,
+                    "traffic_source": ("from_profile: " + pmc_file) if tr is not None else None,
+                    # measured HBM rate of this kernel: counter bytes per launch / average launch duration of THIS run
+                    "hbm_gbs": round(tr / avg_s / 1e9, 3) if tr is not None else None,
+                    "hbm_frac_of_peak": round(tr / avg_s / 1e9 / HBM_PEAK_GBS, 6) if tr is not None else None,
+                    "launches_per_step": n // args.steps,
                     "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": round(bpl, 1),
                     "device_ms_per_step": round(ms / args.steps, 2)}
 
@@ -218,14 +266,31 @@ def main():
             "repairs_per_step": agg["seg_evals"] // args.steps if cfg["mode"] == 1 else None,
             "roofline": roofs[0] if roofs else None,
             "roofline_others": roofs[1:],
+            # the whole pipeline against the same roofline: algorithmic bytes of a pass / wall time of a pass
+            "pipeline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_INPUT_BYTE * len(data) * world / (dt / args.steps) / 1e9, 4),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ALGO_BYTES_PER_INPUT_BYTE * len(data) * world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 8),
+                         "algorithmic_bytes_per_step": int(ALGO_BYTES_PER_INPUT_BYTE * len(data) * world)},
+            "world_size": dist.get_world_size() if distributed else 1,
+            "backend": (backend if distributed else None),
+            "per_rank_MBps": [r[0] for r in per_rank],
+            "gather_ms_per_step": [r[1] for r in per_rank],
             "stage_seconds_per_step": {
                 "prep": round(agg["t_prep_s"] / args.steps, 4),
                 "parse": round(agg["t_parse_s"] / args.steps, 4),
                 "post": round(agg["t_post_s"] / args.steps, 4),
             },
         }
+        # parity of what was timed, outside the timed region: the last timed stream through the oracle's decoder, and its
+        # size against the oracle's encoder (the cpu_baseline leg encodes the same bytes)
+        ok, dec_s = oracle_check(data, bytes(out))
+        res["roundtrip_ok"] = bool(ok)
+        res["roundtrip_checker"] = "oracle decoder (oracle/orz_oracle.c), %.2f s" % dec_s
+        res["size_delta_pct"] = None
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(base, LEVEL)
+            ref = res["cpu_baseline"]["compressed_bytes"]
+            res["size_delta_pct"] = round(100.0 * (len(out) - ref) / ref, 4)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

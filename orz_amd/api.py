@@ -128,7 +128,8 @@ class StreamEncoder:
 
     def encode_device(self, dev_ptr, nbytes, stats=False, raw=False):
         """Encode `nbytes` already resident in this GPU's HBM at address `dev_ptr`.  raw=True returns the library's own
-        host buffer (an OrzBuffer: len(), bytes(), buffer protocol) instead of a bytes copy of it."""
+        host buffer (an OrzBuffer: len(), bytes(), .view() -> memoryview; it does not implement the buffer protocol itself)
+        instead of a bytes copy of it."""
         out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats, raw)
         return (out, st) if stats else out
 
@@ -231,7 +232,9 @@ class MemberEncoder:
 
     def encode(self, data, member_bytes=1 << 26):
         """member_bytes: 64 MiB by default -- a member starts with empty rings and a flat symbol order, and that cold start
-        costs about 1.5 % of the size at 16 MiB members, a quarter of that at 64 MiB"""
+        costs about 1.5 % of the size at 16 MiB members, a quarter of that at 64 MiB.  Members larger than one
+        block (16 MiB) decode with the reference decoder and with `decode_members` (host); the DEVICE decoder
+        (`decode_members_device`) takes members of at most one block and refuses larger ones with a clear error."""
         data = bytes(data)
         buf = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
         return self._run(ctypes.cast(buf, ctypes.c_void_p), len(data), False, member_bytes)
@@ -269,7 +272,9 @@ def decode_members(container):
 
 def decode_members_device(container, device=0, stats=False):
     """decode every member of a concatenation of orz streams ON THE GPU (one member per wavefront; members of at
-    most one block) -> (bytes, n_members[, stats dict]).  Same bytes as `decode_members`."""
+    most one block: 16,777,216 input bytes -- a MemberEncoder container written with the default 64 MiB members is refused
+    with "member larger than one block: use the host decoder") -> (bytes, n_members[, stats dict]).  Same bytes as
+    `decode_members`."""
     lib = _native.load()
     container = bytes(container)
     dst = ctypes.POINTER(ctypes.c_uint8)()

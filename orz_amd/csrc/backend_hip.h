@@ -587,11 +587,11 @@ class HipBackend {
     }
 
     template <class T>
-    T* alloc(size_t n) {
+    T* alloc(size_t n, bool zero = true) {
         void* p = nullptr;
         ORZ_HIP_CHECK(hipSetDevice(device_));
         ORZ_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
-        ORZ_HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), stream_));
+        if (zero) ORZ_HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), stream_));
         return (T*)p;
     }
     void free(void* p) { (void)hipFree(p); }
@@ -752,6 +752,15 @@ class HipBackend {
         if (e != hipSuccess) throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         graph_exec_[key] = ex;
         ORZ_HIP_CHECK(hipGraphLaunch(ex, stream_));
+    }
+    // a launch threw inside the capture: end it, drop the partial graph, leave the stream usable
+    void graph_capture_abort() {
+        if (!capturing_) return;
+        capturing_ = false;
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream_, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
     }
     void set_graphs(bool on) { graphs_ = on; }
     // the captured launches hold the encoder's buffer addresses and settings: forget them when the encoder is rebuilt

@@ -78,11 +78,27 @@ struct orz_stream {
     unsigned ftile = 131072, frounds = 4;
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
+    // Build the encoder for the current settings.  The new one is constructed BEFORE the old one is dropped (a constructor
+    // that throws -- bad tile size, failed allocation -- leaves the handle as it was); callers that change settings go
+    // through `reconfigure`, which also restores them.
     void rebuild() {
-        enc.reset();
         be->clear_graphs();
-        enc.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
+        std::unique_ptr<Enc> fresh(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
+        enc = std::move(fresh);
         enc->trace = tracing ? &trace : nullptr;
+    }
+    // apply a settings change + rebuild as a transaction: on failure every setting is as before and the old encoder lives on
+    template <class Change>
+    void reconfigure(Change change) {
+        const unsigned seg0 = seg, win0 = win, ftile0 = ftile, frounds0 = frounds;
+        const bool fast0 = fast;
+        change();
+        try {
+            rebuild();
+        } catch (...) {
+            seg = seg0; win = win0; ftile = ftile0; frounds = frounds0; fast = fast0;
+            throw;
+        }
     }
 };
 
@@ -153,9 +169,10 @@ void orz_stream_free(orz_stream* s) {
 int orz_stream_set_tuning(orz_stream* s, unsigned seg_bytes, unsigned window_segs) {
     if (!s) return fail(ORZ_EINVAL, "null stream");
     try {
-        if (seg_bytes) s->seg = seg_bytes;
-        if (window_segs) s->win = window_segs;
-        s->rebuild();
+        s->reconfigure([&] {
+            if (seg_bytes) s->seg = seg_bytes;
+            if (window_segs) s->win = window_segs;
+        });
         return ORZ_OK;
     } catch (const std::exception& e) {
         return fail(ORZ_EINVAL, e.what());
@@ -164,10 +181,11 @@ int orz_stream_set_tuning(orz_stream* s, unsigned seg_bytes, unsigned window_seg
 int orz_stream_set_mode(orz_stream* s, int mode, unsigned tile_bytes, unsigned rounds) {
     if (!s || (mode != ORZ_MODE_EXACT && mode != ORZ_MODE_FAST)) return fail(ORZ_EINVAL, "bad mode");
     try {
-        s->fast = mode == ORZ_MODE_FAST;
-        if (tile_bytes) s->ftile = tile_bytes;
-        if (rounds) s->frounds = rounds;
-        s->rebuild();
+        s->reconfigure([&] {
+            s->fast = mode == ORZ_MODE_FAST;
+            if (tile_bytes) s->ftile = tile_bytes;
+            if (rounds) s->frounds = rounds;
+        });
         return ORZ_OK;
     } catch (const std::exception& e) {
         return fail(ORZ_EINVAL, e.what());
@@ -285,7 +303,7 @@ orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_
             if (!s) { drop(); return nullptr; }
             if (jobs_per_device > 1 && !s->fast) {  // exact mode: several streams share the GPU: a smaller speculative window each
                 s->win = env_u("ORZ_MEMBER_WIN", std::max(256u, window_for(*s->be, *cfg, 0) / (unsigned)jobs_per_device));
-                try { s->rebuild(); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); drop(); return nullptr; }
+                try { s->reconfigure([] {}); } catch (const std::exception& e) { fail(ORZ_ENODEV, e.what()); orz_stream_free(s); drop(); return nullptr; }
             }
             m->workers.push_back(s);
         }

@@ -39,33 +39,48 @@ constexpr uint32_t kSeg64 = 64;                    // positions per path segment
 constexpr uint32_t kNSub = kNewMax / kSub + 2;
 constexpr uint32_t kEntries = 240;                 // a path enters a chunk / tile within its first 240 positions
 
+constexpr uint32_t kFastK = 64;                    // run predecessors tabulated per position (one word of the member bitmap)
+constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the history: window offset x lies in subtile (x + 1) >> 12
+constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
+
 struct FastArgs {
     const uint8_t* win;
     uint32_t len, n;            // window end, new bytes
     uint32_t K, depth, lazy1, lazy2, tile;
+    uint32_t dmax;              // max(depth, lazy1, lazy2)
+    uint32_t nent, nk;          // slots of the candidate lists / of the word-predictor lists
     // static per block
     const uint32_t *idx, *epos, *kidx, *kpos, *krun;
-    const uint8_t* rows;        // [n][K]
+    const uint8_t* rows;        // [n][K] common prefix with each of the K predecessors in the run
     const uint8_t* rlen;        // [n] min(255, slots of the run below the position)
+    const uint64_t* rdist;      // [n] eight distance codes: how far back the run predecessors number 1, 2, 4, 8, 16, 32, 48, 64 lie
+    const uint64_t* wmask;      // [n] word predictor: which of the 64 list slots below the position hold its own next two bytes
+    const uint16_t* kmeta;      // [n] list slots below in the same hash2 run (0..64) | slot below is p-1 << 7 | words[] snapshot predicts << 8
     const uint16_t* kw;         // [n+1] the two bytes at each word-list slot's position
     const uint8_t* wsnap;       // words[] at the block start
     const uint32_t* ORD;        // exact ring ordinals of history item starts
     const uint64_t* stext;      // [nent][2] 16 leading bytes of each slot's position
     const uint32_t* runstart;   // first slot of each (ctx, hash) run
+    const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
     uint32_t far;               // slots searched beyond the tabulated K when a long run shows too few item starts
     uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint64_t* v1;               // bit per non-zero word of vbits (V1Build once per parse, then kept in step by FastFlip)
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
-    uint32_t* bs;               // [n+8] best source (window offset)
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
     uint64_t* sbits;            // [n/64+8] item starts of the current path, bit per new position
-    uint8_t *mf, *ef;           // [n+264] what vbits / kbits currently hold for each position
+    uint8_t *mfb, *efb;         // [n/8+40] what vbits / kbits currently hold for each position, bit per position
+    uint8_t* dirty;             // [n+264] the position's candidates changed since it was last evaluated (set by FastFlip)
+    uint32_t* hz;               // [kNSub][256][4] ring horizons per (subtile, ctx): oldest window offset still within 4094 / 510 item starts,
+                                // and the two values one step earlier (what the evaluations of the previous step saw)
+    uint32_t *farlist, *nfar;   // positions of this step that need the far search (FastEval appends, FastFar consumes)
+    uint8_t* fseen;             // [n+8] item starts FastEval saw in the tabulated window of a listed position
     uint8_t *x0, *x1, *x2;      // path maps: per position, per (chunk, entry), per (tile, entry)
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
     uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
     uint32_t* nchg;
+    uint32_t dbg;               // experiment switches (ORZ_FAST_DBG): 1 = evaluate every position every round
 };
 
 ORZ_D uint32_t fast_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -101,6 +116,62 @@ ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
 #endif
 }
 
+ORZ_D uint32_t clz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clz((int)v);
+#else
+    return (uint32_t)__builtin_clz(v);
+#endif
+}
+// A slot of an append-only list: on the device the lanes of a wavefront that append at the same point share ONE atomic
+// (leader adds the count, everybody takes its rank) -- a quarter of the positions of a step append, and that many
+// single atomics on one counter would serialise in L2.
+ORZ_D uint32_t list_slot(uint32_t* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t m = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+#else
+    return (*counter)++;
+#endif
+}
+
+// Position distances as 8-bit codes: exact below 16, then eight steps per octave.  A distance is coded rounded UP, a
+// budget rounded DOWN, so code(distance) <= code(budget) implies distance <= budget (never the other way round by
+// more than one step, 1/8 of the value).
+ORZ_D uint32_t dist_code_up(uint32_t d) {
+    if (d < 16) return d;
+    const uint32_t e = 31 - clz32(d), sh = e - 3;
+    return 16 + (e - 4) * 8 + ((d >> sh) & 7) + ((d & ((1u << sh) - 1)) ? 1 : 0);
+}
+ORZ_D uint32_t dist_code_down(uint32_t d) {
+    if (d < 16) return d;
+    const uint32_t e = 31 - clz32(d), sh = e - 3;
+    return 16 + (e - 4) * 8 + ((d >> sh) & 7);
+}
+// the run predecessors whose distance is sampled (0 = the newest), and how many predecessors a sample vouches for
+ORZ_D uint32_t dist_sample(uint32_t m) { return m < 4 ? (1u << m) - 1 : (m == 4 ? 15 : (m == 5 ? 31 : (m == 6 ? 47 : 63))); }
+// Newest predecessors of a position that lie within `budget` positions, from its eight distance codes: `sure` of them
+// certainly do, the ones from `limit` on certainly do not; what lies between (at most two sample intervals, only when
+// the budget ends inside the window) is for the caller to settle with the positions themselves.
+struct DistBracket { uint32_t sure, limit; };
+ORZ_D DistBracket dist_valid(uint64_t codes, uint32_t budget) {
+    const uint32_t bd = dist_code_down(budget), bu = dist_code_up(budget);
+    DistBracket b{0, 64};
+    bool open = true;
+#pragma unroll
+    for (uint32_t m = 0; m < 8; m++) {
+        const uint32_t code = (uint32_t)((codes >> (8 * m)) & 0xff);
+        if (code <= bd) b.sure = dist_sample(m) + 1;
+        else if (code > bu && open) { b.limit = dist_sample(m); open = false; }
+    }
+    return b;
+}
+
 // runs (ctx, hash) that gained an item start in a repair pass: one bit per run key
 ORZ_D void mark_run(const uint8_t* win, uint64_t* rdirty, uint32_t x) {
     const uint32_t key = bucket_key(win, x);
@@ -133,22 +204,99 @@ struct FastKw {
         kw[s] = (uint16_t)(win[u] | (win[u + 1] << 8));
     }
 };
-// common prefixes of a new position with its K predecessors in the (ctx, hash) run (simple form: thread
-// per position straight from the window; FastRowsWave below is the LDS-staged form the GPU runs)
-struct FastRows {
-    const uint8_t* win;
-    const uint32_t *idx, *epos;
-    const uint8_t* rlen;
-    uint32_t n, K;
-    uint8_t* rows;
-    ORZ_HD void operator()(size_t i) const {
-        if (i >= n) return;
-        const uint32_t p = kPre + (uint32_t)i, j = idx[p], r = fast_min(K, rlen[i]);
-        uint8_t* row = rows + (size_t)i * K;
-        for (uint32_t k = 0; k < K; k++) row[k] = k < r ? (uint8_t)lcp240u(win + epos[j - 1 - k], win + p) : 0;
+// Static half of the word predictor (src/lz.rs:132-133): the prediction for p is the two bytes behind the newest
+// words[] update among the earlier positions of its hash2 run.  Which positions update is decided by the parse (kbits);
+// whether a given one would predict p's bytes is not -- tabulated here once per block for the 64 list slots below p, so
+// that a round needs the bitmap window only.
+struct FastWordMasks {  // thread per word-list slot
+    const uint32_t *kpos, *kkeys, *krun;
+    const uint16_t* kw;
+    const uint8_t* wsnap;
+    uint32_t nk;
+    uint64_t* wmask;
+    uint16_t* kmeta;
+    ORZ_HD void operator()(size_t s) const {
+        if (s >= nk) return;
+        const uint32_t u = kpos[s];
+        if (u < kPre) return;  // (the list starts one position before the block)
+        const uint32_t key = kkeys[s], rk = fast_min(64u, (uint32_t)s - krun[key]);
+        const uint32_t w = kw[s];
+        uint64_t m = 0;
+        for (uint32_t t = 0; t < rk; t++) m |= (uint64_t)(kw[s - 1 - t] == w) << (63 - t);
+        const uint32_t excl = rk && kpos[s - 1] == u - 1;  // the slot right below is u = p-1: its update comes too late
+        const uint32_t snap = ((uint32_t)wsnap[key * 2] | ((uint32_t)wsnap[key * 2 + 1] << 8)) == w;
+        wmask[u - kPre] = m;
+        kmeta[u - kPre] = (uint16_t)(rk | (excl << 7) | (snap << 8));
     }
 };
-// Same table, one wavefront per 64 consecutive slots: the 16 leading bytes of the 64 + K slots involved are
+// History item starts per (unified subtile, ctx): one wavefront per subtile, counters in LDS (the ring horizons of a
+// round reach back into the history: FastHorizon)
+struct HistCountWave {
+    const uint8_t* win;
+    const uint8_t* S;
+    uint32_t* hcm;  // [kHistSub][256]
+    static size_t lds_bytes() { return 256 * 4; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* cnt = (uint32_t*)w.lds();
+        const uint32_t u = w.block(), lane = w.lane();
+        for (uint32_t c = lane; c < 256; c += 64) cnt[c] = 0;
+        w.sync();
+        const uint32_t x0 = u * kSub + lane * 64;  // positions x0 - 1 .. x0 + 62
+        for (uint32_t k = 0; k < 64; k++) {
+            const uint32_t x = x0 + k - 1;
+            if (x0 + k == 0 || x < 1 || x >= kPre) continue;  // position 0 is dead (src/matcher.rs:85)
+            if (S[x]) atom_add32(&cnt[hash1(win, x - 1)], 1);
+        }
+        w.sync();
+        for (uint32_t c = lane; c < 256; c += 64) hcm[(size_t)u * 256 + c] = cnt[c];
+    }
+};
+// Exclusive prefix down the columns of a [rows][256] table in three small launches (groups of 64 rows): group sums,
+// their prefix per column, then the rows of each group.  out[0][c] must hold the base; out gets rows + 1 rows.
+struct ColScanGroups {
+    const uint32_t* in;
+    uint32_t rows;
+    uint32_t* gsum;  // [groups][256]
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = (uint32_t)(tid & 255), g = (uint32_t)(tid >> 8);
+        if (g * 64 >= rows) return;
+        uint32_t v = 0;
+        for (uint32_t r = g * 64; r < rows && r < g * 64 + 64; r++) v += in[(size_t)r * 256 + c];
+        gsum[(size_t)g * 256 + c] = v;
+    }
+};
+struct ColScanTop {
+    uint32_t* gsum;
+    uint32_t rows;
+    const uint32_t* out;  // out[0][c] = base
+    ORZ_HD void operator()(size_t c) const {
+        if (c >= 256) return;
+        uint32_t v = out[c];
+        for (uint32_t g = 0; g * 64 < rows; g++) {
+            const uint32_t t = gsum[(size_t)g * 256 + c];
+            gsum[(size_t)g * 256 + c] = v;
+            v += t;
+        }
+    }
+};
+struct ColScanRows {
+    const uint32_t *in, *gsum;
+    uint32_t rows;
+    uint32_t* out;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = (uint32_t)(tid & 255), g = (uint32_t)(tid >> 8);
+        if (g * 64 >= rows) return;
+        uint32_t v = gsum[(size_t)g * 256 + c];
+        for (uint32_t r = g * 64; r < rows && r < g * 64 + 64; r++) {
+            out[(size_t)r * 256 + c] = v;
+            v += in[(size_t)r * 256 + c];
+        }
+        if (g * 64 + 64 >= rows) out[(size_t)rows * 256 + c] = v;
+    }
+};
+// Common prefixes of a new position with its K predecessors in the (ctx, hash) run.
+// One wavefront per 64 consecutive slots: the 16 leading bytes of the 64 + K slots involved are
 // staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 16 bytes go to the window.
 // The rows leave through LDS as well, 64 columns at a time, so that every 64-byte piece of a row is written by
 // four neighbouring lanes in one go (a lane storing its own row eight bytes at a time costs a partial line per store).
@@ -171,14 +319,16 @@ struct FastRowsWave {
     const uint8_t* rlen;
     uint32_t nent, K;  // K is a multiple of 64
     uint8_t* rows;
+    uint64_t* rdist;   // [n] distance codes of the sampled predecessors (dist_valid)
     static constexpr uint32_t kOutStride = 72;  // bytes per lane in the staging tile (64 + pad against bank conflicts)
-    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride; }
+    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride + 64; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint64_t* t0 = (uint64_t*)w.lds();            // [64+K] bytes 0..7
         uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..15
         uint32_t* ps = (uint32_t*)(t1 + (64 + K));    // [64+K] positions
         uint8_t* outL = (uint8_t*)(ps + (64 + K));    // [64][kOutStride]
+        uint8_t* rL = outL + 64 * kOutStride;         // [64] tabulated depth of each row
         const uint32_t lane = w.lane();
         const int64_t base = (int64_t)w.block() * 64 - K;  // slot of LDS entry 0
         for (uint32_t e = lane; e < 64 + K; e += 64) {
@@ -193,7 +343,17 @@ struct FastRowsWave {
         const uint32_t p = ps[me];
         const bool mine = (int64_t)w.block() * 64 + lane < (int64_t)nent && p >= kPre;
         const uint32_t r = mine ? fast_min(K, rlen[p - kPre]) : 0;
+        rL[lane] = (uint8_t)r;
         const uint64_t a0 = t0[me], a1 = t1[me];
+        if (mine) {  // how far back the sampled predecessors lie (a sample beyond the run's depth stands for its oldest member)
+            uint64_t codes = 0;
+            for (uint32_t m = 0; m < 8; m++) {
+                const uint32_t k = r ? fast_min(dist_sample(m), r - 1) : 0;
+                const uint32_t code = r ? dist_code_up(p - ps[me - 1 - k]) : 255u;
+                codes |= (uint64_t)code << (8 * m);
+            }
+            rdist[p - kPre] = codes;
+        }
         for (uint32_t c0 = 0; c0 < K; c0 += 64) {
             for (uint32_t k0 = 0; k0 < 64; k0 += 8) {
                 uint64_t pack = 0;
@@ -217,7 +377,8 @@ struct FastRowsWave {
             for (uint32_t it = 0; it < 4; it++) {  // 16 rows per pass, four lanes per 64-byte piece
                 const uint32_t row = it * 16 + (lane >> 2), part = lane & 3;
                 const uint32_t pr = ps[K + row];
-                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {
+                // (a row is read up to its run depth only: the 16-byte pieces beyond it are not written)
+                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre && c0 + part * 16 < rL[row]) {
                     const uint64_t v0 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16);
                     const uint64_t v1 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16 + 8);
                     uint64_t* dst = reinterpret_cast<uint64_t*>(rows + (size_t)(pr - kPre) * K + c0 + part * 16);
@@ -276,151 +437,241 @@ struct V1Build {  // thread per summary word: 64 words of the bitmap
     }
 };
 
-// ---- one round: every position of the active range decides from the snapshot --------------------------
+// ---- one round: the positions of the active range decide from the snapshot ----------------------------
+// A position is evaluated in its tile's first round, and afterwards only when the item starts it looks at changed
+// (FastFlip marks it dirty) or when its tile's far search is due.  Everything a round needs per position is either
+// static and read in position order (its row of common prefixes, the distance codes of its run predecessors, the
+// word-predictor masks) or one window of a bitmap in slot order: no load depends on another one except bitmap <- idx,
+// so a launch is bound by HBM bandwidth, not by a chain of latencies.  The far search -- a real walk -- is not done
+// here: positions that need it are appended to a list and FastFar works the list off densely.
+#if !defined(__HIPCC__)
+inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / far-due)
+#endif
 struct FastEval {
     FastArgs a;
-    uint32_t lo, hi;  // window offsets [lo, hi)
-    // The far search (beyond the K tabulated predecessors) is the expensive part and its answer moves little from round
-    // to round: it runs in a tile's second round (the first one, against an empty tile, only sketches the path) and
-    // again in its last one (when every earlier tile is final); the other rounds merge the remembered answer.
-    // [fa0, fa1) and [fb0, fb1): the window offsets (two tiles) where it runs in this launch.
+    uint32_t lo, hi;    // window offsets [lo, hi)
+    uint32_t r1lo;      // positions >= r1lo have not been evaluated in this parse yet (the tile in its first round, and beyond)
+    // [fa0, fa1) and [fb0, fb1): the window offsets (two tiles) whose far search is due in this launch: the tile in its
+    // second round (the first one, against an empty tile, only sketches the path) and the tile in its last one (when
+    // every earlier tile is final); the other rounds merge the remembered answer.
     uint32_t fa0, fa1, fb0, fb1;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
         const uint8_t* win = a.win;
-        const uint32_t i = p - kPre, c = hash1(win, p - 1), K = a.K;
-#if !defined(__HIPCC__)
-        g_far_stats[0]++;
-#endif
-        const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
-        const uint8_t* row = a.rows + (size_t)i * K;
-        const uint32_t sp = i / kSub;
-        // ring ordinal of an item starting at p: exact up to the subtile, interpolated inside it (item starts of one
-        // context are spread evenly enough); validity tests add a margin, the final source assignment is exact
-        const uint32_t cmp_ = a.cm[(size_t)sp * 256 + c];
-        const uint32_t op_lo = a.cp[(size_t)sp * 256 + c] + ((cmp_ * (i & (kSub - 1))) >> 12);
-        const uint32_t op_hi = op_lo + (cmp_ >> 3) + 4;
-        uint32_t best = 0, bsrc = 0, b510 = 0, m1 = 0, m2 = 0, seen = 0;
-        bool stop = false;
-        for (uint32_t m = 0; m * 64 < r && !stop && seen < a.depth; m++) {
-            uint64_t mask = bits_at(a.vbits, (int64_t)j - 64 * (int64_t)(m + 1));
-            const uint32_t span = r - m * 64;  // slots of this group that still belong to the run window
-            if (span < 64) mask &= ~0ull << (64 - span);
-            while (mask && seen < a.depth) {
-                const uint32_t t = 63 - (uint32_t)clz64(mask);
-                mask &= ~(1ull << t);
-                const uint32_t k = m * 64 + 63 - t;
-                const uint32_t l = row[k];
-                if (l > best || (seen < a.lazy1 && l > m1) || (seen < a.lazy2 && l > m2)) {
-                    // ring check, only for candidates that matter (validity is monotone: older = further)
-                    const uint32_t q = a.epos[j - 1 - k];
-                    uint32_t ro_hi, ro_mid;
-                    if (q >= kPre) {
-                        const uint32_t sq = (q - kPre) / kSub;
-                        const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
-                        ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
-                        ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
-                    } else {
-                        ro_hi = op_hi - 1 - a.ORD[q];
-                        ro_mid = op_lo - 1 - a.ORD[q];
-                    }
-                    if (ro_hi > kRing - 1) { stop = true; break; }
-                    if (l > best) { best = l; bsrc = q; b510 = (int32_t)ro_mid < 510; }
-                    if (seen < a.lazy1 && l > m1) m1 = l;
-                    if (seen < a.lazy2 && l > m2) m2 = l;
-                }
-                seen++;
-                if (l == kMaxLen) { stop = true; break; }
-            }
+        const uint32_t i = p - kPre;
+        const uint32_t rl = a.rlen[i];
+        const bool first = p >= r1lo;
+        const bool fardue = (p >= fa0 && p < fa1) || (p >= fb0 && p < fb1);
+        const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
+        const uint32_t c = hash1(win, p - 1);
+        const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
+        const uint32_t h4 = hz[0], h5 = hz[1];
+        const uint64_t codes = a.rdist[i];
+        const DistBracket d4 = dist_valid(codes, p > h4 ? p - h4 : 0);
+        // the ring horizon of (subtile, ctx) moved since the previous step: re-evaluate where that changes which of the
+        // window's predecessors count (every active position looks every step, so one step of history is enough)
+        bool moved = false;
+        if (!first && hz[2] != h4) {
+            const DistBracket o4 = dist_valid(codes, p > hz[2] ? p - hz[2] : 0);
+            moved = o4.sure != d4.sure || o4.limit != d4.limit || d4.sure < fast_min(fast_min(kFastK, rl), d4.limit);
         }
-        if (!stop && seen < a.depth && a.rlen[i] > K && a.far) {
-            if ((p >= fa0 && p < fa1) || (p >= fb0 && p < fb1)) {
-                // a long run whose tabulated K predecessors hold too few item starts (runs of "interior" 4-grams, zero runs):
-                // walk the bitmap further back and take the prefixes from the text records
-                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
-                const uint32_t top = j - K;  // slots [lo2, top) are searched, newest first
-                const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-                const uint64_t a0 = ldu64(win + p), a1 = ldu64(win + p + 8);
-                uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
 #if !defined(__HIPCC__)
-                g_far_stats[1]++;
+        g_eval_stats[0]++;
+        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (fardue && rl > kFastK) g_eval_stats[4]++;
 #endif
-                // item starts of the range, newest first, four at a time: the slots are collected from the bitmap first, their
-                // text records are fetched together (independent loads), then they are examined in order -- the walk was a
-                // chain of dependent loads, one member after the other, and FastEval lasts as long as its longest chain
-                constexpr uint32_t kBatch = 4;
-                uint32_t cur_top = top;
-                bool more = true;
-                while (more) {
-                    uint32_t sl[kBatch], nb = 0;
-                    far_walk(a, lo2, cur_top, [&](uint32_t s2) -> bool { sl[nb++] = s2; return nb < kBatch; });
-                    if (nb == 0) break;
-                    uint64_t x0[kBatch], x1[kBatch];
-#pragma unroll
-                    for (uint32_t k = 0; k < kBatch; k++) {
-                        const uint32_t s2 = k < nb ? sl[k] : sl[0];
-                        x0[k] = a.stext[2 * (size_t)s2] ^ a0;
-                        x1[k] = a.stext[2 * (size_t)s2 + 1] ^ a1;
-                    }
-#pragma unroll
-                    for (uint32_t k = 0; k < kBatch; k++) {
-                        if (k >= nb || !more) break;
+        if (!first && !dirty && !moved && !(fardue && rl > kFastK && a.far)) return;
 #if !defined(__HIPCC__)
-                        g_far_stats[3]++;
+        g_eval_stats[1]++;
 #endif
-                        const uint32_t s2 = sl[k];
-                        uint32_t l;
-                        if (x0[k]) l = (uint32_t)ctz64(x0[k]) >> 3;
-                        else if (x1[k]) l = 8 + ((uint32_t)ctz64(x1[k]) >> 3);
-                        else l = 16 + lcp240u(win + a.epos[s2] + 16, win + p + 16, kMaxLen - 16);
-                        if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
-                            const uint32_t q = a.epos[s2];
-                            uint32_t ro_hi, ro_mid;
-                            if (q >= kPre) {
-                                const uint32_t sq = (q - kPre) / kSub;
-                                const uint32_t oq = a.cp[(size_t)sq * 256 + c] + ((a.cm[(size_t)sq * 256 + c] * ((q - kPre) & (kSub - 1))) >> 12);
-                                ro_hi = op_hi > oq ? op_hi - oq - 1 : 0;
-                                ro_mid = op_lo > oq ? op_lo - oq - 1 : 0;
-                            } else {
-                                ro_hi = op_hi - 1 - a.ORD[q];
-                                ro_mid = op_lo - 1 - a.ORD[q];
-                            }
-                            if (ro_hi > kRing - 1) { stop = true; more = false; break; }
-                            if (l > fbest) { fbest = l; fsrc = q; f510 = (int32_t)ro_mid < 510; }
-                            if (seen < a.lazy1 && l > fm1) fm1 = l;
-                            if (seen < a.lazy2 && l > fm2) fm2 = l;
-                        }
-                        seen++;
-                        if (l == kMaxLen) { stop = true; more = false; break; }
-                        if (seen >= a.depth) { more = false; break; }
-                    }
-                    if (nb < kBatch) break;  // the range is exhausted
-                    cur_top = sl[nb - 1];
+        if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
+        const uint32_t j = a.idx[p], r = fast_min(kFastK, rl);
+        const uint8_t* row = a.rows + (size_t)i * kFastK;
+        // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts
+        const DistBracket d5 = dist_valid(codes, p > h5 ? p - h5 : 0);
+        uint32_t v4 = d4.sure;
+        {   // the ring ends inside the window (hot contexts): settle the uncertain stretch with the positions (independent loads)
+            const uint32_t kend = fast_min(r, d4.limit);
+#if !defined(__HIPCC__)
+            if (v4 < kend) g_eval_stats[5]++;
+#endif
+            uint32_t extra = 0;
+            for (uint32_t k = d4.sure; k < kend; k++) extra += a.epos[j - 1 - k] >= h4;
+            v4 += extra;
+        }
+        if (a.dbg & 2) v4 = 64;
+        uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
+        const uint32_t span = fast_min(r, v4);
+        if (span < 64) mask = span ? mask & (~0ull << (64 - span)) : 0;
+        uint32_t best = 0, bk = 0, m1 = 0, m2 = 0, seen = 0;
+        bool stop = v4 < r;  // the ring ends inside the window: nothing older counts either
+        while (mask && seen < a.depth) {
+            const uint32_t t = 63 - (uint32_t)clz64(mask);
+            mask &= ~(1ull << t);
+            const uint32_t k = 63 - t;
+            const uint32_t l = row[k];
+            if (l > best) { best = l; bk = k; }
+            if (seen < a.lazy1 && l > m1) m1 = l;
+            if (seen < a.lazy2 && l > m2) m2 = l;
+            seen++;
+            if (l == kMaxLen) { stop = true; break; }
+        }
+        uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
+        if (first) a.farv[i] = 0;  // nothing remembered yet
+        if (!stop && seen < a.depth && rl > kFastK && a.far) {
+            if (fardue) {  // FastFar continues from here and merges its answer
+                a.fseen[i] = (uint8_t)seen;
+                a.farlist[list_slot(a.nfar)] = i;
+            } else {
+                const uint32_t fv = a.farv[i];
+                if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
+                    if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
+                    if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
+                    if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
                 }
-                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
-                a.farsrc[i] = fsrc;
-            }
-            const uint32_t fv = a.farv[i];
-            if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
-                if ((fv & 0xff) > best) { best = fv & 0xff; bsrc = a.farsrc[i]; b510 = (fv >> 24) & 1; }
-                if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
-                if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
             }
         }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
-        const uint32_t key2 = hash2(win, p - 1);
-        const uint32_t kj = a.kidx[p], klo = a.krun[key2];
-        uint32_t rk = kj - klo;
-        uint64_t kmask = bits_at(a.kbits, (int64_t)kj - 64);
-        if (rk < 64) kmask &= rk ? ~0ull << (64 - rk) : 0;
-        if (rk && hash2(win, p - 2) == key2) kmask &= ~(1ull << 63);  // the slot right below is u = p-1
-        uint32_t w;
-        if (kmask) w = a.kw[kj - 64 + (63 - (uint32_t)clz64(kmask))];
-        else w = (uint32_t)a.wsnap[key2 * 2] | ((uint32_t)a.wsnap[key2 * 2 + 1] << 8);
-        const uint32_t lwm = w == ((uint32_t)win[p] | ((uint32_t)win[p + 1] << 8));
+        const uint32_t km = a.kmeta[i], rk = km & 0x7f;
+        uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)a.kidx[p] - 64) : 0;
+        if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
+        if (km & 0x80) kmask &= ~(1ull << 63);
+        const uint32_t lwm = kmask ? (uint32_t)((a.wmask[i] >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
+#if !defined(__HIPCC__)
+        if ((a.dbg & 32) && !first && !a.dirty[i] && !moved && !(fardue && rl > kFastK && a.far)) {  // verify mode: would a skipped position have changed?
+            const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
+            if ((o ^ nw) & ~(1u << 25)) {
+                g_eval_stats[6]++;
+                if ((o ^ nw) & (1u << 24)) g_eval_stats[7]++;
+                static int shown = 0;
+                if (shown++ < 20) fprintf(stderr, "skip-miss p=%u old=%08x new=%08x rl=%u\n", p, o, nw, rl);
+            }
+        }
+#endif
         a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
-        a.bs[i] = bsrc;
+    }
+};
+// The far search of the listed positions: a long run whose tabulated K predecessors hold too few item starts (runs of
+// "interior" 4-grams, zero runs) -- walk the bitmap further back through its summary level and take the prefixes from
+// the text records.  Item starts newest first, four at a time: the slots are collected from the bitmap first, their
+// text records are fetched together (independent loads), then they are examined in order.
+struct FastFar {
+    FastArgs a;
+    uint32_t nthreads;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t nf = *a.nfar;
+        const uint8_t* win = a.win;
+        for (uint32_t e = (uint32_t)tid; e < nf; e += nthreads) {
+            const uint32_t i = a.farlist[e], p = kPre + i, j = a.idx[p];
+            const uint32_t c = hash1(win, p - 1);
+            const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
+            const uint32_t h4 = hz[0], h5 = hz[1];
+            const uint32_t e0 = a.ev[i];
+            uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
+            uint32_t seen = a.fseen[i];
+            const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
+            const uint32_t top = j - kFastK;  // slots [lo2, top) are searched, newest first
+            const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+            const uint64_t a0 = a.stext[2 * (size_t)j], a1 = a.stext[2 * (size_t)j + 1];
+            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
+#if !defined(__HIPCC__)
+            g_far_stats[1]++;
+#endif
+            constexpr uint32_t kBatch = 4;
+            uint32_t cur_top = top;
+            bool more = true;
+            while (more) {
+                uint32_t sl[kBatch], nb = 0;
+                far_walk(a, lo2, cur_top, [&](uint32_t s2) -> bool { sl[nb++] = s2; return nb < kBatch; });
+                if (nb == 0) break;
+                uint64_t x0[kBatch], x1[kBatch];
+#pragma unroll
+                for (uint32_t k = 0; k < kBatch; k++) {
+                    const uint32_t s2 = k < nb ? sl[k] : sl[0];
+                    x0[k] = a.stext[2 * (size_t)s2] ^ a0;
+                    x1[k] = a.stext[2 * (size_t)s2 + 1] ^ a1;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < kBatch; k++) {
+                    if (k >= nb || !more) break;
+#if !defined(__HIPCC__)
+                    g_far_stats[3]++;
+#endif
+                    const uint32_t s2 = sl[k];
+                    uint32_t l;
+                    if (x0[k]) l = (uint32_t)ctz64(x0[k]) >> 3;
+                    else if (x1[k]) l = 8 + ((uint32_t)ctz64(x1[k]) >> 3);
+                    else l = 16 + lcp240u(win + a.epos[s2] + 16, win + p + 16, kMaxLen - 16);
+                    if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
+                        const uint32_t q = a.epos[s2];  // ring check, only for candidates that matter (validity is monotone)
+                        if (q < h4) { more = false; break; }
+                        if (l > fbest) { fbest = l; fsrc = q; f510 = q >= h5; }
+                        if (seen < a.lazy1 && l > fm1) fm1 = l;
+                        if (seen < a.lazy2 && l > fm2) fm2 = l;
+                    }
+                    seen++;
+                    if (l == kMaxLen) { more = false; break; }
+                    if (seen >= a.depth) { more = false; break; }
+                }
+                if (nb < kBatch) break;  // the range is exhausted
+                cur_top = sl[nb - 1];
+            }
+            a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+            a.farsrc[i] = fsrc;
+            if (fbest > best) { best = fbest; b510 = f510; }
+            if (fm1 > m1) m1 = fm1;
+            if (fm2 > m2) m2 = fm2;
+            a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
+        }
+    }
+};
+// Ring horizons of the subtiles [s0, s1] per context: the oldest window offset from which at most `limit` item starts of
+// the context lie before the END of the subtile -- candidates at or after it are inside the ring (limit 4094 - margin) /
+// cost fewer than 8 offset bits (510), whatever the position inside the subtile (conservative by the subtile's own
+// count).  Counts come from cp (new region, kept by FastPrefix; the tile about to start is extrapolated there) and hpre
+// (history).  Thread per (subtile, ctx), two binary searches over L2-resident columns.
+struct FastHorizon {
+    FastArgs a;
+    uint32_t s0, s1;
+    ORZ_D uint32_t horizon(uint32_t s, uint32_t c, uint32_t limit) const {
+        // counted from the MIDDLE of the subtile's own item starts (a position sees those before it: half of them on average)
+        const uint32_t c0 = a.cp[(size_t)s * 256 + c], c1 = a.cp[(size_t)(s + 1) * 256 + c];
+        const uint32_t end = c0 + (c1 - c0) / 2, base = a.cp[c];
+        if (end - base > limit) {  // inside the new region: smallest s' in [0, s + 1] with end - cp[s'] <= limit
+            uint32_t lo = 0, hi = s + 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) / 2;
+                const uint32_t v = a.cp[(size_t)mid * 256 + c];
+                if (v >= end || end - v <= limit) hi = mid; else lo = mid + 1;
+            }
+            uint32_t h = kPre + lo * kSub;
+            if (lo) {  // part of the subtile before still fits: its item starts are taken as evenly spread
+                const uint32_t v = a.cp[(size_t)lo * 256 + c], room = limit - (v >= end ? 0 : end - v);
+                const uint32_t m = v - a.cp[(size_t)(lo - 1) * 256 + c];
+                if (m) h -= (uint32_t)(((uint64_t)fast_min(room, m) * kSub) / m);
+            }
+            return h;
+        }
+        const uint32_t room = limit - (end - base), tot = a.hpre[(size_t)kHistSub * 256 + c];
+        uint32_t lo = 0, hi = kHistSub;  // smallest unified subtile u with tot - hpre[u] <= room
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (tot - a.hpre[(size_t)mid * 256 + c] <= room) hi = mid; else lo = mid + 1;
+        }
+        if (!lo) return 1;
+        uint32_t h = lo * kSub - 1;
+        const uint32_t left = room - (tot - a.hpre[(size_t)lo * 256 + c]);
+        const uint32_t m = a.hpre[(size_t)lo * 256 + c] - a.hpre[(size_t)(lo - 1) * 256 + c];
+        if (m) h -= (uint32_t)(((uint64_t)fast_min(left, m) * kSub) / m);
+        return h > 1 ? h : 1;
+    }
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t c = (uint32_t)(tid & 255), s = s0 + (uint32_t)(tid >> 8);
+        if (s > s1) return;
+        uint32_t* hz = a.hz + ((size_t)s * 256 + c) * 4;
+        hz[2] = hz[0]; hz[3] = hz[1];
+        hz[0] = horizon(s, c, kRing - kRingMargin);
+        hz[1] = horizon(s, c, 510);
     }
 };
 // src/lz.rs:139-234 on the snapshot's answers: e = ev of the position, e1 / e2 = ev of the next two (0 past the end);
@@ -445,6 +696,7 @@ struct FastDecide {  // thread per position (measured: inside PathUpWave the fou
     uint32_t lo, hi;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
+        if (tid == 0) *a.nfar = 0;  // (FastFar has consumed this step's list)
         if (p >= hi) return;
         const uint32_t i = p - kPre;
         const uint32_t d = fast_decide(p, a.len, a.ev[i], p + 1 < a.len ? a.ev[i + 1] : 0, p + 2 < a.len ? a.ev[i + 2] : 0);
@@ -667,48 +919,75 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// bring the slot-order bitmaps in line with the path (thread per 8 positions)
+// Bring the slot-order bitmaps in line with the path (thread per 8 positions), and mark the positions whose next
+// evaluation would see the difference: a flipped item start matters to the later positions of its run for which it is
+// among the newest `dmax` item starts below them -- walk up the run (slots ascend with the position) until that many
+// set bits have been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped
+// word update matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks:
+// whichever state a walk observes, the union of the marks contains every position whose answer can have changed.
 struct FastFlip {
     FastArgs a;
     uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
+    uint32_t mark_hi;    // positions below this one are marked dirty (0 = no marking: the repair passes)
+    ORZ_D void mark_candidates(uint32_t j, uint32_t y) const {
+        uint32_t passed = 0;
+        const uint32_t end = fast_min(a.nent, j + 1 + kFastK);
+        for (uint32_t s = j + 1; s < end; s++) {
+            const uint32_t q = a.epos[s];
+            if (q <= y || q >= mark_hi) break;  // another run / beyond the active range (evaluated in full when its tile starts)
+            a.dirty[q - kPre] = 1;
+            if ((a.vbits[s >> 6] >> (s & 63)) & 1)
+                if (++passed >= a.dmax) break;
+        }
+    }
+    ORZ_D void mark_words(uint32_t ku, uint32_t u) const {
+        const uint32_t end = fast_min(a.nk, ku + 1 + 64);
+        for (uint32_t s = ku + 1; s < end; s++) {
+            const uint32_t q = a.kpos[s];
+            if (q <= u || q >= mark_hi) break;
+            if (q >= kPre) a.dirty[q - kPre] = 1;
+            if ((a.kbits[s >> 6] >> (s & 63)) & 1) break;  // positions above see this update first
+        }
+    }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t y0 = lo + (uint32_t)tid * 8;
         if (y0 > hi) return;
         const uint32_t i0 = y0 - kPre;
         const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;  // where the path leaves the range / the block
         const uint32_t sb = (uint32_t)((a.sbits[i0 / 64] >> (i0 & 63)) & 0xff);
-        uint64_t mfw = *reinterpret_cast<const uint64_t*>(a.mf + i0);
-        uint64_t efw = *reinterpret_cast<const uint64_t*>(a.ef + i0);
+        uint32_t mfw = a.mfb[i0 / 8], efw = a.efb[i0 / 8];
         const uint64_t ptw = *reinterpret_cast<const uint64_t*>(a.pt + i0);
-        const uint64_t mf0 = mfw, ef0 = efw;
+        const uint32_t mf0 = mfw, ef0 = efw;
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t y = y0 + k;
             if (y > hi) break;
             uint32_t s = y == exit_at;
             if (y < a.len) {
                 s |= (sb >> k) & 1;
-                if (s != ((mfw >> (8 * k)) & 0xff)) {
-                    mfw = (mfw & ~(0xffull << (8 * k))) | ((uint64_t)s << (8 * k));
+                if (s != ((mfw >> k) & 1)) {
+                    mfw ^= 1u << k;
                     // the summary level follows: every zero <-> non-zero transition of a word toggles its bit (the atomics on
                     // a word are totally ordered and each transition is seen by exactly the operation that makes it, so the
                     // toggles commute and the bit ends as "word non-zero" however they interleave)
                     const uint32_t j = a.idx[y];
                     const uint64_t bit = 1ull << (j & 63), old = atom_fetch_xor64(&a.vbits[j >> 6], bit);
                     if ((old == 0) != ((old ^ bit) == 0)) atom_xor64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
+                    if (mark_hi) mark_candidates(j, y);
                 }
             }
             if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
                 const uint32_t e = s && ((ptw >> (8 * k)) & 0xff) != kTyWord;
-                if (e != ((efw >> (8 * k)) & 0xff)) {
-                    efw = (efw & ~(0xffull << (8 * k))) | ((uint64_t)e << (8 * k));
+                if (e != ((efw >> k) & 1)) {
+                    efw ^= 1u << k;
                     const uint32_t ku = a.kidx[y - 2];
                     atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+                    if (mark_hi) mark_words(ku, y - 2);
                 }
             }
         }
-        if (mfw != mf0) *reinterpret_cast<uint64_t*>(a.mf + i0) = mfw;
-        if (efw != ef0) *reinterpret_cast<uint64_t*>(a.ef + i0) = efw;
+        if (mfw != mf0) a.mfb[i0 / 8] = (uint8_t)mfw;
+        if (efw != ef0) a.efb[i0 / 8] = (uint8_t)efw;
     }
 };
 // item starts per (subtile, ctx) of the current path: one wavefront per 4096-position subtile, lane = 64 positions,
@@ -737,19 +1016,26 @@ struct CountWave {
         for (uint32_t c = lane; c < 256; c += 64) a.cm[(size_t)s * 256 + c] = cnt[c];
     }
 };
-struct FastPrefix {  // cp[s][c] = cp[s0][c] + sum of cm[s0 .. s)[c] for s in (s0, s1]: thread per (s, ctx), independent loads
+// cp[s][c] = cp[s0][c] + sum of cm[s0 .. s)[c] for s in (s0, s1 + ext]: thread per (s, ctx), independent loads.  The `ext`
+// subtiles behind s1 belong to the tile that starts next: it has no item starts yet, so its counts are taken from the
+// same places one tile (`cpt` subtiles) earlier -- the ring horizons of its first round need an estimate.
+struct FastPrefix {
     FastArgs a;
-    uint32_t s0, s1;
+    uint32_t s0, s1, ext, cpt;
+    ORZ_D uint32_t cmx(uint32_t t, uint32_t c) const {
+        if (t < s1) return a.cm[(size_t)t * 256 + c];
+        return t >= cpt ? a.cm[(size_t)(t - cpt) * 256 + c] : 0;
+    }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t c = (uint32_t)(tid & 255), s = s0 + 1 + (uint32_t)(tid >> 8);
-        if (s > s1) return;
+        if (s > s1 + ext) return;
         uint32_t v0 = a.cp[(size_t)s0 * 256 + c], v1 = 0, v2 = 0, v3 = 0;
         uint32_t t = s0;
         for (; t + 4 <= s; t += 4) {
-            v0 += a.cm[(size_t)t * 256 + c]; v1 += a.cm[(size_t)(t + 1) * 256 + c];
-            v2 += a.cm[(size_t)(t + 2) * 256 + c]; v3 += a.cm[(size_t)(t + 3) * 256 + c];
+            v0 += cmx(t, c); v1 += cmx(t + 1, c);
+            v2 += cmx(t + 2, c); v3 += cmx(t + 3, c);
         }
-        for (; t < s; t++) v0 += a.cm[(size_t)t * 256 + c];
+        for (; t < s; t++) v0 += cmx(t, c);
         a.cp[(size_t)s * 256 + c] = v0 + v1 + v2 + v3;
     }
 };
@@ -774,6 +1060,95 @@ struct FastPrefixSerial {  // whole block, thread per ctx: sixteen independent l
 };
 
 // ---- after the rounds: sources, repairs, exact predictor ---------------------------------------------
+// The repair passes run without the host in the loop: every kernel of a pass returns at once when an earlier pass found
+// nothing to repair (`done`), FastPassEnd closes a pass on the device, and the host reads this block once per group of
+// passes.
+struct FastCtl {
+    uint32_t chg;      // repairs of the running pass
+    uint32_t done;     // a pass ended with none
+    uint32_t total;    // repairs of all passes
+    uint32_t passes;   // passes that did work
+    uint32_t nmem;     // item starts when the last pass began (FastItemTotal)
+    uint32_t acc;
+    uint32_t lt;       // type of the item that ended at the block end (carried to the next block)
+    uint32_t pad;
+};
+struct FastCtlReset {
+    FastCtl* ctl;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid) return;
+        ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;
+    }
+};
+struct FastPassEnd {
+    FastCtl* ctl;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid || ctl->done) return;
+        ctl->total += ctl->chg;
+        ctl->passes++;
+        if (ctl->chg == 0) ctl->done = 1;
+        ctl->chg = 0;
+        ctl->nmem = ctl->acc;
+        ctl->acc = 0;
+    }
+};
+struct FastItemTotal {  // item starts of the block from the per-ctx ordinals (thread per ctx)
+    const uint32_t* cp;
+    uint32_t nsub;
+    FastCtl* ctl;
+    ORZ_HD void operator()(size_t c) const {
+        if (c >= 256 || ctl->done) return;
+        atom_add32(&ctl->acc, cp[(size_t)nsub * 256 + c] - cp[c]);
+    }
+};
+// Exact ring ordinals (Bucket.head arithmetic, src/matcher.rs:62-80) of the block's item starts without sorting them:
+// ORD = cp[subtile][ctx] + rank among the subtile's earlier item starts of the same ctx.  One wavefront per subtile,
+// lane = 64 positions: per-lane counts per ctx in LDS, an exclusive prefix down each ctx column, then every lane walks
+// its item starts again.  Rows are padded to 257 entries against bank conflicts.
+struct OrdWave {
+    const uint8_t* win;
+    const uint64_t* sbits;
+    const uint32_t* cp;
+    uint32_t n;
+    uint32_t* ORD;
+    const FastCtl* ctl;
+    static constexpr uint32_t kRow = 257;
+    static size_t lds_bytes() { return (size_t)64 * kRow * 2 + 64; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        if (ctl->done) return;
+        uint16_t* cnt = (uint16_t*)w.lds();
+        const uint32_t s = w.block(), lane = w.lane();
+        uint16_t* mine = cnt + (size_t)lane * kRow;
+        for (uint32_t c = 0; c < kRow; c++) mine[c] = 0;
+        const uint32_t i0 = s * kSub + lane * 64;
+        const uint64_t m0 = i0 < n ? sbits[i0 / 64] : 0;
+        const uint8_t* b = win + kPre + i0;
+        for (uint64_t m = m0; m;) {
+            const uint32_t t = (uint32_t)ctz64(m);
+            m &= m - 1;
+            if (i0 + t < n) mine[(uint32_t)(b[(int)t - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)t - 2]) << 7)]++;
+        }
+        w.sync();
+        for (uint32_t c = lane; c < 256; c += 64) {
+            uint32_t run = 0;
+            for (uint32_t r = 0; r < 64; r++) {
+                const uint32_t v = cnt[(size_t)r * kRow + c];
+                cnt[(size_t)r * kRow + c] = (uint16_t)run;
+                run += v;
+            }
+        }
+        w.sync();
+        for (uint64_t m = m0; m;) {
+            const uint32_t t = (uint32_t)ctz64(m);
+            m &= m - 1;
+            if (i0 + t >= n) break;
+            const uint32_t c = (uint32_t)(b[(int)t - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)t - 2]) << 7);
+            ORD[kPre + i0 + t] = cp[(size_t)s * 256 + c] + mine[c]++;
+        }
+    }
+};
+
 struct MemberFlags32 {
     const uint64_t* sbits;
     uint32_t n;
@@ -823,8 +1198,9 @@ struct FastSource {
     // the ordinals between it and the item grew past the ring (checked here with the fresh ordinals).
     const uint64_t* rdirty;
     uint32_t cap;  // item starts examined beyond the tabulated window before the search gives up (the item is cut then)
+    const FastCtl* ctl;
     ORZ_HD void operator()(size_t i) const {
-        if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
+        if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
         const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], K = a.K;
         const uint32_t op = a.ORD[p];
         if (rdirty) {
@@ -882,7 +1258,7 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
     uint32_t* cutend;
     uint64_t* rdirty;  // runs that gain an item start here (read by the next pass's FastSource)
     ORZ_HD void operator()(size_t i) const {
-        if (i >= a.n || !cutend[i]) return;
+        if (i >= a.n || !cutend[i]) return;  // (nothing is cut once the passes are done)
         const uint32_t end = cutend[i];
         cutend[i] = 0;
         uint32_t x = kPre + (uint32_t)i + a.nl[i];
@@ -925,8 +1301,9 @@ struct FastWordCheck {  // a WORD item whose prediction the exact state does not
     FastArgs a;
     const uint32_t* laste;
     uint64_t* rdirty;
+    const FastCtl* ctl;
     ORZ_HD void operator()(size_t i) const {
-        if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
+        if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
         const uint32_t p = kPre + (uint32_t)i;
         const uint32_t w = fast_word_at(a, laste, p);
         if (w == ((uint32_t)a.win[p] | ((uint32_t)a.win[p + 1] << 8))) return;
@@ -941,13 +1318,13 @@ struct FastWordCheck {  // a WORD item whose prediction the exact state does not
 struct FastCommit {  // per-position arrays the post stage reads (orz_stream.h)
     FastArgs a;
     const uint32_t* laste;
-    uint32_t lt0;  // type of the item that ended at the block start
+    const uint32_t* lt0p;  // type of the item that ended at the block start
     uint8_t *S, *TY, *ML, *W0;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n) return;
         const uint32_t p = kPre + (uint32_t)i;
         if (!((a.sbits[i / 64] >> (i & 63)) & 1)) { S[p] = 0; ML[p] = 0; return; }
-        const uint32_t t = a.ty[i], prev = i ? a.pt[i] : lt0;
+        const uint32_t t = a.ty[i], prev = i ? a.pt[i] : *lt0p;
         S[p] = 1;
         TY[p] = (uint8_t)(t | ((prev == kTyLit) << 2));
         ML[p] = t == kTyMatch ? a.nl[i] : 0;
@@ -976,9 +1353,18 @@ struct FastCtxCarry {
 };
 struct FastCpInit {
     const uint32_t* ctxcount;
-    uint32_t* cp;
+    uint32_t *cp, *tentry;
     ORZ_HD void operator()(size_t c) const {
         if (c < 256) cp[c] = ctxcount[c];
+        if (c == 0) tentry[0] = kPre;  // the path enters the first tile at the block start
+    }
+};
+struct FastLtCarry {  // the type of the item that ends at the block end goes to the next block (runs after FastCommit)
+    const uint8_t* pt;
+    uint32_t n;
+    FastCtl* ctl;
+    ORZ_HD void operator()(size_t tid) const {
+        if (!tid) ctl->lt = pt[n];
     }
 };
 

@@ -56,6 +56,14 @@ struct Flags32 {
         if (tid < n) f[tid] = S[kPre + tid];
     }
 };
+struct SumLast {  // out[0] = scan[last] + flag[last]: the total of an exclusive scan, so that the host reads one word
+    const uint32_t *scan, *flag;
+    uint32_t last;
+    uint32_t* out;
+    ORZ_HD void operator()(size_t tid) const {
+        if (!tid) out[0] = scan[last] + flag[last];
+    }
+};
 struct CompactPos32 {
     const uint32_t* flag;
     const uint32_t* scan;
@@ -264,13 +272,11 @@ class StreamEncoder {
                   uint32_t fast_tile = 131072, uint32_t fast_rounds = 4)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs), fast_(fast), ftile_(fast_tile), frounds_(fast_rounds) {
         if (fast_) {
-            if (ftile_ < kSub || ftile_ % kSub) throw std::runtime_error("fast tile must be a multiple of 4096");
+            if (ftile_ < kSub || ftile_ % kSub || ftile_ > kNewMax) throw std::runtime_error("fast tile must be a multiple of 4096 in [4096, 16777216]");
             if (frounds_ < 1 || frounds_ > 64) throw std::runtime_error("fast rounds must be in [1, 64]");
             // run predecessors tabulated per position: item starts are about a quarter of a run's positions on text and far
             // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
-            fK_ = 64;  // (deeper runs are searched through the bitmap + the text records: FastEval's far search)
-            if (const char* k = getenv("ORZ_FAST_K")) fK_ = (uint32_t)atoi(k);  // experiments
-            if (fK_ < 64 || fK_ > 192 || fK_ % 64) throw std::runtime_error("ORZ_FAST_K must be 64, 128 or 192");
+            fK_ = kFastK;  // (deeper runs are searched through the bitmap + the text records: FastFar)
             if (const char* u = getenv("ORZ_FAST_UNIT")) unit_ = (uint32_t)atoi(u);
             if (unit_ < (1u << 20) || unit_ > kNewMax || unit_ % kSub) throw std::runtime_error("ORZ_FAST_UNIT must be a multiple of 4096 in [1 MiB, 16 MiB]");
         }
@@ -288,17 +294,17 @@ class StreamEncoder {
             ML_ = take<uint8_t>(kWLen);
             ORD_ = take<uint32_t>(kWLen);
             LR_ = take<uint8_t>(kWLen);
-            SRC_ = take<uint32_t>(kWLen);
+            SRC_ = take<uint32_t>(kWLen, false);
             W0_ = take<uint8_t>(kWLen);
             TY_ = take<uint8_t>(kWLen);
             LENMIN_ = take<uint8_t>(kWLen);
             LMV_ = take<uint8_t>(kWLen);
-            idx_ = take<uint32_t>(kWLen);
-            kidx_ = take<uint32_t>(kWLen);
+            idx_ = take<uint32_t>(kWLen, false);
+            kidx_ = take<uint32_t>(kWLen, false);
             // sort buffers double as u64 scratch of the post stage (entA_/entB_ views)
-            entA_ = take<uint64_t>((size_t)kWLen);
-            entB_ = take<uint64_t>((size_t)kWLen);
-            epos_ = take<uint32_t>(kWLen);
+            entA_ = take<uint64_t>((size_t)kWLen, false);
+            entB_ = take<uint64_t>((size_t)kWLen, false);
+            epos_ = take<uint32_t>(kWLen, false);
             kpos_ = take<uint32_t>((size_t)kNewMax + 8);
             runstart_ = take<uint32_t>(kNumKeys + 1);
             krun_ = take<uint32_t>(32768 + 1);
@@ -318,17 +324,27 @@ class StreamEncoder {
                 partial_ = take<uint32_t>((size_t)2 * (wsegs_ / kRankChunk + 1) * 256);
             } else {
                 const size_t nn = (size_t)kNewMax + 512;
-                frows_ = take<uint8_t>((size_t)kNewMax * fK_ + 64);
+                frows_ = take<uint8_t>((size_t)kNewMax * fK_ + 64, false);
                 frlen_ = take<uint8_t>(nn);
-                fstext_ = take<uint64_t>((size_t)kWLen * 2);
+                fstext_ = take<uint64_t>((size_t)kWLen * 2, false);
                 fkw_ = take<uint16_t>(nn);
-                fev_ = take<uint32_t>(nn);
-                fbs_ = take<uint32_t>(nn);
+                fev_ = take<uint32_t>(nn, false);
                 fty_ = take<uint8_t>(nn);
                 fnl_ = take<uint8_t>(nn);
                 fpt_ = take<uint8_t>(nn);
-                fmf_ = take<uint8_t>(nn);
-                fef_ = take<uint8_t>(nn);
+                fmf_ = take<uint8_t>(nn / 8 + 64);
+                fef_ = take<uint8_t>(nn / 8 + 64);
+                fdirty_ = take<uint8_t>(nn);
+                frdist_ = take<uint64_t>(nn, false);
+                fwmask_ = take<uint64_t>(nn, false);
+                fkmeta_ = take<uint16_t>(nn);
+                fhz_ = take<uint32_t>((size_t)(kNSub + 2) * 256 * 4);
+                fhcm_ = take<uint32_t>((size_t)kHistSub * 256);
+                fhpre_ = take<uint32_t>((size_t)(kHistSub + 1) * 256);
+                fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256);
+                ffarlist_ = take<uint32_t>(nn, false);
+                fnfar_ = take<uint32_t>(4);
+                ffseen_ = take<uint8_t>(nn);
                 fx0_ = take<uint8_t>(nn);
                 fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
                 fx2_ = take<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
@@ -340,13 +356,13 @@ class StreamEncoder {
                 fcut_ = take<uint32_t>(nn);
                 frdirty_ = take<uint64_t>((size_t)2 * kDirtyWords);
                 flaste_ = take<uint32_t>(nn);
-                fnchg_ = take<uint32_t>(4);
+                fctl_ = take<FastCtl>(1);
                 fcstart_ = take<uint32_t>(260);
-                ffarv_ = take<uint32_t>(nn);
-                ffarsrc_ = take<uint32_t>(nn);
+                ffarv_ = take<uint32_t>(nn, false);
+                ffarsrc_ = take<uint32_t>(nn, false);
             }
-            f32_ = take<uint32_t>(kWLen);
-            sc32_ = take<uint32_t>(kWLen);
+            f32_ = take<uint32_t>(kWLen, false);
+            sc32_ = take<uint32_t>(kWLen, false);
             hpos_ = take<uint32_t>(kPre + 1);
             ctxcount_ = take<uint32_t>(256);
             tailkey_ = take<uint32_t>(4);
@@ -354,7 +370,7 @@ class StreamEncoder {
             wlast_ = take<uint32_t>(32768);
             // items and tail-stage buffers: two sets, taken by the blocks alternately (see post_stage)
             for (TailSet& t : ts_) {
-                t.ipos = take<uint32_t>((size_t)kNewMax + 1);
+                t.ipos = take<uint32_t>((size_t)kNewMax + 1, false);
                 t.isym = take<uint16_t>(kNewMax);
                 t.ictx = take<uint16_t>(kNewMax);
                 t.irank = take<uint16_t>(kNewMax);
@@ -364,10 +380,10 @@ class StreamEncoder {
                 t.iunl = take<uint8_t>(kNewMax);
                 t.ienc = take<uint8_t>(kNewMax);
                 t.ial = take<uint8_t>(kNewMax);
-                t.gsym = take<uint32_t>(kNewMax);
-                t.sperm = take<uint32_t>(kNewMax);
-                t.blen = take<uint32_t>(kNewMax);
-                t.bscan = take<uint32_t>(kNewMax);
+                t.gsym = take<uint32_t>(kNewMax, false);
+                t.sperm = take<uint32_t>(kNewMax, false);
+                t.blen = take<uint32_t>(kNewMax, false);
+                t.bscan = take<uint32_t>(kNewMax, false);
                 t.rstart = take<uint32_t>(520);
                 t.hw = take<uint32_t>((size_t)kMaxChunks * kHwStride);
                 t.hl = take<uint8_t>((size_t)kMaxChunks * kHwStride);
@@ -375,7 +391,7 @@ class StreamEncoder {
                 t.hscr = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
                 t.hdrbits = take<uint32_t>(kMaxChunks);
                 t.tot = take<uint32_t>(kMaxChunks);
-                t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords);
+                t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords, false);
             }
             counts_ = take<uint32_t>(kSyms + 3);
             order_ = take<uint16_t>(kSyms + 3);
@@ -411,6 +427,7 @@ class StreamEncoder {
         pend_order_.clear();
         cur_set_ = 0;
         lt_carry_ = kTyLit;
+        if (fast_) { const uint32_t lt = kTyLit; be_.h2d(&fctl_->lt, &lt, 4); }
         stream_start_ = true;
         stats = EncodeStats();
     }
@@ -444,11 +461,9 @@ class StreamEncoder {
         if (!stream_start_) {
             be_.launch(kPre, HistFlags32{S_, f32_});
             be_.exclusive_scan_u32(f32_, sc32_, kPre);
-            uint32_t a, b2;
-            be_.d2h(&a, sc32_ + (kPre - 1), 4);
-            be_.d2h(&b2, f32_ + (kPre - 1), 4);
-            nhist = a + b2;
+            be_.launch(1, SumLast{sc32_, f32_, kPre - 1, tailkey_ + 3});
             be_.launch(kPre, CompactPos32{f32_, sc32_, kPre, 0, hpos_});
+            be_.d2h(&nhist, tailkey_ + 3, 4);
         }
         // ---- candidate lists: stable radix sort of positions by (ctx8, hash) and by hash2
         const uint32_t nent = nhist + n;
@@ -466,10 +481,9 @@ class StreamEncoder {
         be_.memset(krunend_, 0, 32769 * 4);
         be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_, krunend_});
         if (fast_) {
-            be_.sync();
-            double tf = be_.now();
+            double tf = be_.now();  // (no sync here: the prep kernels are queued, the parse follows on the same stream)
             stats.t_prep += tf - t0;
-            fast_parse(n, len, nent, keysB);
+            fast_parse(n, len, nent, keysB, kkeysB);
             double t2f = be_.now();
             stats.t_parse += t2f - tf;
             post_stage(n, len, out, chunk_ends, t2f);
@@ -616,29 +630,45 @@ class StreamEncoder {
         post_stage(n, len, out, chunk_ends, t2);
     }
 
+    // exclusive prefix down the 256 columns of in[rows][256] -> out[rows + 1][256] (out[0] holds the base)
+    void col_scan(const uint32_t* in, uint32_t rows, uint32_t* out) {
+        const size_t groups = (rows + 63) / 64;
+        be_.launch(groups * 256, ColScanGroups{in, rows, fgsum_});
+        be_.launch(256, ColScanTop{fgsum_, rows, out});
+        be_.launch(groups * 256, ColScanRows{in, fgsum_, rows, out});
+    }
+
     // The GPU-native parse of one block (orz_fast.h): fills S_/TY_/ML_/SRC_/ORD_/W0_ for the new region and
     // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
-    void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys) {
+    void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys) {
         const uint8_t* win = dwin();
         const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
-        be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
         be_.launch(nent, FastSlotInit{epos_, slot_keys, runstart_, nent, vbits_, frlen_});
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
+        be_.launch(nk, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_});
+        // history item starts per (unified subtile, ctx) and their prefix: what the ring horizons reach back into
+        if (stream_start_) be_.memset(fhcm_, 0, (size_t)kHistSub * 256 * 4);
+        else be_.launch_waves(kHistSub, HistCountWave{win, S_, fhcm_}, HistCountWave::lds_bytes());
+        be_.memset(fhpre_, 0, 256 * 4);
+        col_scan(fhcm_, kHistSub, fhpre_);
         uint64_t* stext = fstext_;
         be_.launch(nent, FastText{win, epos_, nent, stext});
         be_.timed_begin(2);
-        be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_}, FastRowsWave::lds_bytes(K));
+        be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_, frdist_}, FastRowsWave::lds_bytes(K));
         be_.timed_end(2);
         FastArgs a;
         a.win = win; a.len = len; a.n = n; a.K = K; a.depth = (uint32_t)cfg_.depth; a.lazy1 = (uint32_t)cfg_.lazy1;
-        a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_;
+        a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_; a.dmax = dmax_; a.nent = nent; a.nk = nk;
         a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
+        a.rdist = frdist_; a.wmask = fwmask_; a.kmeta = fkmeta_; a.hpre = fhpre_;
         a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
-        a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_; a.bs = fbs_;
-        a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mf = fmf_; a.ef = fef_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
-        a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = fnchg_;
+        a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_;
+        a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
+        a.farlist = ffarlist_; a.nfar = fnfar_; a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
+        a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
         // anyway), and a block whose parse turns out unstable -- many items lost their source -- is redone with tiles
         // a quarter the size (match-dense, highly repetitive data; never seen on text).
@@ -651,7 +681,7 @@ class StreamEncoder {
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it takes tiles twice the size -- half the steps, ~+0.1 % on that block's output.
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 2;
-            if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = lead_mul * ftile_;
+            if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
         }
         for (;;) {
             a.tile = T;
@@ -660,22 +690,30 @@ class StreamEncoder {
             be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
             be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             const size_t nn = (size_t)n + 264;
-            be_.memset(fev_, 0, ((size_t)n + 8) * 4);
-            be_.memset(ffarv_, 0, ((size_t)n + 8) * 4);
+            // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
             be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
-            be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
+            be_.memset(fmf_, 0, nn / 8 + 8); be_.memset(fef_, 0, nn / 8 + 8);
             be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
-            be_.launch(256, FastCpInit{ctxcount_, fcp_});
-            { uint32_t e0 = kPre; be_.h2d(ftentry_, &e0, 4); }
+            be_.memset(fnfar_, 0, 4);
+            be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
+            const uint32_t far_threads = std::max<uint32_t>(256, T / 2);
+            // ring horizons of the first tile (no counts yet: the history alone)
+            be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt});
+            be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
             const bool replayed = use_graph && be_.graph_replay(gkey);
-            if (use_graph && !replayed) be_.graph_capture_begin();
+            struct CaptureGuard {  // a launch that throws inside the capture must not leave the stream capturing
+                BE& be;
+                bool on;
+                ~CaptureGuard() { if (on) be.graph_capture_abort(); }
+            } capture{be_, use_graph && !replayed};
+            if (capture.on) be_.graph_capture_begin();
             if (replayed) stats.sweeps += ntile + R - 1;
             for (uint32_t step = 1; step <= ntile + R - 1 && !replayed; step++) {
                 const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
@@ -688,7 +726,11 @@ class StreamEncoder {
                 static const int far_sched = getenv("ORZ_FAST_FARSCHED") ? atoi(getenv("ORZ_FAST_FARSCHED")) : 3;  // bit 0: last round, bit 1: second round
                 if ((far_sched & 1) && step >= R && step - R < ntile) { fa0 = kPre + (step - R) * T; fa1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fa0 + T); }
                 if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, fa0, fa1, fb0, fb1});
+                // the newest active tile is in its first round while tiles are still being started; the two positions behind
+                // the range (the lazy rules look ahead) have never been evaluated either
+                const uint32_t r1lo = step <= ntile ? kPre + t_hi * T : hi;
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, fa0, fa1, fb0, fb1});
+                if (a.far && (fa1 > fa0 || fb1 > fb0)) be_.launch(far_threads, FastFar{a, far_threads});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -698,68 +740,59 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1});
-                be_.launch((size_t)nc * 256, FastPrefix{a, c0, c0 + nc});
+                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, hi});
+                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
+                const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
+                be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
+                be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
                 stats.sweeps++;
             }
+            capture.on = false;
             if (use_graph && !replayed) be_.graph_capture_end(gkey);
-            // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes
-            uint32_t* ckeys = (uint32_t*)entA_;
-            uint32_t* ckeys2 = ckeys + kWLen;
-            uint32_t* cvals = (uint32_t*)entB_;
-            uint32_t* fipos = cvals + kWLen;
-            bool done = false;
+            // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes.  The passes are launched in
+            // groups without the host in between: a pass that finds nothing to repair sets `done` on the device and the
+            // kernels of later passes return at once; the control block is read once per group.
             const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (tests, experiments: every pass walks for every match)
             static const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 256;  // (0 = no limit)
-            uint64_t total_repairs = 0;
-            uint32_t nmem_last = 0;
-            for (int pass = 0; pass < 200 && !done; pass++) {
-                be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
-                be_.launch(n, MemberFlags32{fsbits_, n, f32_});
-                be_.exclusive_scan_u32(f32_, sc32_, n);
-                uint32_t x0, x1;
-                be_.d2h(&x0, sc32_ + (n - 1), 4);
-                be_.d2h(&x1, f32_ + (n - 1), 4);
-                const uint32_t nmem = x0 + x1;
-                be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, fipos});
-                be_.launch(nmem, CtxKeys{win, fipos, nmem, ckeys});
-                be_.sort_pairs_u32(ckeys, ckeys2, fipos, cvals, nmem, 8);
-                be_.launch(257, CtxStarts{ckeys2, nmem, fcstart_});
-                be_.launch(nmem, OrdAssign{ckeys2, cvals, fcstart_, ctxcount_, nmem, ORD_});
-                be_.memset(fnchg_, 0, 4);
-                // the first pass walks for every match; later ones only where the previous pass added item starts
-                uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
-                uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
-                be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
-                be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap});
-                be_.launch(n, FastRecut{a, fcut_, rd_out});
-                be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u});
-                be_.launch(nk, KbitVals{kbits_, nk, f32_});
-                be_.inclusive_max_scan_u32(f32_, flaste_, nk);
-                be_.launch(n, FastWordCheck{a, flaste_, rd_out});
-                uint32_t chg = 0;
-                be_.d2h(&chg, fnchg_, 4);
-                stats.seg_evals += chg;  // (fast mode: repairs made)
-                total_repairs += chg;
-                nmem_last = nmem;
-                done = chg == 0;
+            FastCtl h{};
+            be_.launch(1, FastCtlReset{fctl_});
+            int pass = 0;
+            for (int group = 0; group < 64 && !h.done; group++) {
+                const int todo = group == 0 ? 5 : 2;  // (text converges in ~6 passes)
+                for (int k = 0; k < todo; k++, pass++) {
+                    be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u, 0});
+                    // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
+                    be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
+                    col_scan(fcm_, nsub, fcp_);
+                    be_.launch(256, FastItemTotal{fcp_, nsub, fctl_});
+                    be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
+                    // the first pass walks for every match; later ones only where the previous pass added item starts
+                    uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
+                    uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
+                    be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
+                    be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_});
+                    be_.launch(n, FastRecut{a, fcut_, rd_out});
+                    be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u, 0});
+                    be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                    be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                    be_.launch(n, FastWordCheck{a, flaste_, rd_out, fctl_});
+                    be_.launch(1, FastPassEnd{fctl_});
+                }
+                be_.d2h(&h, fctl_, sizeof h);
             }
-            if (!done) throw std::runtime_error("fast parse: repairs did not converge");
+            if (!h.done) throw std::runtime_error("fast parse: repairs did not converge");
+            stats.seg_evals += h.total;  // (fast mode: repairs made)
             // unstable = more than 0.5 % of the items repaired AND more than one repair per 2000 input bytes (sparse item
             // streams -- long zero runs -- reach the first mark with a handful of repairs that cost nothing)
-            if (T <= kSub || total_repairs * 200 < (uint64_t)nmem_last || total_repairs * 2000 < (uint64_t)n) break;
+            if (T <= kSub || (uint64_t)h.total * 200 < (uint64_t)h.nmem || (uint64_t)h.total * 2000 < (uint64_t)n) break;
             T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
-            stats.seg_evals -= total_repairs;  // (count the repairs of the parse that is kept)
+            stats.seg_evals -= h.total;  // (count the repairs of the parse that is kept)
         }
-        // ---- hand over to the post stage; carry the model state
-        be_.launch(n, FastCommit{a, flaste_, (uint32_t)lt_carry_, S_, TY_, ML_, W0_});
+        // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
+        be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
+        be_.launch(1, FastLtCarry{fpt_, n, fctl_});
         be_.launch(32768, FastWordsCarry{a, flaste_, krunend_, wsnap_});
-        be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
-        be_.launch(256, FastPrefixSerial{a, 0, nsub});
         be_.launch(256, FastCtxCarry{fcp_, nsub, ctxcount_});
-        uint8_t last_ty = kTyLit;
-        be_.d2h(&last_ty, fpt_ + n, 1);
-        lt_carry_ = last_ty;
     }
 
     // Second half of a block: items -> len_min -> symbols -> symrank -> Huffman -> bit pack (shared by both parse modes).
@@ -779,11 +812,10 @@ class StreamEncoder {
         // ---- items
         be_.launch(n, Flags32{S_, n, f32_});
         be_.exclusive_scan_u32(f32_, sc32_, n);
-        uint32_t a, b2;
-        be_.d2h(&a, sc32_ + (n - 1), 4);
-        be_.d2h(&b2, f32_ + (n - 1), 4);
-        const uint32_t nitems = a + b2;
+        uint32_t nitems = 0;
+        be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
         be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
+        be_.d2h(&nitems, tailkey_ + 3, 4);
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
         const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
@@ -957,9 +989,12 @@ class StreamEncoder {
     ItemTrace* trace = nullptr;  // when set, every block appends its items
 
    private:
+    // device allocation owned by this encoder (freed by release_all, also when the constructor throws); `zero` = false for
+    // the large tables that are always written before they are read (a stream's state is ~5 GB: filling all of it costs
+    // more than encoding a small input)
     template <class T>
-    T* take(size_t n) {  // device allocation owned by this encoder (freed by release_all, also when the constructor throws)
-        T* p = be_.template alloc<T>(n);
+    T* take(size_t n, bool zero = true) {
+        T* p = be_.template alloc<T>(n, zero);
         owned_.push_back(p);
         return p;
     }
@@ -975,11 +1010,14 @@ class StreamEncoder {
     uint32_t ftile_ = 131072, frounds_ = 4, fK_ = 64;
     bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
-            *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr;
-    uint16_t* fkw_ = nullptr;
-    uint32_t *fev_ = nullptr, *fbs_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
-             *flaste_ = nullptr, *fnchg_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
+            *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr, *ffseen_ = nullptr;
+    uint16_t *fkw_ = nullptr, *fkmeta_ = nullptr;
+    uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
+    uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr, *ffarlist_ = nullptr, *fnfar_ = nullptr;
+    uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
+             *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr;
+    FastCtl* fctl_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
     // buffers of the item stage and the tail stage, two sets (block parity)

@@ -37,7 +37,10 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
     dist.all_gather(all_sizes, sizes)
     # one payload held in the library's own buffer (api.OrzBuffer: bench.py's case, one member per rank) is sent from
     # where it lies; several members, or plain bytes, are joined first
-    if len(mine) == 1 and hasattr(local[mine[0]], "view"):
+    from .api import OrzBuffer
+
+    single_buf = len(mine) == 1 and isinstance(local[mine[0]], OrzBuffer)
+    if single_buf:
         blob = local[mine[0]]
         flat = torch.frombuffer(blob.view(), dtype=torch.uint8) if len(blob) else None
     else:
@@ -47,22 +50,29 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
         if flat is not None:
             dist.send(flat.to(dev), dst=0)
         return None
+    # rank 0: post the receives of ALL peers first, then wait -- every peer has its own link to the root, so the
+    # transfers overlap instead of running in rank order
+    bufs, reqs = {}, []
+    for r in range(1, world):
+        total = int(all_sizes[r].sum())
+        if total:
+            bufs[r] = torch.empty(total, dtype=torch.uint8, device=dev)
+            reqs.append(dist.irecv(bufs[r], src=r))
+    for q in reqs:
+        q.wait()
     out = [None] * n_members
     for r in range(world):
-        total = int(all_sizes[r].sum())
+        ms = members_of_rank(n_members, r, world)
         if r == 0:
-            raw = blob
-        elif total:
-            buf = torch.empty(total, dtype=torch.uint8, device=dev)
-            dist.recv(buf, src=r)
-            raw = buf.cpu().numpy().tobytes() if to_host else buf
+            raw = bytes(blob) if (to_host or not single_buf) else blob  # to_host: always plain bytes
+        elif r in bufs:
+            raw = bufs[r].cpu().numpy().tobytes() if to_host else bufs[r]
         else:
             raw = b""
-        at = 0
-        ms = members_of_rank(n_members, r, world)
-        if len(ms) == 1 and hasattr(raw, "view"):  # a single payload in a buffer object (rank 0's own, or a received tensor): as it is
+        if len(ms) == 1 and not isinstance(raw, (bytes, bytearray)):  # a single payload left where it is (to_host=False)
             out[ms[0]] = raw
             continue
+        at = 0
         for i, m in enumerate(ms):
             ln = int(all_sizes[r][i])
             out[m] = raw[at:at + ln]

@@ -18,7 +18,7 @@ namespace {
 struct EmuBackend {
     int order = 1;  // simt::Order for wave kernels
     uint64_t seed = 1;
-    template <class T> T* alloc(size_t n) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
+    template <class T> T* alloc(size_t n, bool = true) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
     void free(void* p) { std::free(p); }
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
@@ -38,6 +38,7 @@ struct EmuBackend {
     bool graph_replay(uint64_t) { return false; }
     void graph_capture_begin() {}
     void graph_capture_end(uint64_t) {}
+    void graph_capture_abort() {}
     void timed_begin(int = 0) {}
     void timed_end(int = 0) {}
     void set_timing(bool) {}
@@ -172,6 +173,9 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
             stats5[0] = enc.stats.blocks; stats5[1] = enc.stats.sweeps; stats5[2] = enc.stats.seg_evals;
             stats5[3] = enc.stats.items; stats5[4] = enc.stats.chunks;
         }
+        if (std::getenv("ORZ_EVAL_STATS"))
+            std::fprintf(stderr, "eval: %llu positions visited, %llu evaluated (first round %llu, dirty %llu, far due %llu), %llu settled the ring end with positions; verify: %llu skipped would differ (%llu in lwm)\n", orz::g_eval_stats[0],
+                         orz::g_eval_stats[1], orz::g_eval_stats[2], orz::g_eval_stats[3], orz::g_eval_stats[4], orz::g_eval_stats[5], orz::g_eval_stats[6], orz::g_eval_stats[7]);
         if (std::getenv("ORZ_FAR_STATS"))
             std::fprintf(stderr, "far search: %llu evaluations, %llu far searches, %llu bitmap words, %llu members examined\n",
                          orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2], orz::g_far_stats[3]);

@@ -96,13 +96,17 @@ def test_parse_kernel_keeps_three_waves_per_simd():
 
 
 def test_bench_traffic_artefact_is_committed():
-    """bench.py reports `roofline.traffic` from the committed PMC summary of this round (tools/profile_round.sh): the file
-    it names must exist and hold the per-launch bytes of the kernels the roofline rows are about"""
+    """bench.py reports `roofline.traffic` from the newest committed PMC summary (tools/profile_round.sh) and labels it
+    `from_profile: <file>`: the file must exist and hold the per-launch bytes of the kernels the roofline rows are about"""
+    import importlib.util
     import json
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "bench.py")).read()
-    names = re.findall(r'"(r\d+\w*_pmc_hbm_traffic_\w+\.json)"', src)
-    assert len(names) == 1, names
-    data = json.load(open(os.path.join(root, "profiles", names[0])))
-    assert data["by_name"]["orz_symrank_kernel"] > 0 and data["by_name"]["orz_thread_kernel<FastEval>"] > 0
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    name, by_name = bench.newest_pmc_profile()
+    assert name and name.startswith("profiles/") and os.path.exists(os.path.join(root, name))
+    data = json.load(open(os.path.join(root, name)))
+    assert data["by_name"] == by_name
+    assert by_name["orz_symrank_kernel"] > 0 and by_name["orz_thread_kernel<FastEval>"] > 0
