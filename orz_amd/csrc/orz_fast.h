@@ -75,6 +75,7 @@ struct FastArgs {
     uint32_t* hz;               // [kNSub][256][4] ring horizons per (subtile, ctx): oldest window offset still within 4094 / 510 item starts,
                                 // and the two values one step earlier (what the evaluations of the previous step saw)
     uint32_t *farlist, *nfar;   // positions of this step that need the far search (FastEval appends, FastFar consumes)
+    uint32_t *marklist, *nmark; // slots flipped in this step (| 1 << 31: word-update bitmap): FastFlip appends, FastMark consumes
     uint8_t* fseen;             // [n+8] item starts FastEval saw in the tabulated window of a listed position
     uint8_t *x0, *x1, *x2;      // path maps: per position, per (chunk, entry), per (tile, entry)
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
@@ -116,6 +117,13 @@ ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
 #endif
 }
 
+ORZ_D int popc64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll((unsigned long long)v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
 ORZ_D uint32_t clz32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__clz((int)v);
@@ -208,23 +216,34 @@ struct FastKw {
 // words[] update among the earlier positions of its hash2 run.  Which positions update is decided by the parse (kbits);
 // whether a given one would predict p's bytes is not -- tabulated here once per block for the 64 list slots below p, so
 // that a round needs the bitmap window only.
-struct FastWordMasks {  // thread per word-list slot
+struct FastWordMasks {  // one wavefront per 64 word-list slots, the two bytes of the 64 + 64 slots involved staged in LDS
     const uint32_t *kpos, *kkeys, *krun;
     const uint16_t* kw;
     const uint8_t* wsnap;
     uint32_t nk;
     uint64_t* wmask;
     uint16_t* kmeta;
-    ORZ_HD void operator()(size_t s) const {
+    static size_t lds_bytes() { return 128 * 2; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint16_t* kwL = (uint16_t*)w.lds();
+        const uint32_t lane = w.lane();
+        const int64_t base = (int64_t)w.block() * 64 - 64;  // slot of LDS entry 0
+        for (uint32_t e = lane; e < 128; e += 64) {
+            const int64_t s = base + e;
+            kwL[e] = s >= 0 && s < (int64_t)nk ? kw[s] : 0;
+        }
+        w.sync();
+        const uint32_t s = w.block() * 64 + lane;
         if (s >= nk) return;
         const uint32_t u = kpos[s];
         if (u < kPre) return;  // (the list starts one position before the block)
-        const uint32_t key = kkeys[s], rk = fast_min(64u, (uint32_t)s - krun[key]);
-        const uint32_t w = kw[s];
+        const uint32_t key = kkeys[s], rk = fast_min(64u, s - krun[key]);
+        const uint32_t me = 64 + lane, wv = kwL[me];
         uint64_t m = 0;
-        for (uint32_t t = 0; t < rk; t++) m |= (uint64_t)(kw[s - 1 - t] == w) << (63 - t);
+        for (uint32_t t = 0; t < rk; t++) m |= (uint64_t)(kwL[me - 1 - t] == wv) << (63 - t);
         const uint32_t excl = rk && kpos[s - 1] == u - 1;  // the slot right below is u = p-1: its update comes too late
-        const uint32_t snap = ((uint32_t)wsnap[key * 2] | ((uint32_t)wsnap[key * 2 + 1] << 8)) == w;
+        const uint32_t snap = ((uint32_t)wsnap[key * 2] | ((uint32_t)wsnap[key * 2 + 1] << 8)) == wv;
         wmask[u - kPre] = m;
         kmeta[u - kPre] = (uint16_t)(rk | (excl << 7) | (snap << 8));
     }
@@ -321,14 +340,13 @@ struct FastRowsWave {
     uint8_t* rows;
     uint64_t* rdist;   // [n] distance codes of the sampled predecessors (dist_valid)
     static constexpr uint32_t kOutStride = 72;  // bytes per lane in the staging tile (64 + pad against bank conflicts)
-    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride + 64; }
+    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint64_t* t0 = (uint64_t*)w.lds();            // [64+K] bytes 0..7
         uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..15
         uint32_t* ps = (uint32_t*)(t1 + (64 + K));    // [64+K] positions
         uint8_t* outL = (uint8_t*)(ps + (64 + K));    // [64][kOutStride]
-        uint8_t* rL = outL + 64 * kOutStride;         // [64] tabulated depth of each row
         const uint32_t lane = w.lane();
         const int64_t base = (int64_t)w.block() * 64 - K;  // slot of LDS entry 0
         for (uint32_t e = lane; e < 64 + K; e += 64) {
@@ -343,7 +361,6 @@ struct FastRowsWave {
         const uint32_t p = ps[me];
         const bool mine = (int64_t)w.block() * 64 + lane < (int64_t)nent && p >= kPre;
         const uint32_t r = mine ? fast_min(K, rlen[p - kPre]) : 0;
-        rL[lane] = (uint8_t)r;
         const uint64_t a0 = t0[me], a1 = t1[me];
         if (mine) {  // how far back the sampled predecessors lie (a sample beyond the run's depth stands for its oldest member)
             uint64_t codes = 0;
@@ -377,8 +394,7 @@ struct FastRowsWave {
             for (uint32_t it = 0; it < 4; it++) {  // 16 rows per pass, four lanes per 64-byte piece
                 const uint32_t row = it * 16 + (lane >> 2), part = lane & 3;
                 const uint32_t pr = ps[K + row];
-                // (a row is read up to its run depth only: the 16-byte pieces beyond it are not written)
-                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre && c0 + part * 16 < rL[row]) {
+                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {  // (whole 64-byte lines: pieces of a line cost a read-modify-write)
                     const uint64_t v0 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16);
                     const uint64_t v1 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16 + 8);
                     uint64_t* dst = reinterpret_cast<uint64_t*>(rows + (size_t)(pr - kPre) * K + c0 + part * 16);
@@ -457,6 +473,7 @@ struct FastEval {
     uint32_t fa0, fa1, fb0, fb1;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
+        if (tid == 0) *a.nmark = 0;  // (FastMark has consumed the previous step's flips)
         if (p >= hi) return;
         const uint8_t* win = a.win;
         const uint32_t i = p - kPre;
@@ -466,27 +483,48 @@ struct FastEval {
         const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
-        const uint32_t h4 = hz[0], h5 = hz[1];
+        const uint32_t h4 = hz[0], h4was = hz[2];
+        const bool need = first || dirty || (fardue && rl > kFastK && a.far);
+#if !defined(__HIPCC__)
+        g_eval_stats[0]++;
+        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (fardue && rl > kFastK) g_eval_stats[4]++;
+#endif
+        if (!need && h4was == h4) return;
         const uint64_t codes = a.rdist[i];
         const DistBracket d4 = dist_valid(codes, p > h4 ? p - h4 : 0);
         // the ring horizon of (subtile, ctx) moved since the previous step: re-evaluate where that changes which of the
         // window's predecessors count (every active position looks every step, so one step of history is enough)
         bool moved = false;
-        if (!first && hz[2] != h4) {
-            const DistBracket o4 = dist_valid(codes, p > hz[2] ? p - hz[2] : 0);
+        if (!first && h4was != h4) {
+            const DistBracket o4 = dist_valid(codes, p > h4was ? p - h4was : 0);
             moved = o4.sure != d4.sure || o4.limit != d4.limit || d4.sure < fast_min(fast_min(kFastK, rl), d4.limit);
         }
-#if !defined(__HIPCC__)
-        g_eval_stats[0]++;
-        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (fardue && rl > kFastK) g_eval_stats[4]++;
-#endif
-        if (!first && !dirty && !moved && !(fardue && rl > kFastK && a.far)) return;
+        if (!need && !moved) return;
 #if !defined(__HIPCC__)
         g_eval_stats[1]++;
 #endif
+        // ---- everything the evaluation reads, asked for up front: position-ordered statics, then the two bitmap windows
+        const uint32_t j = a.idx[p], kj = a.kidx[p], r = fast_min(kFastK, rl);
+        const uint32_t km = a.kmeta[i], rk = km & 0x7f;
+        const uint64_t wm = a.wmask[i];
+        const uint32_t h5 = hz[1];
+        uint32_t rw[16];  // the row of common prefixes, in registers (only the 16-byte pieces the run depth reaches)
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a.rows + (size_t)i * kFastK);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                if (r > q * 16) {
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) rw[q * 4 + d] = src[q * 4 + d];
+                } else {
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) rw[q * 4 + d] = 0;
+                }
+            }
+        }
+        uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
+        uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)kj - 64) : 0;
         if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
-        const uint32_t j = a.idx[p], r = fast_min(kFastK, rl);
-        const uint8_t* row = a.rows + (size_t)i * kFastK;
         // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts
         const DistBracket d5 = dist_valid(codes, p > h5 ? p - h5 : 0);
         uint32_t v4 = d4.sure;
@@ -500,22 +538,24 @@ struct FastEval {
             v4 += extra;
         }
         if (a.dbg & 2) v4 = 64;
-        uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
         const uint32_t span = fast_min(r, v4);
         if (span < 64) mask = span ? mask & (~0ull << (64 - span)) : 0;
+        // the candidates, newest first, straight from the registers: no load in this loop
         uint32_t best = 0, bk = 0, m1 = 0, m2 = 0, seen = 0;
-        bool stop = v4 < r;  // the ring ends inside the window: nothing older counts either
-        while (mask && seen < a.depth) {
-            const uint32_t t = 63 - (uint32_t)clz64(mask);
-            mask &= ~(1ull << t);
-            const uint32_t k = 63 - t;
-            const uint32_t l = row[k];
-            if (l > best) { best = l; bk = k; }
-            if (seen < a.lazy1 && l > m1) m1 = l;
-            if (seen < a.lazy2 && l > m2) m2 = l;
-            seen++;
-            if (l == kMaxLen) { stop = true; break; }
+        bool full = false;  // a candidate matched all 240 bytes: nothing older is looked at
+#pragma unroll
+        for (uint32_t k = 0; k < 64; k++) {
+            if ((k & 15) == 0 && !(mask & (~0ull >> k))) break;  // no item start left in the window
+            const uint32_t l = (rw[k >> 2] >> (8 * (k & 3))) & 0xff;
+            if (((mask >> (63 - k)) & 1) && !full && seen < a.depth) {
+                if (l > best) { best = l; bk = k; }
+                if (seen < a.lazy1 && l > m1) m1 = l;
+                if (seen < a.lazy2 && l > m2) m2 = l;
+                seen++;
+                full = l == kMaxLen;
+            }
         }
+        const bool stop = full || v4 < r;  // (the ring ends inside the window: nothing older counts either)
         uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
         if (first) a.farv[i] = 0;  // nothing remembered yet
         if (!stop && seen < a.depth && rl > kFastK && a.far) {
@@ -532,11 +572,9 @@ struct FastEval {
             }
         }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
-        const uint32_t km = a.kmeta[i], rk = km & 0x7f;
-        uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)a.kidx[p] - 64) : 0;
         if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
         if (km & 0x80) kmask &= ~(1ull << 63);
-        const uint32_t lwm = kmask ? (uint32_t)((a.wmask[i] >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
+        const uint32_t lwm = kmask ? (uint32_t)((wm >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
 #if !defined(__HIPCC__)
         if ((a.dbg & 32) && !first && !a.dirty[i] && !moved && !(fardue && rl > kFastK && a.far)) {  // verify mode: would a skipped position have changed?
             const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
@@ -622,6 +660,112 @@ struct FastFar {
             if (fm1 > m1) m1 = fm1;
             if (fm2 > m2) m2 = fm2;
             a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
+        }
+    }
+};
+// The same far search, sixteen lanes per listed position (four positions per wavefront): a trip looks at sixteen words
+// of the bitmap at once (one coalesced load), the up to sixteen item starts found are examined side by side -- text
+// record, window bytes beyond it, ring position, all independent loads -- and then resolved in order by every lane of
+// the group (the serial rules of FastFar, unchanged: same answers).  The thread-per-position form lasts as long as its
+// longest chain of dependent loads (~90 us a launch); this one a few microseconds a trip.
+struct FastFarWave {
+    FastArgs a;
+    uint32_t nwaves;
+    static size_t lds_bytes() { return 64 * (8 + 4 + 4 + 4); }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint64_t* mL = (uint64_t*)w.lds();
+        uint32_t* lenL = (uint32_t*)(mL + 64);
+        uint32_t* qL = lenL + 64;
+        uint32_t* sL = qL + 64;
+        const uint8_t* win = a.win;
+        const uint32_t lane = w.lane(), g = lane >> 4, sl = lane & 15, gb = g * 16;
+        const uint32_t nf = *a.nfar;
+        for (uint32_t base = w.block() * 4; base < nf; base += nwaves * 4) {
+            const bool act = base + g < nf;
+            uint32_t i = 0, p = 0, h4 = 0, h5 = 0, e0 = 0, seen = 0, lo2 = 0, cur_top = 0;
+            uint64_t a0 = 0, a1 = 0;
+            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
+            if (act) {
+                i = a.farlist[base + g]; p = kPre + i;
+                const uint32_t j = a.idx[p], c = hash1(win, p - 1);
+                const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
+                h4 = hz[0]; h5 = hz[1];
+                e0 = a.ev[i];
+                seen = a.fseen[i];
+                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
+                cur_top = j - kFastK;  // slots [lo2, cur_top) are searched, newest first
+                lo2 = cur_top - rs > a.far ? cur_top - a.far : rs;
+                a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
+            }
+            bool need = act && cur_top > lo2 && seen < a.depth;
+            while (w.ballot(need)) {
+                // ---- sixteen words of the bitmap, the newest in lane 0 of the group
+                const uint32_t wtop = need ? (cur_top - 1) >> 6 : 0, wlo = lo2 >> 6;
+                uint64_t m = 0;
+                if (need && wtop >= sl && wtop - sl >= wlo) {
+                    const uint32_t wi = wtop - sl;
+                    m = a.vbits[wi];
+                    if (wi == wtop && (cur_top & 63)) m &= (1ull << (cur_top & 63)) - 1;
+                    if (wi == wlo) m &= ~0ull << (lo2 & 63);
+                }
+                mL[lane] = m;
+                w.sync();
+                uint32_t tot = 0;
+                for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
+                const uint32_t want = need ? fast_min(fast_min(tot, 16u), a.depth - seen) : 0;
+                // ---- member number sl of the trip: its slot, its common prefix with p, its position
+                uint32_t l = 0, q = 0, s2 = 0;
+                if (sl < want) {
+                    uint32_t run = 0;
+                    for (uint32_t t = 0; t < 16; t++) {
+                        uint64_t mm = mL[gb + t];
+                        const uint32_t cnt = (uint32_t)popc64(mm);
+                        if (sl < run + cnt) {
+                            for (uint32_t n = sl - run; n; n--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
+                            s2 = (wtop - t) * 64 + 63 - (uint32_t)clz64(mm);
+                            break;
+                        }
+                        run += cnt;
+                    }
+                    const uint64_t x0 = a.stext[2 * (size_t)s2] ^ a0, x1 = a.stext[2 * (size_t)s2 + 1] ^ a1;
+                    q = a.epos[s2];
+                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
+                    else if (x1) l = 8 + ((uint32_t)ctz64(x1) >> 3);
+                    else l = 16 + lcp240u(win + q + 16, win + p + 16, kMaxLen - 16);
+                }
+                lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
+                w.sync();
+                // ---- resolved in order by every lane of the group (src/matcher.rs:135-192 on these candidates)
+                if (need) {
+                    bool fin = false;
+                    for (uint32_t k = 0; k < want; k++) {
+                        const uint32_t ll = lenL[gb + k], qq = qL[gb + k];
+                        if (ll > fbest || (seen < a.lazy1 && ll > fm1) || (seen < a.lazy2 && ll > fm2)) {
+                            if (qq < h4) { fin = true; break; }  // left the ring: so did everything older
+                            if (ll > fbest) { fbest = ll; fsrc = qq; f510 = qq >= h5; }
+                            if (seen < a.lazy1 && ll > fm1) fm1 = ll;
+                            if (seen < a.lazy2 && ll > fm2) fm2 = ll;
+                        }
+                        seen++;
+                        if (ll == kMaxLen || seen >= a.depth) { fin = true; break; }
+                    }
+                    if (fin) need = false;
+                    else if (tot > 16) cur_top = sL[gb + 15];          // more item starts in these words: go on below the sixteenth
+                    else cur_top = wtop >= 16 ? (wtop - 15) * 64 : 0;  // these words are done
+                    if (cur_top <= lo2) need = false;
+                }
+                w.sync();
+            }
+            if (act && sl == 0) {
+                uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
+                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+                a.farsrc[i] = fsrc;
+                if (fbest > best) { best = fbest; b510 = f510; }
+                if (fm1 > m1) m1 = fm1;
+                if (fm2 > m2) m2 = fm2;
+                a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
+            }
         }
     }
 };
@@ -919,37 +1063,13 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// Bring the slot-order bitmaps in line with the path (thread per 8 positions), and mark the positions whose next
-// evaluation would see the difference: a flipped item start matters to the later positions of its run for which it is
-// among the newest `dmax` item starts below them -- walk up the run (slots ascend with the position) until that many
-// set bits have been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped
-// word update matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks:
-// whichever state a walk observes, the union of the marks contains every position whose answer can have changed.
+// Bring the slot-order bitmaps in line with the path (thread per 8 positions).  Every flipped slot is appended to a list;
+// FastMark then marks the positions whose next evaluation would see the difference.
 struct FastFlip {
     FastArgs a;
     uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
-    uint32_t mark_hi;    // positions below this one are marked dirty (0 = no marking: the repair passes)
-    ORZ_D void mark_candidates(uint32_t j, uint32_t y) const {
-        uint32_t passed = 0;
-        const uint32_t end = fast_min(a.nent, j + 1 + kFastK);
-        for (uint32_t s = j + 1; s < end; s++) {
-            const uint32_t q = a.epos[s];
-            if (q <= y || q >= mark_hi) break;  // another run / beyond the active range (evaluated in full when its tile starts)
-            a.dirty[q - kPre] = 1;
-            if ((a.vbits[s >> 6] >> (s & 63)) & 1)
-                if (++passed >= a.dmax) break;
-        }
-    }
-    ORZ_D void mark_words(uint32_t ku, uint32_t u) const {
-        const uint32_t end = fast_min(a.nk, ku + 1 + 64);
-        for (uint32_t s = ku + 1; s < end; s++) {
-            const uint32_t q = a.kpos[s];
-            if (q <= u || q >= mark_hi) break;
-            if (q >= kPre) a.dirty[q - kPre] = 1;
-            if ((a.kbits[s >> 6] >> (s & 63)) & 1) break;  // positions above see this update first
-        }
-    }
+    uint32_t mark;       // 1 = list the flips for FastMark (the rounds), 0 = do not (the repair passes)
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t y0 = lo + (uint32_t)tid * 8;
         if (y0 > hi) return;
@@ -973,7 +1093,7 @@ struct FastFlip {
                     const uint32_t j = a.idx[y];
                     const uint64_t bit = 1ull << (j & 63), old = atom_fetch_xor64(&a.vbits[j >> 6], bit);
                     if ((old == 0) != ((old ^ bit) == 0)) atom_xor64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
-                    if (mark_hi) mark_candidates(j, y);
+                    if (mark) a.marklist[list_slot(a.nmark)] = j;
                 }
             }
             if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
@@ -982,12 +1102,50 @@ struct FastFlip {
                     efw ^= 1u << k;
                     const uint32_t ku = a.kidx[y - 2];
                     atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-                    if (mark_hi) mark_words(ku, y - 2);
+                    if (mark) a.marklist[list_slot(a.nmark)] = ku | 0x80000000u;
                 }
             }
         }
         if (mfw != mf0) a.mfb[i0 / 8] = (uint8_t)mfw;
         if (efw != ef0) a.efb[i0 / 8] = (uint8_t)efw;
+    }
+};
+// A flipped item start matters to the later positions of its run for which it is among the newest `dmax` item starts
+// below them: walk up the run (slots ascend with the position) until that many set bits have been passed, the run ends
+// or the range that is still being re-evaluated (< mark_hi) is left; a flipped word update matters up to the next set
+// bit above it.  Bits that flip concurrently are covered by their own walks: whichever state a walk observes, the union
+// of the marks contains every position whose answer can have changed.  Thread per listed flip, four slots per trip
+// (independent loads: most walks end in the first trip).
+struct FastMark {
+    FastArgs a;
+    uint32_t nthreads, mark_hi;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t nm = *a.nmark;
+        for (uint32_t e = (uint32_t)tid; e < nm; e += nthreads) {
+            const uint32_t ent = a.marklist[e], slot = ent & 0x7fffffffu;
+            const bool words = ent >> 31;
+            const uint32_t* pos = words ? a.kpos : a.epos;
+            const uint64_t* bits = words ? a.kbits : a.vbits;
+            const uint32_t y = pos[slot], lim = words ? 1u : a.dmax;
+            const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
+            uint32_t passed = 0;
+            bool more = true;
+            for (uint32_t s = slot + 1; s < end && more; s += 4) {
+                uint32_t q[4];
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++) q[b] = s + b < end ? pos[s + b] : 0;
+                const uint64_t w0 = bits[s >> 6], w1 = bits[(s + 3) >> 6];
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++) {
+                    if (!more) break;
+                    const uint32_t qq = q[b];
+                    if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / beyond the active range
+                    if (qq >= kPre) a.dirty[qq - kPre] = 1;
+                    const uint64_t w = ((s + b) >> 6) == (s >> 6) ? w0 : w1;
+                    if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) { more = false; break; }
+                }
+            }
+        }
     }
 };
 // item starts per (subtile, ctx) of the current path: one wavefront per 4096-position subtile, lane = 64 positions,

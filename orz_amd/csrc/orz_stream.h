@@ -279,6 +279,9 @@ class StreamEncoder {
             fK_ = kFastK;  // (deeper runs are searched through the bitmap + the text records: FastFar)
             if (const char* u = getenv("ORZ_FAST_UNIT")) unit_ = (uint32_t)atoi(u);
             if (unit_ < (1u << 20) || unit_ > kNewMax || unit_ % kSub) throw std::runtime_error("ORZ_FAST_UNIT must be a multiple of 4096 in [1 MiB, 16 MiB]");
+            cur_unit_ = unit_;
+            if (const char* u = getenv("ORZ_FAST_LEADUNIT")) lead_unit_ = (uint32_t)atoi(u);
+            if (lead_unit_ && (lead_unit_ < (1u << 20) || lead_unit_ > kNewMax || lead_unit_ % kSub)) throw std::runtime_error("ORZ_FAST_LEADUNIT must be 0 or a multiple of 4096 in [1 MiB, 16 MiB]");
         }
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
@@ -647,7 +650,7 @@ class StreamEncoder {
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
         be_.launch(nent, FastSlotInit{epos_, slot_keys, runstart_, nent, vbits_, frlen_});
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
-        be_.launch(nk, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_});
+        be_.launch_waves(((size_t)nk + 63) / 64, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_}, FastWordMasks::lds_bytes());
         // history item starts per (unified subtile, ctx) and their prefix: what the ring horizons reach back into
         if (stream_start_) be_.memset(fhcm_, 0, (size_t)kHistSub * 256 * 4);
         else be_.launch_waves(kHistSub, HistCountWave{win, S_, fhcm_}, HistCountWave::lds_bytes());
@@ -666,7 +669,7 @@ class StreamEncoder {
         a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
         a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
-        a.farlist = ffarlist_; a.nfar = fnfar_; a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.farlist = ffarlist_; a.nfar = fnfar_; a.marklist = f32_; a.nmark = fnfar_ + 1; a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
@@ -677,7 +680,7 @@ class StreamEncoder {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
-            if (n >= unit_) T = ftile_;  // (a full unit is not a short input)
+            if (n >= cur_unit_) T = ftile_;  // (a full unit is not a short input)
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it takes tiles twice the size -- half the steps, ~+0.1 % on that block's output.
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 2;
@@ -696,16 +699,16 @@ class StreamEncoder {
             be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
-            be_.memset(fnfar_, 0, 4);
+            be_.memset(fnfar_, 0, 8);
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
-            const uint32_t far_threads = std::max<uint32_t>(256, T / 2);
+            const uint32_t far_threads = std::max<uint32_t>(256, T / 2), far_waves = std::max<uint32_t>(32, T / 16);
             // ring horizons of the first tile (no counts yet: the history alone)
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt});
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
-            const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == unit_);
+            const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
             const bool replayed = use_graph && be_.graph_replay(gkey);
             struct CaptureGuard {  // a launch that throws inside the capture must not leave the stream capturing
@@ -730,7 +733,13 @@ class StreamEncoder {
                 // the range (the lazy rules look ahead) have never been evaluated either
                 const uint32_t r1lo = step <= ntile ? kPre + t_hi * T : hi;
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, fa0, fa1, fb0, fb1});
-                if (a.far && (fa1 > fa0 || fb1 > fb0)) be_.launch(far_threads, FastFar{a, far_threads});
+                if (a.far && (fa1 > fa0 || fb1 > fb0)) {
+                    // (the host emulation takes the thread-per-position form by default: same answers, and its SIMT emulator pays
+                    // dearly for every wave collective; one CPU test runs the cooperative form against it)
+                    static const bool far_thread = getenv("ORZ_FAST_FARTHREAD") != nullptr;
+                    if (be_.far_cooperative() && !far_thread) be_.launch_waves(far_waves, FastFarWave{a, far_waves}, FastFarWave::lds_bytes());
+                    else be_.launch(far_threads, FastFar{a, far_threads});
+                }
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -740,7 +749,8 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, hi});
+                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, 1});
+                be_.launch(far_threads, FastMark{a, far_threads, hi});
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
@@ -969,21 +979,31 @@ class StreamEncoder {
     // default, see unit_): the decoder accepts any chunk ends inside a block (it slides when the block is full,
     // src/lib.rs:119-124), so each unit closes its last chunk early, and the symbol ranking of unit k runs beside the
     // parse of unit k+1; a unit's parse sees the 16 MiB before it (the reference sees up to 16 MiB more).
+    // The LEAD block of a longer stream is different: nothing overlaps its parse (later blocks parse while the block before
+    // is ranked), so it is cut into small units (lead_unit_) -- ranking starts after the first unit's parse and is the
+    // bottleneck from then on (a unit parses faster than it ranks); the lead block has no history, so the units' repeated
+    // prep is cheap.
     template <class OutT>
     void encode_block_units(uint32_t take, bool lead, OutT& out) {
-        const uint32_t unit = fast_ ? unit_ : kNewMax;
+        uint32_t unit = fast_ ? unit_ : kNewMax;
+        const bool lead_units = fast_ && lead && lead_unit_ && lead_unit_ < unit;
+        if (lead_units) unit = lead_unit_;
+        cur_unit_ = unit;
         uint32_t done = 0;
         while (done < take) {
             uint32_t n = std::min(unit, take - done);
             if (take - done - n < unit / 8) n = take - done;  // no crumbs: a short rest joins the unit before it
-            set_lead_block(lead && done == 0);
+            set_lead_block(lead && done == 0 && !lead_units);
             unit_base_ = done;
             encode_block(n, out);
             done += n;
             if (done < take) slide_by(n, take - done);
         }
         unit_base_ = 0;
+        cur_unit_ = fast_ ? unit_ : kNewMax;
     }
+    void set_lead_unit(uint32_t bytes) { lead_unit_ = bytes; }  // 0 = the lead block is encoded like the others
+    uint32_t lead_unit() const { return lead_unit_; }
 
     EncodeStats stats;
     ItemTrace* trace = nullptr;  // when set, every block appends its items
@@ -1046,6 +1066,8 @@ class StreamEncoder {
     // fill the pipeline 18 ms sooner but cost 28 ms of parse (the history is sorted once per unit, the round pipeline and
     // the repair passes start once per unit): 353 vs 350 ms, 4 MiB units 377 ms -- so a unit is the whole block by default.
     uint32_t unit_ = kNewMax;
+    uint32_t cur_unit_ = kNewMax;  // unit size in effect for the block being encoded
+    uint32_t lead_unit_ = 0;       // unit size of a stream's lead block (0 = off)
     std::vector<int> pend_order_;  // sets whose output is still on the device, oldest first
     uint8_t* winbuf_;
     uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;

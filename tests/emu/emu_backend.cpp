@@ -28,6 +28,7 @@ struct EmuBackend {
     void sync() {}
     uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
     uint32_t handoff_deadline() const { return 0; }
+    bool far_cooperative() const { return std::getenv("ORZ_EMU_FARWAVE") != nullptr; }
     uint32_t near_blocks() const { return 16; }  // small windows here: exercise the far-wave paths too
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }
