@@ -74,9 +74,7 @@ struct FastArgs {
     uint8_t* dirty;             // [n+264] the position's candidates changed since it was last evaluated (set by FastFlip)
     uint32_t* hz;               // [kNSub][256][4] ring horizons per (subtile, ctx): oldest window offset still within 4094 / 510 item starts,
                                 // and the two values one step earlier (what the evaluations of the previous step saw)
-    uint32_t *farlist, *nfar;   // positions of this step that need the far search (FastEval appends, FastFar consumes)
-    uint32_t *marklist, *nmark; // slots flipped in this step (| 1 << 31: word-update bitmap): FastFlip appends, FastMark consumes
-    uint8_t* fseen;             // [n+8] item starts FastEval saw in the tabulated window of a listed position
+    uint8_t* fseen;             // [n+8] 0x80 | item starts seen in the tabulated window: the position needs the far search (FastEval -> FastFarWave)
     uint8_t *x0, *x1, *x2;      // path maps: per position, per (chunk, entry), per (tile, entry)
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
     uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
@@ -109,6 +107,15 @@ ORZ_D uint64_t atom_fetch_xor64(uint64_t* p, uint64_t v) {  // returns the old w
     return o;
 #endif
 }
+ORZ_D uint32_t atom_fetch_add32(uint32_t* p, uint32_t v) {  // returns the old value
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    const uint32_t o = *p;
+    *p = o + v;
+    return o;
+#endif
+}
 ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicSub(p, v);
@@ -131,23 +138,6 @@ ORZ_D uint32_t clz32(uint32_t v) {
     return (uint32_t)__builtin_clz(v);
 #endif
 }
-// A slot of an append-only list: on the device the lanes of a wavefront that append at the same point share ONE atomic
-// (leader adds the count, everybody takes its rank) -- a quarter of the positions of a step append, and that many
-// single atomics on one counter would serialise in L2.
-ORZ_D uint32_t list_slot(uint32_t* counter) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint64_t m = __ballot(1);
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-#else
-    return (*counter)++;
-#endif
-}
-
 // Position distances as 8-bit codes: exact below 16, then eight steps per octave.  A distance is coded rounded UP, a
 // budget rounded DOWN, so code(distance) <= code(budget) implies distance <= budget (never the other way round by
 // more than one step, 1/8 of the value).
@@ -473,7 +463,6 @@ struct FastEval {
     uint32_t fa0, fa1, fb0, fb1;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
-        if (tid == 0) *a.nmark = 0;  // (FastMark has consumed the previous step's flips)
         if (p >= hi) return;
         const uint8_t* win = a.win;
         const uint32_t i = p - kPre;
@@ -534,7 +523,13 @@ struct FastEval {
             if (v4 < kend) g_eval_stats[5]++;
 #endif
             uint32_t extra = 0;
-            for (uint32_t k = d4.sure; k < kend; k++) extra += a.epos[j - 1 - k] >= h4;
+            for (uint32_t k0 = d4.sure; k0 < kend; k0 += 8) {  // (eight loads in flight; validity is monotone, so counting is enough)
+                uint32_t q[8];
+#pragma unroll
+                for (uint32_t b = 0; b < 8; b++) q[b] = k0 + b < kend ? a.epos[j - 1 - (k0 + b)] : 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 8; b++) extra += k0 + b < kend && q[b] >= h4;
+            }
             v4 += extra;
         }
         if (a.dbg & 2) v4 = 64;
@@ -558,11 +553,10 @@ struct FastEval {
         const bool stop = full || v4 < r;  // (the ring ends inside the window: nothing older counts either)
         uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
         if (first) a.farv[i] = 0;  // nothing remembered yet
+        uint32_t farflag = 0;
         if (!stop && seen < a.depth && rl > kFastK && a.far) {
-            if (fardue) {  // FastFar continues from here and merges its answer
-                a.fseen[i] = (uint8_t)seen;
-                a.farlist[list_slot(a.nfar)] = i;
-            } else {
+            if (fardue) farflag = 0x80 | seen;  // FastFarWave continues from here and merges its answer
+            else {
                 const uint32_t fv = a.farv[i];
                 if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
                     if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
@@ -587,26 +581,185 @@ struct FastEval {
         }
 #endif
         a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
+        if (first || fardue) a.fseen[i] = (uint8_t)farflag;  // (a position is flagged only by an evaluation in a far-due round)
     }
 };
-// The far search of the listed positions: a long run whose tabulated K predecessors hold too few item starts (runs of
-// "interior" 4-grams, zero runs) -- walk the bitmap further back through its summary level and take the prefixes from
-// the text records.  Item starts newest first, four at a time: the slots are collected from the bitmap first, their
-// text records are fetched together (independent loads), then they are examined in order.
+// The far search of the flagged positions: a long run whose tabulated K predecessors hold too few item starts (runs of
+// "interior" 4-grams, zero runs) -- the bitmap is searched further back (up to `far` slots) through its summary level and
+// the prefixes come from the text records.  One wavefront per 256 positions of the two far-due tiles: the flagged ones
+// are compacted in LDS, then sixteen lanes serve one position (four at a time).  A trip takes the sixteen newest
+// non-empty words of the range (found in the summary words: one load), then the up to sixteen newest item starts in
+// them are examined side by side -- text record, window bytes beyond it, ring position, all independent loads -- and
+// resolved in order by every lane of the group with the serial rules of find_match (src/matcher.rs:135-192).  No global
+// atomics, no list in memory; a thread-per-position form of this lasted as long as its longest chain of dependent
+// loads (~90 us a launch).
+struct FastFarWave {
+    FastArgs a;
+    uint32_t fa0, fa1, fb0, fb1;  // the far-due ranges (window offsets)
+    static constexpr uint32_t kSeg = 256;
+    static size_t lds_bytes() { return kSeg * 4 + 16 + 64 * (8 + 4 + 4 + 4 + 4); }
+    ORZ_HD uint32_t nwaves() const { return (fa1 - fa0 + kSeg - 1) / kSeg + (fb1 - fb0 + kSeg - 1) / kSeg; }
+    // slot index of the n-th set bit (from the top) of the sixteen words w[0..16), word t standing for index top - t
+    ORZ_D static bool nth_from_top(const uint64_t* w, uint32_t n, uint32_t top, uint32_t* out) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 16; t++) {
+            uint64_t mm = w[t];
+            const uint32_t cnt = (uint32_t)popc64(mm);
+            if (n < run + cnt) {
+                for (uint32_t k = n - run; k; k--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
+                *out = (top - t) * 64 + 63 - (uint32_t)clz64(mm);
+                return true;
+            }
+            run += cnt;
+        }
+        return false;
+    }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* listL = (uint32_t*)w.lds();
+        uint32_t* cntL = listL + kSeg;
+        uint64_t* mL = (uint64_t*)(cntL + 4);
+        uint32_t* lenL = (uint32_t*)(mL + 64);
+        uint32_t* qL = lenL + 64;
+        uint32_t* sL = qL + 64;
+        uint32_t* wL = sL + 64;
+        const uint8_t* win = a.win;
+        const uint32_t lane = w.lane(), g = lane >> 4, sl = lane & 15, gb = g * 16;
+        // ---- this wavefront's 256 positions; the flagged ones into the LDS list
+        const uint32_t na = (fa1 - fa0 + kSeg - 1) / kSeg;
+        const uint32_t s0 = w.block() < na ? fa0 + w.block() * kSeg : fb0 + (w.block() - na) * kSeg;
+        const uint32_t s1 = fast_min(w.block() < na ? fa1 : fb1, s0 + kSeg);
+        if (lane == 0) *cntL = 0;
+        w.sync();
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t pos = s0 + lane * 4 + b;
+            if (pos < s1 && (a.fseen[pos - kPre] & 0x80)) listL[atom_fetch_add32(cntL, 1)] = pos - kPre;
+        }
+        w.sync();
+        const uint32_t nf = *cntL;
+        for (uint32_t base = 0; base < nf; base += 4) {
+            const bool act = base + g < nf;
+            uint32_t i = 0, p = 0, h4 = 0, h5 = 0, e0 = 0, seen = 0, lo2 = 0, cur_top = 0;
+            uint64_t a0 = 0, a1 = 0;
+            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
+            if (act) {
+                i = listL[base + g]; p = kPre + i;
+                const uint32_t j = a.idx[p], c = hash1(win, p - 1);
+                const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
+                h4 = hz[0]; h5 = hz[1];
+                e0 = a.ev[i];
+                seen = a.fseen[i] & 0x7f;
+                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
+                cur_top = j - kFastK;  // slots [lo2, cur_top) are searched, newest first
+                lo2 = cur_top - rs > a.far ? cur_top - a.far : rs;
+                a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
+            }
+            bool need = act && cur_top > lo2 && seen < a.depth;
+            while (w.ballot(need)) {
+                // ---- the summary words of the range (a word of v1 = 64 words of the bitmap), the newest in lane 0 of the group
+                const uint32_t wtop = need ? (cur_top - 1) >> 6 : 0, wlo = lo2 >> 6, gtop = wtop >> 6, glo = wlo >> 6;
+                uint64_t sm = 0;
+                if (need && gtop >= sl && gtop - sl >= glo) {
+                    const uint32_t gi = gtop - sl;
+                    sm = a.v1[gi];
+                    if (gi == gtop && (wtop & 63) != 63) sm &= (2ull << (wtop & 63)) - 1;
+                    if (gi == glo) sm &= ~0ull << (wlo & 63);
+                }
+                mL[lane] = sm;
+                w.sync();
+                // ---- the sixteen newest non-empty words of the bitmap, one per lane
+                uint32_t nwords = 0;
+                for (uint32_t t = 0; t < 16; t++) nwords += (uint32_t)popc64(mL[gb + t]);
+                uint32_t wi = 0;
+                uint64_t m = 0;
+                if (need && sl < nwords && nth_from_top(mL + gb, sl, gtop, &wi)) {
+                    m = a.vbits[wi];
+                    if (wi == wtop && (cur_top & 63)) m &= (1ull << (cur_top & 63)) - 1;
+                    if (wi == wlo) m &= ~0ull << (lo2 & 63);
+                }
+                w.sync();
+                mL[lane] = m; wL[lane] = wi;
+                w.sync();
+                uint32_t tot = 0;
+                for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
+                const uint32_t want = need ? fast_min(fast_min(tot, 16u), a.depth - seen) : 0;
+                // ---- member number sl of the trip: its slot, its common prefix with p, its position
+                uint32_t l = 0, q = 0, s2 = 0;
+                if (sl < want) {
+                    uint32_t run = 0;
+                    for (uint32_t t = 0; t < 16; t++) {
+                        uint64_t mm = mL[gb + t];
+                        const uint32_t cnt = (uint32_t)popc64(mm);
+                        if (sl < run + cnt) {
+                            for (uint32_t k = sl - run; k; k--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
+                            s2 = wL[gb + t] * 64 + 63 - (uint32_t)clz64(mm);
+                            break;
+                        }
+                        run += cnt;
+                    }
+                    const uint64_t x0 = a.stext[2 * (size_t)s2] ^ a0, x1 = a.stext[2 * (size_t)s2 + 1] ^ a1;
+                    q = a.epos[s2];
+                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
+                    else if (x1) l = 8 + ((uint32_t)ctz64(x1) >> 3);
+                    else l = 16 + lcp240u(win + q + 16, win + p + 16, kMaxLen - 16);
+                }
+                lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
+                w.sync();
+                // ---- resolved in order by every lane of the group
+                if (need) {
+                    bool fin = false;
+                    for (uint32_t k = 0; k < want; k++) {
+                        const uint32_t ll = lenL[gb + k], qq = qL[gb + k];
+                        if (ll > fbest || (seen < a.lazy1 && ll > fm1) || (seen < a.lazy2 && ll > fm2)) {
+                            if (qq < h4) { fin = true; break; }  // left the ring (only candidates that matter are asked): so did everything older
+                            if (ll > fbest) { fbest = ll; fsrc = qq; f510 = qq >= h5; }
+                            if (seen < a.lazy1 && ll > fm1) fm1 = ll;
+                            if (seen < a.lazy2 && ll > fm2) fm2 = ll;
+                        }
+                        seen++;
+                        if (ll == kMaxLen || seen >= a.depth) { fin = true; break; }
+                    }
+                    if (fin) need = false;
+                    else if (tot > 16) cur_top = sL[gb + 15];      // more item starts in these words: go on below the sixteenth
+                    else if (nwords > 16) cur_top = wL[gb + 15] * 64;  // these words are done, older non-empty ones exist
+                    else need = false;                              // the range is exhausted
+                    if (cur_top <= lo2) need = false;
+                }
+                w.sync();
+            }
+            if (act && sl == 0) {
+                uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
+                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+                a.farsrc[i] = fsrc;
+                if (fbest > best) { best = fbest; b510 = f510; }
+                if (fm1 > m1) m1 = fm1;
+                if (fm2 > m2) m2 = fm2;
+                a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
+                a.fseen[i] = 0;
+            }
+        }
+    }
+};
+// The same search as one serial walk per flagged position (thread per position of the far-due ranges).  This is the form
+// the HOST EMULATION runs (tests/emu: every wave collective costs its SIMT emulator 64 context switches, FastFarWave has
+// seven a trip); the GPU never launches it.  tests/test_emu_fast.py runs both forms on the emulator: the same bytes.
 struct FastFar {
     FastArgs a;
-    uint32_t nthreads;
+    uint32_t fa0, fa1, fb0, fb1;  // the far-due ranges (window offsets); thread per position of both
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t nf = *a.nfar;
         const uint8_t* win = a.win;
-        for (uint32_t e = (uint32_t)tid; e < nf; e += nthreads) {
-            const uint32_t i = a.farlist[e], p = kPre + i, j = a.idx[p];
+        {
+            const uint32_t na = fa1 - fa0;
+            const uint32_t p = tid < na ? fa0 + (uint32_t)tid : fb0 + ((uint32_t)tid - na);
+            if (tid >= (size_t)na + (fb1 - fb0)) return;
+            const uint32_t i = p - kPre, j = a.idx[p];
+            if (!(a.fseen[i] & 0x80)) return;
             const uint32_t c = hash1(win, p - 1);
             const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
             const uint32_t h4 = hz[0], h5 = hz[1];
             const uint32_t e0 = a.ev[i];
             uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
-            uint32_t seen = a.fseen[i];
+            uint32_t seen = a.fseen[i] & 0x7f;
             const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
             const uint32_t top = j - kFastK;  // slots [lo2, top) are searched, newest first
             const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
@@ -660,112 +813,7 @@ struct FastFar {
             if (fm1 > m1) m1 = fm1;
             if (fm2 > m2) m2 = fm2;
             a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
-        }
-    }
-};
-// The same far search, sixteen lanes per listed position (four positions per wavefront): a trip looks at sixteen words
-// of the bitmap at once (one coalesced load), the up to sixteen item starts found are examined side by side -- text
-// record, window bytes beyond it, ring position, all independent loads -- and then resolved in order by every lane of
-// the group (the serial rules of FastFar, unchanged: same answers).  The thread-per-position form lasts as long as its
-// longest chain of dependent loads (~90 us a launch); this one a few microseconds a trip.
-struct FastFarWave {
-    FastArgs a;
-    uint32_t nwaves;
-    static size_t lds_bytes() { return 64 * (8 + 4 + 4 + 4); }
-    template <class W>
-    ORZ_D void operator()(W& w) const {
-        uint64_t* mL = (uint64_t*)w.lds();
-        uint32_t* lenL = (uint32_t*)(mL + 64);
-        uint32_t* qL = lenL + 64;
-        uint32_t* sL = qL + 64;
-        const uint8_t* win = a.win;
-        const uint32_t lane = w.lane(), g = lane >> 4, sl = lane & 15, gb = g * 16;
-        const uint32_t nf = *a.nfar;
-        for (uint32_t base = w.block() * 4; base < nf; base += nwaves * 4) {
-            const bool act = base + g < nf;
-            uint32_t i = 0, p = 0, h4 = 0, h5 = 0, e0 = 0, seen = 0, lo2 = 0, cur_top = 0;
-            uint64_t a0 = 0, a1 = 0;
-            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
-            if (act) {
-                i = a.farlist[base + g]; p = kPre + i;
-                const uint32_t j = a.idx[p], c = hash1(win, p - 1);
-                const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
-                h4 = hz[0]; h5 = hz[1];
-                e0 = a.ev[i];
-                seen = a.fseen[i];
-                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
-                cur_top = j - kFastK;  // slots [lo2, cur_top) are searched, newest first
-                lo2 = cur_top - rs > a.far ? cur_top - a.far : rs;
-                a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
-            }
-            bool need = act && cur_top > lo2 && seen < a.depth;
-            while (w.ballot(need)) {
-                // ---- sixteen words of the bitmap, the newest in lane 0 of the group
-                const uint32_t wtop = need ? (cur_top - 1) >> 6 : 0, wlo = lo2 >> 6;
-                uint64_t m = 0;
-                if (need && wtop >= sl && wtop - sl >= wlo) {
-                    const uint32_t wi = wtop - sl;
-                    m = a.vbits[wi];
-                    if (wi == wtop && (cur_top & 63)) m &= (1ull << (cur_top & 63)) - 1;
-                    if (wi == wlo) m &= ~0ull << (lo2 & 63);
-                }
-                mL[lane] = m;
-                w.sync();
-                uint32_t tot = 0;
-                for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
-                const uint32_t want = need ? fast_min(fast_min(tot, 16u), a.depth - seen) : 0;
-                // ---- member number sl of the trip: its slot, its common prefix with p, its position
-                uint32_t l = 0, q = 0, s2 = 0;
-                if (sl < want) {
-                    uint32_t run = 0;
-                    for (uint32_t t = 0; t < 16; t++) {
-                        uint64_t mm = mL[gb + t];
-                        const uint32_t cnt = (uint32_t)popc64(mm);
-                        if (sl < run + cnt) {
-                            for (uint32_t n = sl - run; n; n--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
-                            s2 = (wtop - t) * 64 + 63 - (uint32_t)clz64(mm);
-                            break;
-                        }
-                        run += cnt;
-                    }
-                    const uint64_t x0 = a.stext[2 * (size_t)s2] ^ a0, x1 = a.stext[2 * (size_t)s2 + 1] ^ a1;
-                    q = a.epos[s2];
-                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
-                    else if (x1) l = 8 + ((uint32_t)ctz64(x1) >> 3);
-                    else l = 16 + lcp240u(win + q + 16, win + p + 16, kMaxLen - 16);
-                }
-                lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
-                w.sync();
-                // ---- resolved in order by every lane of the group (src/matcher.rs:135-192 on these candidates)
-                if (need) {
-                    bool fin = false;
-                    for (uint32_t k = 0; k < want; k++) {
-                        const uint32_t ll = lenL[gb + k], qq = qL[gb + k];
-                        if (ll > fbest || (seen < a.lazy1 && ll > fm1) || (seen < a.lazy2 && ll > fm2)) {
-                            if (qq < h4) { fin = true; break; }  // left the ring: so did everything older
-                            if (ll > fbest) { fbest = ll; fsrc = qq; f510 = qq >= h5; }
-                            if (seen < a.lazy1 && ll > fm1) fm1 = ll;
-                            if (seen < a.lazy2 && ll > fm2) fm2 = ll;
-                        }
-                        seen++;
-                        if (ll == kMaxLen || seen >= a.depth) { fin = true; break; }
-                    }
-                    if (fin) need = false;
-                    else if (tot > 16) cur_top = sL[gb + 15];          // more item starts in these words: go on below the sixteenth
-                    else cur_top = wtop >= 16 ? (wtop - 15) * 64 : 0;  // these words are done
-                    if (cur_top <= lo2) need = false;
-                }
-                w.sync();
-            }
-            if (act && sl == 0) {
-                uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
-                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
-                a.farsrc[i] = fsrc;
-                if (fbest > best) { best = fbest; b510 = f510; }
-                if (fm1 > m1) m1 = fm1;
-                if (fm2 > m2) m2 = fm2;
-                a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
-            }
+            a.fseen[i] = 0;
         }
     }
 };
@@ -840,7 +888,6 @@ struct FastDecide {  // thread per position (measured: inside PathUpWave the fou
     uint32_t lo, hi;
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
-        if (tid == 0) *a.nfar = 0;  // (FastFar has consumed this step's list)
         if (p >= hi) return;
         const uint32_t i = p - kPre;
         const uint32_t d = fast_decide(p, a.len, a.ev[i], p + 1 < a.len ? a.ev[i + 1] : 0, p + 2 < a.len ? a.ev[i + 2] : 0);
@@ -1063,13 +1110,43 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// Bring the slot-order bitmaps in line with the path (thread per 8 positions).  Every flipped slot is appended to a list;
-// FastMark then marks the positions whose next evaluation would see the difference.
+// Bring the slot-order bitmaps in line with the path (thread per 8 positions), and mark the positions whose next
+// evaluation would see the difference (dirty).  A flipped item start matters to the later positions of its run for which
+// it is among the newest `dmax` item starts below them: walk up the run (slots ascend with the position) until that many
+// set bits have been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped
+// word update matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks:
+// whichever state a walk observes, the union of the marks contains every position whose answer can have changed.
+// A walk loads four slots per trip (independent loads; most walks end in the first trip).  All atomics are
+// fire-and-forget: the summary level v1 is only ever set here (a bit whose word went back to zero costs a walker one
+// wasted load; V1Build makes it exact again at the start of a parse).
 struct FastFlip {
     FastArgs a;
     uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
-    uint32_t mark;       // 1 = list the flips for FastMark (the rounds), 0 = do not (the repair passes)
+    uint32_t mark_hi;    // positions below this one are marked dirty (0 = no marking: the repair passes)
+    ORZ_D void mark_from(bool words, uint32_t slot, uint32_t y) const {
+        const uint32_t* pos = words ? a.kpos : a.epos;
+        const uint64_t* bits = words ? a.kbits : a.vbits;
+        const uint32_t lim = words ? 1u : a.dmax;
+        const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
+        uint32_t passed = 0;
+        bool more = true;
+        for (uint32_t s = slot + 1; s < end && more; s += 4) {
+            uint32_t q[4];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) q[b] = s + b < end ? pos[s + b] : 0;
+            const uint64_t w0 = bits[s >> 6], w1 = bits[(s + 3) >> 6];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+                if (!more) break;
+                const uint32_t qq = q[b];
+                if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / beyond the active range
+                if (qq >= kPre) a.dirty[qq - kPre] = 1;
+                const uint64_t w = ((s + b) >> 6) == (s >> 6) ? w0 : w1;
+                if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) { more = false; break; }
+            }
+        }
+    }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t y0 = lo + (uint32_t)tid * 8;
         if (y0 > hi) return;
@@ -1078,74 +1155,34 @@ struct FastFlip {
         const uint32_t sb = (uint32_t)((a.sbits[i0 / 64] >> (i0 & 63)) & 0xff);
         uint32_t mfw = a.mfb[i0 / 8], efw = a.efb[i0 / 8];
         const uint64_t ptw = *reinterpret_cast<const uint64_t*>(a.pt + i0);
-        const uint32_t mf0 = mfw, ef0 = efw;
+        // what the bitmaps should hold for the eight positions
+        uint32_t sw = 0, ew = 0;
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t y = y0 + k;
-            if (y > hi) break;
-            uint32_t s = y == exit_at;
-            if (y < a.len) {
-                s |= (sb >> k) & 1;
-                if (s != ((mfw >> k) & 1)) {
-                    mfw ^= 1u << k;
-                    // the summary level follows: every zero <-> non-zero transition of a word toggles its bit (the atomics on
-                    // a word are totally ordered and each transition is seen by exactly the operation that makes it, so the
-                    // toggles commute and the bit ends as "word non-zero" however they interleave)
-                    const uint32_t j = a.idx[y];
-                    const uint64_t bit = 1ull << (j & 63), old = atom_fetch_xor64(&a.vbits[j >> 6], bit);
-                    if ((old == 0) != ((old ^ bit) == 0)) atom_xor64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
-                    if (mark) a.marklist[list_slot(a.nmark)] = j;
-                }
+            if (y > hi) { sw |= ((mfw >> k) & 1) << k; ew |= ((efw >> k) & 1) << k; continue; }  // (outside the range: as it is)
+            const uint32_t s = (y == exit_at) | (y < a.len ? (sb >> k) & 1 : 0);
+            sw |= (y < a.len ? s : (mfw >> k) & 1) << k;
+            // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
+            ew |= (y >= kPre + 1 ? (uint32_t)(s && ((ptw >> (8 * k)) & 0xff) != kTyWord) : (efw >> k) & 1) << k;
+        }
+        const uint32_t dv = sw ^ mfw, de = ew ^ efw;
+        if (!(dv | de)) return;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t y = y0 + k;
+            if ((dv >> k) & 1) {
+                const uint32_t j = a.idx[y];
+                atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+                if ((sw >> k) & 1) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
+                if (mark_hi) mark_from(false, j, y);
             }
-            if (y >= kPre + 1) {  // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
-                const uint32_t e = s && ((ptw >> (8 * k)) & 0xff) != kTyWord;
-                if (e != ((efw >> k) & 1)) {
-                    efw ^= 1u << k;
-                    const uint32_t ku = a.kidx[y - 2];
-                    atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-                    if (mark) a.marklist[list_slot(a.nmark)] = ku | 0x80000000u;
-                }
+            if ((de >> k) & 1) {
+                const uint32_t ku = a.kidx[y - 2];
+                atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+                if (mark_hi) mark_from(true, ku, y - 2);
             }
         }
-        if (mfw != mf0) a.mfb[i0 / 8] = (uint8_t)mfw;
-        if (efw != ef0) a.efb[i0 / 8] = (uint8_t)efw;
-    }
-};
-// A flipped item start matters to the later positions of its run for which it is among the newest `dmax` item starts
-// below them: walk up the run (slots ascend with the position) until that many set bits have been passed, the run ends
-// or the range that is still being re-evaluated (< mark_hi) is left; a flipped word update matters up to the next set
-// bit above it.  Bits that flip concurrently are covered by their own walks: whichever state a walk observes, the union
-// of the marks contains every position whose answer can have changed.  Thread per listed flip, four slots per trip
-// (independent loads: most walks end in the first trip).
-struct FastMark {
-    FastArgs a;
-    uint32_t nthreads, mark_hi;
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t nm = *a.nmark;
-        for (uint32_t e = (uint32_t)tid; e < nm; e += nthreads) {
-            const uint32_t ent = a.marklist[e], slot = ent & 0x7fffffffu;
-            const bool words = ent >> 31;
-            const uint32_t* pos = words ? a.kpos : a.epos;
-            const uint64_t* bits = words ? a.kbits : a.vbits;
-            const uint32_t y = pos[slot], lim = words ? 1u : a.dmax;
-            const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
-            uint32_t passed = 0;
-            bool more = true;
-            for (uint32_t s = slot + 1; s < end && more; s += 4) {
-                uint32_t q[4];
-#pragma unroll
-                for (uint32_t b = 0; b < 4; b++) q[b] = s + b < end ? pos[s + b] : 0;
-                const uint64_t w0 = bits[s >> 6], w1 = bits[(s + 3) >> 6];
-#pragma unroll
-                for (uint32_t b = 0; b < 4; b++) {
-                    if (!more) break;
-                    const uint32_t qq = q[b];
-                    if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / beyond the active range
-                    if (qq >= kPre) a.dirty[qq - kPre] = 1;
-                    const uint64_t w = ((s + b) >> 6) == (s >> 6) ? w0 : w1;
-                    if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) { more = false; break; }
-                }
-            }
-        }
+        if (dv) a.mfb[i0 / 8] = (uint8_t)sw;
+        if (de) a.efb[i0 / 8] = (uint8_t)ew;
     }
 };
 // item starts per (subtile, ctx) of the current path: one wavefront per 4096-position subtile, lane = 64 positions,

@@ -345,8 +345,6 @@ class StreamEncoder {
                 fhcm_ = take<uint32_t>((size_t)kHistSub * 256);
                 fhpre_ = take<uint32_t>((size_t)(kHistSub + 1) * 256);
                 fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256);
-                ffarlist_ = take<uint32_t>(nn, false);
-                fnfar_ = take<uint32_t>(4);
                 ffseen_ = take<uint8_t>(nn);
                 fx0_ = take<uint8_t>(nn);
                 fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
@@ -669,7 +667,7 @@ class StreamEncoder {
         a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
         a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
-        a.farlist = ffarlist_; a.nfar = fnfar_; a.marklist = f32_; a.nmark = fnfar_ + 1; a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
@@ -699,11 +697,9 @@ class StreamEncoder {
             be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
-            be_.memset(fnfar_, 0, 8);
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
-            const uint32_t far_threads = std::max<uint32_t>(256, T / 2), far_waves = std::max<uint32_t>(32, T / 16);
             // ring horizons of the first tile (no counts yet: the history alone)
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt});
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
@@ -734,11 +730,9 @@ class StreamEncoder {
                 const uint32_t r1lo = step <= ntile ? kPre + t_hi * T : hi;
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, fa0, fa1, fb0, fb1});
                 if (a.far && (fa1 > fa0 || fb1 > fb0)) {
-                    // (the host emulation takes the thread-per-position form by default: same answers, and its SIMT emulator pays
-                    // dearly for every wave collective; one CPU test runs the cooperative form against it)
-                    static const bool far_thread = getenv("ORZ_FAST_FARTHREAD") != nullptr;
-                    if (be_.far_cooperative() && !far_thread) be_.launch_waves(far_waves, FastFarWave{a, far_waves}, FastFarWave::lds_bytes());
-                    else be_.launch(far_threads, FastFar{a, far_threads});
+                    const FastFarWave ff{a, fa0, fa1, fb0, fb1};
+                    if (be_.far_cooperative()) be_.launch_waves(ff.nwaves(), ff, FastFarWave::lds_bytes());
+                    else be_.launch((size_t)(fa1 - fa0) + (fb1 - fb0), FastFar{a, fa0, fa1, fb0, fb1});  // (host emulation: see FastFar)
                 }
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
@@ -749,8 +743,7 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, 1});
-                be_.launch(far_threads, FastMark{a, far_threads, hi});
+                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, hi});
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
@@ -1033,7 +1026,7 @@ class StreamEncoder {
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr, *ffseen_ = nullptr;
     uint16_t *fkw_ = nullptr, *fkmeta_ = nullptr;
     uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
-    uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr, *ffarlist_ = nullptr, *fnfar_ = nullptr;
+    uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr;
     uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
              *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr;

@@ -123,10 +123,11 @@ def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle):
     assert abs(len(big) - len(ref)) <= 0.003 * len(ref)
 
 
+
 def test_cooperative_far_search_gives_the_same_stream(emu, oracle, monkeypatch):
-    """FastFarWave (sixteen lanes per listed position, what the GPU runs) against FastFar (thread per position, what the
-    emulation runs by default because every wave collective is costly on the SIMT emulator): the very same bytes -- on
-    data whose runs are deep enough to need the far search (zero runs with noise, text)"""
+    """FastFarWave (sixteen lanes per flagged position, what the GPU runs) against FastFar (one serial walk per position,
+    what the emulation runs by default because every wave collective is costly on the SIMT emulator): the very same
+    bytes -- on data whose runs are deep enough to need the far search (zero runs with noise, text)"""
     import corpus
 
     for data in (_data.zeros_noise(300_000), corpus.enwik_like(700_000)):
