@@ -79,7 +79,8 @@ struct FastArgs {
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
     uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
     uint32_t* nchg;
-    uint32_t dbg;               // experiment switches (ORZ_FAST_DBG): 1 = evaluate every position every round
+    uint32_t dbg;               // experiment switches (ORZ_FAST_DBG): 1 = evaluate every position every round, 64 = collect `stats`
+    unsigned long long* stats;  // [32] counters / wall-clock ticks of kernel phases when dbg & 64 (diagnostics only)
 };
 
 ORZ_D uint32_t fast_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -457,6 +458,8 @@ struct FastEval {
     FastArgs a;
     uint32_t lo, hi;    // window offsets [lo, hi)
     uint32_t r1lo;      // positions >= r1lo have not been evaluated in this parse yet (the tile in its first round, and beyond)
+    uint32_t r2lo;      // positions >= r2lo are evaluated whatever their flags say (the tiles in their first two rounds: after a
+                        // tile's first round nearly every position with a predecessor inside the tile is dirty anyway)
     // [fa0, fa1) and [fb0, fb1): the window offsets (two tiles) whose far search is due in this launch: the tile in its
     // second round (the first one, against an empty tile, only sketches the path) and the tile in its last one (when
     // every earlier tile is final); the other rounds merge the remembered answer.
@@ -473,7 +476,7 @@ struct FastEval {
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
         const uint32_t h4 = hz[0], h4was = hz[2];
-        const bool need = first || dirty || (fardue && rl > kFastK && a.far);
+        const bool need = p >= r2lo || dirty || (fardue && rl > kFastK && a.far);
 #if !defined(__HIPCC__)
         g_eval_stats[0]++;
         if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (fardue && rl > kFastK) g_eval_stats[4]++;
@@ -570,7 +573,7 @@ struct FastEval {
         if (km & 0x80) kmask &= ~(1ull << 63);
         const uint32_t lwm = kmask ? (uint32_t)((wm >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
 #if !defined(__HIPCC__)
-        if ((a.dbg & 32) && !first && !a.dirty[i] && !moved && !(fardue && rl > kFastK && a.far)) {  // verify mode: would a skipped position have changed?
+        if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved && !(fardue && rl > kFastK && a.far)) {  // verify mode: would a skipped position have changed?
             const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
             if ((o ^ nw) & ~(1u << 25)) {
                 g_eval_stats[6]++;
@@ -584,9 +587,22 @@ struct FastEval {
         if (first || fardue) a.fseen[i] = (uint8_t)farflag;  // (a position is flagged only by an evaluation in a far-due round)
     }
 };
+// Common prefix of a[0..) and b[0..), capped at `cap` (a multiple of 16 is not required), 64 bytes per trip with all
+// sixteen loads of a trip in flight: a long match costs a few memory latencies instead of one per eight bytes.
+ORZ_D uint32_t lcp_wide(const uint8_t* x, const uint8_t* y, uint32_t cap) {
+    for (uint32_t off = 0; off < cap; off += 64) {
+        uint64_t d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) d[k] = ldu64(x + off + 8 * k) ^ ldu64(y + off + 8 * k);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++)
+            if (d[k]) { const uint32_t l = off + 8 * k + ((uint32_t)ctz64(d[k]) >> 3); return l < cap ? l : cap; }
+    }
+    return cap;
+}
 // The far search of the flagged positions: a long run whose tabulated K predecessors hold too few item starts (runs of
 // "interior" 4-grams, zero runs) -- the bitmap is searched further back (up to `far` slots) through its summary level and
-// the prefixes come from the text records.  One wavefront per 256 positions of the two far-due tiles: the flagged ones
+// the prefixes come from the text records.  One wavefront per 32 positions of the two far-due tiles: the flagged ones
 // are compacted in LDS, then sixteen lanes serve one position (four at a time).  A trip takes the sixteen newest
 // non-empty words of the range (found in the summary words: one load), then the up to sixteen newest item starts in
 // them are examined side by side -- text record, window bytes beyond it, ring position, all independent loads -- and
@@ -596,7 +612,7 @@ struct FastEval {
 struct FastFarWave {
     FastArgs a;
     uint32_t fa0, fa1, fb0, fb1;  // the far-due ranges (window offsets)
-    static constexpr uint32_t kSeg = 256;
+    static constexpr uint32_t kSeg = 32;   // positions per wavefront: ~7 flagged ones, two rounds of four
     static size_t lds_bytes() { return kSeg * 4 + 16 + 64 * (8 + 4 + 4 + 4 + 4); }
     ORZ_HD uint32_t nwaves() const { return (fa1 - fa0 + kSeg - 1) / kSeg + (fb1 - fb0 + kSeg - 1) / kSeg; }
     // slot index of the n-th set bit (from the top) of the sixteen words w[0..16), word t standing for index top - t
@@ -631,14 +647,16 @@ struct FastFarWave {
         const uint32_t s1 = fast_min(w.block() < na ? fa1 : fb1, s0 + kSeg);
         if (lane == 0) *cntL = 0;
         w.sync();
-        for (uint32_t b = 0; b < 4; b++) {
-            const uint32_t pos = s0 + lane * 4 + b;
-            if (pos < s1 && (a.fseen[pos - kPre] & 0x80)) listL[atom_fetch_add32(cntL, 1)] = pos - kPre;
-        }
+        for (uint32_t pos = s0 + lane; pos < s1; pos += 64)
+            if (a.fseen[pos - kPre] & 0x80) listL[atom_fetch_add32(cntL, 1)] = pos - kPre;
         w.sync();
         const uint32_t nf = *cntL;
+        const bool st = (a.dbg & 64) && lane == 0;
+        unsigned long long tk0 = st ? w.wallclock() : 0, tk;
+        if (st) { atom_add64(&a.stats[0], 1); atom_add64(&a.stats[1], nf); }
         for (uint32_t base = 0; base < nf; base += 4) {
             const bool act = base + g < nf;
+            if (st) { tk = w.wallclock(); atom_add64(&a.stats[8], tk - tk0); tk0 = tk; atom_add64(&a.stats[2], 1); }
             uint32_t i = 0, p = 0, h4 = 0, h5 = 0, e0 = 0, seen = 0, lo2 = 0, cur_top = 0;
             uint64_t a0 = 0, a1 = 0;
             uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
@@ -655,7 +673,9 @@ struct FastFarWave {
                 a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
             }
             bool need = act && cur_top > lo2 && seen < a.depth;
+            if (st) { tk = w.wallclock(); atom_add64(&a.stats[9], tk - tk0); tk0 = tk; }
             while (w.ballot(need)) {
+                if (st) atom_add64(&a.stats[3], 1);
                 // ---- the summary words of the range (a word of v1 = 64 words of the bitmap), the newest in lane 0 of the group
                 const uint32_t wtop = need ? (cur_top - 1) >> 6 : 0, wlo = lo2 >> 6, gtop = wtop >> 6, glo = wlo >> 6;
                 uint64_t sm = 0;
@@ -680,6 +700,7 @@ struct FastFarWave {
                 w.sync();
                 mL[lane] = m; wL[lane] = wi;
                 w.sync();
+                if (st) { tk = w.wallclock(); atom_add64(&a.stats[10], tk - tk0); tk0 = tk; }
                 uint32_t tot = 0;
                 for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
                 const uint32_t want = need ? fast_min(fast_min(tot, 16u), a.depth - seen) : 0;
@@ -701,10 +722,12 @@ struct FastFarWave {
                     q = a.epos[s2];
                     if (x0) l = (uint32_t)ctz64(x0) >> 3;
                     else if (x1) l = 8 + ((uint32_t)ctz64(x1) >> 3);
-                    else l = 16 + lcp240u(win + q + 16, win + p + 16, kMaxLen - 16);
+                    else l = 16 + lcp_wide(win + q + 16, win + p + 16, kMaxLen - 16);
                 }
                 lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
+                if ((a.dbg & 64) && sl < want) { atom_add64(&a.stats[4], 1); if (l >= 16) atom_add64(&a.stats[5], 1); }
                 w.sync();
+                if (st) { tk = w.wallclock(); atom_add64(&a.stats[11], tk - tk0); tk0 = tk; }
                 // ---- resolved in order by every lane of the group
                 if (need) {
                     bool fin = false;
@@ -726,6 +749,7 @@ struct FastFarWave {
                     if (cur_top <= lo2) need = false;
                 }
                 w.sync();
+                if (st) { tk = w.wallclock(); atom_add64(&a.stats[12], tk - tk0); tk0 = tk; }
             }
             if (act && sl == 0) {
                 uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
@@ -1123,7 +1147,8 @@ struct FastFlip {
     FastArgs a;
     uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
-    uint32_t mark_hi;    // positions below this one are marked dirty (0 = no marking: the repair passes)
+    uint32_t mark_hi;    // positions below this one are marked dirty: those beyond are evaluated in the next step whatever their
+                         // flags say (FastEval r2lo); 0 = no marking (the repair passes)
     ORZ_D void mark_from(bool words, uint32_t slot, uint32_t y) const {
         const uint32_t* pos = words ? a.kpos : a.epos;
         const uint64_t* bits = words ? a.kbits : a.vbits;
@@ -1132,6 +1157,7 @@ struct FastFlip {
         uint32_t passed = 0;
         bool more = true;
         for (uint32_t s = slot + 1; s < end && more; s += 4) {
+            if (a.dbg & 64) atom_add64(&a.stats[words ? 19 : 18], 1);
             uint32_t q[4];
 #pragma unroll
             for (uint32_t b = 0; b < 4; b++) q[b] = s + b < end ? pos[s + b] : 0;
@@ -1140,7 +1166,7 @@ struct FastFlip {
             for (uint32_t b = 0; b < 4; b++) {
                 if (!more) break;
                 const uint32_t qq = q[b];
-                if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / beyond the active range
+                if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / evaluated anyway next step
                 if (qq >= kPre) a.dirty[qq - kPre] = 1;
                 const uint64_t w = ((s + b) >> 6) == (s >> 6) ? w0 : w1;
                 if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) { more = false; break; }
@@ -1170,15 +1196,17 @@ struct FastFlip {
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t y = y0 + k;
             if ((dv >> k) & 1) {
+                if (a.dbg & 64) atom_add64(&a.stats[16], 1);
                 const uint32_t j = a.idx[y];
                 atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
                 if ((sw >> k) & 1) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
-                if (mark_hi) mark_from(false, j, y);
+                if (y < mark_hi) mark_from(false, j, y);
             }
             if ((de >> k) & 1) {
+                if (a.dbg & 64) atom_add64(&a.stats[17], 1);
                 const uint32_t ku = a.kidx[y - 2];
                 atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-                if (mark_hi) mark_from(true, ku, y - 2);
+                if (y - 2 < mark_hi) mark_from(true, ku, y - 2);
             }
         }
         if (dv) a.mfb[i0 / 8] = (uint8_t)sw;

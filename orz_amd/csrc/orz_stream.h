@@ -344,7 +344,7 @@ class StreamEncoder {
                 fhz_ = take<uint32_t>((size_t)(kNSub + 2) * 256 * 4);
                 fhcm_ = take<uint32_t>((size_t)kHistSub * 256);
                 fhpre_ = take<uint32_t>((size_t)(kHistSub + 1) * 256);
-                fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256);
+                fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256 + 2 * 8192 + 64);
                 ffseen_ = take<uint8_t>(nn);
                 fx0_ = take<uint8_t>(nn);
                 fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
@@ -670,6 +670,8 @@ class StreamEncoder {
         a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
+        a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
+        if (a.dbg & 64) be_.memset(a.stats, 0, 32 * 8);
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
         // anyway), and a block whose parse turns out unstable -- many items lost their source -- is redone with tiles
         // a quarter the size (match-dense, highly repetitive data; never seen on text).
@@ -728,7 +730,10 @@ class StreamEncoder {
                 // the newest active tile is in its first round while tiles are still being started; the two positions behind
                 // the range (the lazy rules look ahead) have never been evaluated either
                 const uint32_t r1lo = step <= ntile ? kPre + t_hi * T : hi;
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, fa0, fa1, fb0, fb1});
+                // the tiles in their first two rounds are evaluated in full; the flips of this step mark below the next step's line
+                const uint32_t r2lo = step >= 2 && step - 2 < ntile ? kPre + (step - 2) * T : (step < 2 ? kPre : hi);
+                const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, fa0, fa1, fb0, fb1});
                 if (a.far && (fa1 > fa0 || fb1 > fb0)) {
                     const FastFarWave ff{a, fa0, fa1, fb0, fb1};
                     if (be_.far_cooperative()) be_.launch_waves(ff.nwaves(), ff, FastFarWave::lds_bytes());
@@ -743,7 +748,7 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, hi});
+                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
@@ -790,6 +795,12 @@ class StreamEncoder {
             if (T <= kSub || (uint64_t)h.total * 200 < (uint64_t)h.nmem || (uint64_t)h.total * 2000 < (uint64_t)n) break;
             T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
             stats.seg_evals -= h.total;  // (count the repairs of the parse that is kept)
+        }
+        if (a.dbg & 64) {  // diagnostics: counters and wall-clock ticks (10 ns) of kernel phases
+            unsigned long long h[32];
+            be_.d2h(h, a.stats, sizeof h);
+            fprintf(stderr, "far: %llu waves, %llu flagged, %llu rounds, %llu trips, %llu members (%llu beyond 16 bytes); ticks: compaction+tail %llu, setup %llu, words %llu, members %llu, resolve %llu | flip: %llu item flips, %llu word flips, walk trips %llu / %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[16], h[17], h[18], h[19]);
         }
         // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
         be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
