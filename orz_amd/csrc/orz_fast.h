@@ -59,10 +59,12 @@ struct FastArgs {
     const uint16_t* kw;         // [n+1] the two bytes at each word-list slot's position
     const uint8_t* wsnap;       // words[] at the block start
     const uint32_t* ORD;        // exact ring ordinals of history item starts
-    const uint64_t* stext;      // [nent][2] 16 leading bytes of each slot's position
+    const uint64_t* stext;      // [nent][2] slot records: the 12 leading bytes of the slot's position | the position << 96 (one 16-byte load
+                                // gives a candidate's text and where it lies)
     const uint32_t* runstart;   // first slot of each (ctx, hash) run
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
     uint32_t far;               // slots searched beyond the tabulated K when a long run shows too few item starts
+    uint32_t far2;              // (experiments) item starts a tile's SECOND-round far search looks at, 0 = as many as the last round's
     uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
@@ -70,7 +72,7 @@ struct FastArgs {
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
     uint64_t* sbits;            // [n/64+8] item starts of the current path, bit per new position
-    uint8_t *mfb, *efb;         // [n/8+40] what vbits / kbits currently hold for each position, bit per position
+    uint8_t *mfb, *efb;         // [n+264] what vbits / kbits currently hold for each position
     uint8_t* dirty;             // [n+264] the position's candidates changed since it was last evaluated (set by FastFlip)
     uint32_t* hz;               // [kNSub][256][4] ring horizons per (subtile, ctx): oldest window offset still within 4094 / 510 item starts,
                                 // and the two values one step earlier (what the evaluations of the previous step saw)
@@ -305,21 +307,31 @@ struct ColScanRows {
         if (g * 64 + 64 >= rows) out[(size_t)rows * 256 + c] = v;
     }
 };
+// Slot record = 12 text bytes + the position.  rec_lcp: common prefix of two records' texts, 12 = all twelve agree
+// (the rest comes from the window).
+constexpr uint32_t kRecText = 12;
+ORZ_D uint32_t rec_pos(uint64_t hi) { return (uint32_t)(hi >> 32); }
+ORZ_D uint32_t rec_lcp(uint64_t lo_a, uint64_t hi_a, uint64_t lo_b, uint64_t hi_b) {
+    const uint64_t x0 = lo_a ^ lo_b;
+    if (x0) return (uint32_t)ctz64(x0) >> 3;
+    const uint32_t x1 = (uint32_t)(hi_a ^ hi_b);
+    return x1 ? 8 + ((uint32_t)ctz64((uint64_t)x1) >> 3) : kRecText;
+}
 // Common prefixes of a new position with its K predecessors in the (ctx, hash) run.
-// One wavefront per 64 consecutive slots: the 16 leading bytes of the 64 + K slots involved are
-// staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 16 bytes go to the window.
+// One wavefront per 64 consecutive slots: the records (12 leading bytes + position) of the 64 + K slots involved are
+// staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 12 bytes go to the window.
 // The rows leave through LDS as well, 64 columns at a time, so that every 64-byte piece of a row is written by
 // four neighbouring lanes in one go (a lane storing its own row eight bytes at a time costs a partial line per store).
-struct FastText {  // the 16 leading bytes of every slot's position, in slot order (one scattered read per slot, once per block)
+struct FastText {  // the slot records, in slot order (one scattered read per slot, once per block)
     const uint8_t* win;
     const uint32_t* epos;
     uint32_t nent;
     uint64_t* stext;
     ORZ_HD void operator()(size_t j) const {
         if (j >= nent) return;
-        const uint8_t* p = win + epos[j];
-        stext[2 * j] = ldu64(p);
-        stext[2 * j + 1] = ldu64(p + 8);
+        const uint32_t q = epos[j];
+        stext[2 * j] = ldu64(win + q);
+        stext[2 * j + 1] = (uint64_t)ldu32(win + q + 8) | ((uint64_t)q << 32);
     }
 };
 struct FastRowsWave {
@@ -331,25 +343,23 @@ struct FastRowsWave {
     uint8_t* rows;
     uint64_t* rdist;   // [n] distance codes of the sampled predecessors (dist_valid)
     static constexpr uint32_t kOutStride = 72;  // bytes per lane in the staging tile (64 + pad against bank conflicts)
-    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 20 + 64 * kOutStride; }
+    static size_t lds_bytes(uint32_t K) { return (size_t)(64 + K) * 16 + 64 * kOutStride; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint64_t* t0 = (uint64_t*)w.lds();            // [64+K] bytes 0..7
-        uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..15
-        uint32_t* ps = (uint32_t*)(t1 + (64 + K));    // [64+K] positions
-        uint8_t* outL = (uint8_t*)(ps + (64 + K));    // [64][kOutStride]
+        uint64_t* t1 = t0 + (64 + K);                 // [64+K] bytes 8..11 | position << 32
+        uint8_t* outL = (uint8_t*)(t1 + (64 + K));    // [64][kOutStride]
         const uint32_t lane = w.lane();
         const int64_t base = (int64_t)w.block() * 64 - K;  // slot of LDS entry 0
         for (uint32_t e = lane; e < 64 + K; e += 64) {
             const int64_t s = base + e;
-            uint32_t q = 0;
             uint64_t a = 0, b = 0;
-            if (s >= 0 && s < (int64_t)nent) { q = epos[s]; a = stext[2 * s]; b = stext[2 * s + 1]; }
-            t0[e] = a; t1[e] = b; ps[e] = q;
+            if (s >= 0 && s < (int64_t)nent) { a = stext[2 * s]; b = stext[2 * s + 1]; }
+            t0[e] = a; t1[e] = b;
         }
         w.sync();
         const uint32_t me = K + lane;
-        const uint32_t p = ps[me];
+        const uint32_t p = rec_pos(t1[me]);
         const bool mine = (int64_t)w.block() * 64 + lane < (int64_t)nent && p >= kPre;
         const uint32_t r = mine ? fast_min(K, rlen[p - kPre]) : 0;
         const uint64_t a0 = t0[me], a1 = t1[me];
@@ -357,7 +367,7 @@ struct FastRowsWave {
             uint64_t codes = 0;
             for (uint32_t m = 0; m < 8; m++) {
                 const uint32_t k = r ? fast_min(dist_sample(m), r - 1) : 0;
-                const uint32_t code = r ? dist_code_up(p - ps[me - 1 - k]) : 255u;
+                const uint32_t code = r ? dist_code_up(p - rec_pos(t1[me - 1 - k])) : 255u;
                 codes |= (uint64_t)code << (8 * m);
             }
             rdist[p - kPre] = codes;
@@ -370,12 +380,9 @@ struct FastRowsWave {
                     uint32_t l = 0;
                     if (k < r) {
                         const uint32_t e = me - 1 - k;
-                        const uint64_t x0 = t0[e] ^ a0;
-                        if (x0) l = (uint32_t)ctz64(x0) >> 3;
-                        else {
-                            const uint64_t x1 = t1[e] ^ a1;
-                            l = x1 ? 8 + ((uint32_t)ctz64(x1) >> 3) : 16 + lcp240u(win + ps[e] + 16, win + p + 16, kMaxLen - 16);
-                        }
+                        const uint64_t hi = t1[e];
+                        l = rec_lcp(t0[e], hi, a0, a1);
+                        if (l == kRecText) l += lcp240u(win + rec_pos(hi) + kRecText, win + p + kRecText, kMaxLen - kRecText);
                     }
                     pack |= (uint64_t)l << (8 * kk);
                 }
@@ -384,7 +391,7 @@ struct FastRowsWave {
             w.sync();
             for (uint32_t it = 0; it < 4; it++) {  // 16 rows per pass, four lanes per 64-byte piece
                 const uint32_t row = it * 16 + (lane >> 2), part = lane & 3;
-                const uint32_t pr = ps[K + row];
+                const uint32_t pr = rec_pos(t1[K + row]);
                 if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {  // (whole 64-byte lines: pieces of a line cost a read-modify-write)
                     const uint64_t v0 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16);
                     const uint64_t v1 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16 + 8);
@@ -398,14 +405,13 @@ struct FastRowsWave {
 };
 
 
-// common prefix of position p (its 16 leading bytes in a0/a1) with the position of slot s: from the text records,
-// through the window only when all 16 bytes agree
-ORZ_D uint32_t far_lcp(const FastArgs& a, uint32_t p, uint64_t a0, uint64_t a1, uint32_t s) {
-    const uint64_t x0 = a.stext[2 * (size_t)s] ^ a0;
-    if (x0) return (uint32_t)ctz64(x0) >> 3;
-    const uint64_t x1 = a.stext[2 * (size_t)s + 1] ^ a1;
-    if (x1) return 8 + ((uint32_t)ctz64(x1) >> 3);
-    return 16 + lcp240u(a.win + a.epos[s] + 16, a.win + p + 16, kMaxLen - 16);
+// common prefix of position p (its record in a0/a1) with the position of slot s (returned in *q): from the slot records,
+// through the window only when all 12 text bytes agree
+ORZ_D uint32_t far_lcp(const FastArgs& a, uint32_t p, uint64_t a0, uint64_t a1, uint32_t s, uint32_t* q) {
+    const uint64_t lo = a.stext[2 * (size_t)s], hi = a.stext[2 * (size_t)s + 1];
+    *q = rec_pos(hi);
+    const uint32_t l = rec_lcp(lo, hi, a0, a1);
+    return l < kRecText ? l : kRecText + lcp240u(a.win + *q + kRecText, a.win + p + kRecText, kMaxLen - kRecText);
 }
 
 // Item starts among the slots [lo, top), newest first, through the summary level: visit(slot) returns false to stop.
@@ -516,7 +522,6 @@ struct FastEval {
         }
         uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
         uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)kj - 64) : 0;
-        if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
         // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts
         const DistBracket d5 = dist_valid(codes, p > h5 ? p - h5 : 0);
         uint32_t v4 = d4.sure;
@@ -555,11 +560,10 @@ struct FastEval {
         }
         const bool stop = full || v4 < r;  // (the ring ends inside the window: nothing older counts either)
         uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
-        if (first) a.farv[i] = 0;  // nothing remembered yet
         uint32_t farflag = 0;
         if (!stop && seen < a.depth && rl > kFastK && a.far) {
             if (fardue) farflag = 0x80 | seen;  // FastFarWave continues from here and merges its answer
-            else {
+            else if (!first) {  // (nothing remembered yet in a first evaluation)
                 const uint32_t fv = a.farv[i];
                 if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
                     if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
@@ -583,8 +587,11 @@ struct FastEval {
             }
         }
 #endif
+        // ---- stores last: a load queued behind scattered stores would wait for them
         a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
         if (first || fardue) a.fseen[i] = (uint8_t)farflag;  // (a position is flagged only by an evaluation in a far-due round)
+        if (first) a.farv[i] = 0;
+        if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
     }
 };
 // Common prefix of a[0..) and b[0..), capped at `cap` (a multiple of 16 is not required), 64 bytes per trip with all
@@ -673,6 +680,8 @@ struct FastFarWave {
                 a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
             }
             bool need = act && cur_top > lo2 && seen < a.depth;
+            // (a tile's second-round search looks at a few item starts only: its last-round search sees every earlier tile final)
+            uint32_t budget = a.far2 && w.block() >= na ? a.far2 : ~0u;
             if (st) { tk = w.wallclock(); atom_add64(&a.stats[9], tk - tk0); tk0 = tk; }
             while (w.ballot(need)) {
                 if (st) atom_add64(&a.stats[3], 1);
@@ -703,7 +712,7 @@ struct FastFarWave {
                 if (st) { tk = w.wallclock(); atom_add64(&a.stats[10], tk - tk0); tk0 = tk; }
                 uint32_t tot = 0;
                 for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
-                const uint32_t want = need ? fast_min(fast_min(tot, 16u), a.depth - seen) : 0;
+                const uint32_t want = need ? fast_min(fast_min(fast_min(tot, 16u), a.depth - seen), budget) : 0;
                 // ---- member number sl of the trip: its slot, its common prefix with p, its position
                 uint32_t l = 0, q = 0, s2 = 0;
                 if (sl < want) {
@@ -718,14 +727,13 @@ struct FastFarWave {
                         }
                         run += cnt;
                     }
-                    const uint64_t x0 = a.stext[2 * (size_t)s2] ^ a0, x1 = a.stext[2 * (size_t)s2 + 1] ^ a1;
-                    q = a.epos[s2];
-                    if (x0) l = (uint32_t)ctz64(x0) >> 3;
-                    else if (x1) l = 8 + ((uint32_t)ctz64(x1) >> 3);
-                    else l = 16 + lcp_wide(win + q + 16, win + p + 16, kMaxLen - 16);
+                    const uint64_t rlo = a.stext[2 * (size_t)s2], rhi = a.stext[2 * (size_t)s2 + 1];  // one 16-byte record: text + position
+                    q = rec_pos(rhi);
+                    l = rec_lcp(rlo, rhi, a0, a1);
+                    if (l == kRecText) l += lcp_wide(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
                 }
                 lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
-                if ((a.dbg & 64) && sl < want) { atom_add64(&a.stats[4], 1); if (l >= 16) atom_add64(&a.stats[5], 1); }
+                if ((a.dbg & 64) && sl < want) { atom_add64(&a.stats[4], 1); if (l >= kRecText) atom_add64(&a.stats[5], 1); }
                 w.sync();
                 if (st) { tk = w.wallclock(); atom_add64(&a.stats[11], tk - tk0); tk0 = tk; }
                 // ---- resolved in order by every lane of the group
@@ -742,7 +750,8 @@ struct FastFarWave {
                         seen++;
                         if (ll == kMaxLen || seen >= a.depth) { fin = true; break; }
                     }
-                    if (fin) need = false;
+                    budget -= budget == ~0u ? 0 : want;
+                    if (fin || budget == 0) need = false;
                     else if (tot > 16) cur_top = sL[gb + 15];      // more item starts in these words: go on below the sixteenth
                     else if (nwords > 16) cur_top = wL[gb + 15] * 64;  // these words are done, older non-empty ones exist
                     else need = false;                              // the range is exhausted
@@ -793,7 +802,7 @@ struct FastFar {
             g_far_stats[1]++;
 #endif
             constexpr uint32_t kBatch = 4;
-            uint32_t cur_top = top;
+            uint32_t cur_top = top, looked = 0;
             bool more = true;
             while (more) {
                 uint32_t sl[kBatch], nb = 0;
@@ -803,8 +812,8 @@ struct FastFar {
 #pragma unroll
                 for (uint32_t k = 0; k < kBatch; k++) {
                     const uint32_t s2 = k < nb ? sl[k] : sl[0];
-                    x0[k] = a.stext[2 * (size_t)s2] ^ a0;
-                    x1[k] = a.stext[2 * (size_t)s2 + 1] ^ a1;
+                    x0[k] = a.stext[2 * (size_t)s2];
+                    x1[k] = a.stext[2 * (size_t)s2 + 1];
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < kBatch; k++) {
@@ -813,12 +822,12 @@ struct FastFar {
                     g_far_stats[3]++;
 #endif
                     const uint32_t s2 = sl[k];
-                    uint32_t l;
-                    if (x0[k]) l = (uint32_t)ctz64(x0[k]) >> 3;
-                    else if (x1[k]) l = 8 + ((uint32_t)ctz64(x1[k]) >> 3);
-                    else l = 16 + lcp240u(win + a.epos[s2] + 16, win + p + 16, kMaxLen - 16);
+                    (void)s2;
+                    const uint32_t q = rec_pos(x1[k]);
+                    uint32_t l = rec_lcp(x0[k], x1[k], a0, a1);
+                    if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
                     if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
-                        const uint32_t q = a.epos[s2];  // ring check, only for candidates that matter (validity is monotone)
+                        // ring check, only for candidates that matter (validity is monotone)
                         if (q < h4) { more = false; break; }
                         if (l > fbest) { fbest = l; fsrc = q; f510 = q >= h5; }
                         if (seen < a.lazy1 && l > fm1) fm1 = l;
@@ -827,6 +836,7 @@ struct FastFar {
                     seen++;
                     if (l == kMaxLen) { more = false; break; }
                     if (seen >= a.depth) { more = false; break; }
+                    if (a.far2 && p >= fb0 && p < fb1 && ++looked >= a.far2) { more = false; break; }
                 }
                 if (nb < kBatch) break;  // the range is exhausted
                 cur_top = sl[nb - 1];
@@ -1134,29 +1144,30 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// Bring the slot-order bitmaps in line with the path (thread per 8 positions), and mark the positions whose next
-// evaluation would see the difference (dirty).  A flipped item start matters to the later positions of its run for which
-// it is among the newest `dmax` item starts below them: walk up the run (slots ascend with the position) until that many
-// set bits have been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped
-// word update matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks:
-// whichever state a walk observes, the union of the marks contains every position whose answer can have changed.
-// A walk loads four slots per trip (independent loads; most walks end in the first trip).  All atomics are
+// Bring the slot-order bitmaps in line with the path (thread per position), and mark the positions whose next evaluation
+// would see the difference (dirty).  A flipped item start matters to the later positions of its run for which it is among
+// the newest `dmax` item starts below them: walk up the run (slots ascend with the position) until that many set bits have
+// been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped word update
+// matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks: whichever state
+// a walk observes, the union of the marks contains every position whose answer can have changed.
+// A thread is one short chain: its loads first (the walks only COUNT the slots to mark, four slots per trip), then
+// its stores and atomics -- on this hardware a load queued behind scattered stores waits for them.  All atomics are
 // fire-and-forget: the summary level v1 is only ever set here (a bit whose word went back to zero costs a walker one
 // wasted load; V1Build makes it exact again at the start of a parse).
 struct FastFlip {
     FastArgs a;
-    uint32_t lo, hi;     // positions y in [lo, hi]; lo - kPre is a multiple of 8
+    uint32_t lo, hi;     // positions y in [lo, hi]
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
     uint32_t mark_hi;    // positions below this one are marked dirty: those beyond are evaluated in the next step whatever their
                          // flags say (FastEval r2lo); 0 = no marking (the repair passes)
-    ORZ_D void mark_from(bool words, uint32_t slot, uint32_t y) const {
+    // slots above `slot` whose positions are to be marked
+    ORZ_D uint32_t walk(bool words, uint32_t slot, uint32_t y) const {
         const uint32_t* pos = words ? a.kpos : a.epos;
         const uint64_t* bits = words ? a.kbits : a.vbits;
         const uint32_t lim = words ? 1u : a.dmax;
         const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
-        uint32_t passed = 0;
-        bool more = true;
-        for (uint32_t s = slot + 1; s < end && more; s += 4) {
+        uint32_t passed = 0, n = 0;
+        for (uint32_t s = slot + 1; s < end; s += 4) {
             if (a.dbg & 64) atom_add64(&a.stats[words ? 19 : 18], 1);
             uint32_t q[4];
 #pragma unroll
@@ -1164,53 +1175,56 @@ struct FastFlip {
             const uint64_t w0 = bits[s >> 6], w1 = bits[(s + 3) >> 6];
 #pragma unroll
             for (uint32_t b = 0; b < 4; b++) {
-                if (!more) break;
                 const uint32_t qq = q[b];
-                if (s + b >= end || qq <= y || qq >= mark_hi) { more = false; break; }  // another run / evaluated anyway next step
-                if (qq >= kPre) a.dirty[qq - kPre] = 1;
+                if (s + b >= end || qq <= y || qq >= mark_hi) return n;  // another run / evaluated anyway next step
+                n++;
                 const uint64_t w = ((s + b) >> 6) == (s >> 6) ? w0 : w1;
-                if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) { more = false; break; }
+                if (((w >> ((s + b) & 63)) & 1) && ++passed >= lim) return n;
             }
+        }
+        return n;
+    }
+    ORZ_D void mark(bool words, uint32_t slot, uint32_t n) const {
+        const uint32_t* pos = words ? a.kpos : a.epos;
+        for (uint32_t k = 0; k < n; k += 4) {
+            uint32_t q[4];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) q[b] = k + b < n ? pos[slot + 1 + k + b] : 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++)
+                if (k + b < n && q[b] >= kPre) a.dirty[q[b] - kPre] = 1;
         }
     }
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t y0 = lo + (uint32_t)tid * 8;
-        if (y0 > hi) return;
-        const uint32_t i0 = y0 - kPre;
+        const uint32_t y = lo + (uint32_t)tid;
+        if (y > hi) return;
+        const uint32_t i = y - kPre;
         const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;  // where the path leaves the range / the block
-        const uint32_t sb = (uint32_t)((a.sbits[i0 / 64] >> (i0 & 63)) & 0xff);
-        uint32_t mfw = a.mfb[i0 / 8], efw = a.efb[i0 / 8];
-        const uint64_t ptw = *reinterpret_cast<const uint64_t*>(a.pt + i0);
-        // what the bitmaps should hold for the eight positions
-        uint32_t sw = 0, ew = 0;
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t y = y0 + k;
-            if (y > hi) { sw |= ((mfw >> k) & 1) << k; ew |= ((efw >> k) & 1) << k; continue; }  // (outside the range: as it is)
-            const uint32_t s = (y == exit_at) | (y < a.len ? (sb >> k) & 1 : 0);
-            sw |= (y < a.len ? s : (mfw >> k) & 1) << k;
-            // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
-            ew |= (y >= kPre + 1 ? (uint32_t)(s && ((ptw >> (8 * k)) & 0xff) != kTyWord) : (efw >> k) & 1) << k;
+        const uint32_t mf = a.mfb[i], ef = a.efb[i];
+        const uint32_t s = (uint32_t)(y == exit_at) | (y < a.len ? (uint32_t)((a.sbits[i / 64] >> (i & 63)) & 1) : 0);
+        const uint32_t sw = y < a.len ? s : mf;
+        // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
+        const uint32_t ew = y >= kPre + 1 ? (uint32_t)(s && a.pt[i] != kTyWord) : ef;
+        const bool dv = sw != mf, de = ew != ef;
+        if (!dv && !de) return;
+        // ---- loads
+        const uint32_t j = dv ? a.idx[y] : 0, ku = de ? a.kidx[y - 2] : 0;
+        const uint32_t nv = dv && y < mark_hi ? walk(false, j, y) : 0;
+        const uint32_t nk = de && y - 2 < mark_hi ? walk(true, ku, y - 2) : 0;
+        // ---- stores
+        if (dv) {
+            if (a.dbg & 64) atom_add64(&a.stats[16], 1);
+            atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+            if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
+            a.mfb[i] = (uint8_t)sw;
+            mark(false, j, nv);
         }
-        const uint32_t dv = sw ^ mfw, de = ew ^ efw;
-        if (!(dv | de)) return;
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t y = y0 + k;
-            if ((dv >> k) & 1) {
-                if (a.dbg & 64) atom_add64(&a.stats[16], 1);
-                const uint32_t j = a.idx[y];
-                atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
-                if ((sw >> k) & 1) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
-                if (y < mark_hi) mark_from(false, j, y);
-            }
-            if ((de >> k) & 1) {
-                if (a.dbg & 64) atom_add64(&a.stats[17], 1);
-                const uint32_t ku = a.kidx[y - 2];
-                atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-                if (y - 2 < mark_hi) mark_from(true, ku, y - 2);
-            }
+        if (de) {
+            if (a.dbg & 64) atom_add64(&a.stats[17], 1);
+            atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+            a.efb[i] = (uint8_t)ew;
+            mark(true, ku, nk);
         }
-        if (dv) a.mfb[i0 / 8] = (uint8_t)sw;
-        if (de) a.efb[i0 / 8] = (uint8_t)ew;
     }
 };
 // item starts per (subtile, ctx) of the current path: one wavefront per 4096-position subtile, lane = 64 positions,
@@ -1456,12 +1470,12 @@ struct FastSource {
             const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(a.win, p)];
             const uint32_t top = j - K;
             const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-            const uint64_t a0 = ldu64(a.win + p), a1 = ldu64(a.win + p + 8);
+            const uint64_t a0 = a.stext[2 * (size_t)j], a1 = a.stext[2 * (size_t)j + 1];
             uint32_t left = cap;
             far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
-                const uint32_t l = far_lcp(a, p, a0, a1, sl);
+                uint32_t q;
+                const uint32_t l = far_lcp(a, p, a0, a1, sl, &q);
                 if (l >= kMinLen && (l >= L || l > best)) {
-                    const uint32_t q = a.epos[sl];
                     if (op - 1 - a.ORD[q] > kRing - 1) { stop = true; return false; }
                     if (l >= L) { found = q; return false; }
                     best = l; bsrc = q;

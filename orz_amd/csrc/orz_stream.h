@@ -335,8 +335,8 @@ class StreamEncoder {
                 fty_ = take<uint8_t>(nn);
                 fnl_ = take<uint8_t>(nn);
                 fpt_ = take<uint8_t>(nn);
-                fmf_ = take<uint8_t>(nn / 8 + 64);
-                fef_ = take<uint8_t>(nn / 8 + 64);
+                fmf_ = take<uint8_t>(nn);
+                fef_ = take<uint8_t>(nn);
                 fdirty_ = take<uint8_t>(nn);
                 frdist_ = take<uint64_t>(nn, false);
                 fwmask_ = take<uint64_t>(nn, false);
@@ -669,6 +669,7 @@ class StreamEncoder {
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
+        a.far2 = getenv("ORZ_FAST_FAR2") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR2")) : 4;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
         if (a.dbg & 64) be_.memset(a.stats, 0, 32 * 8);
@@ -695,7 +696,7 @@ class StreamEncoder {
             const size_t nn = (size_t)n + 264;
             // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
             be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
-            be_.memset(fmf_, 0, nn / 8 + 8); be_.memset(fef_, 0, nn / 8 + 8);
+            be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
             be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
@@ -748,7 +749,7 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch(((size_t)fhi - lo + 8) / 8, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
+                be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
@@ -768,7 +769,7 @@ class StreamEncoder {
             for (int group = 0; group < 64 && !h.done; group++) {
                 const int todo = group == 0 ? 5 : 2;  // (text converges in ~6 passes)
                 for (int k = 0; k < todo; k++, pass++) {
-                    be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u, 0});
+                    be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0});
                     // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
                     be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
                     col_scan(fcm_, nsub, fcp_);
@@ -780,7 +781,7 @@ class StreamEncoder {
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_});
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
-                    be_.launch(((size_t)n + 8) / 8, FastFlip{a, kPre, len, ~0u, 0});
+                    be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
                     be_.inclusive_max_scan_u32(f32_, flaste_, nk);
                     be_.launch(n, FastWordCheck{a, flaste_, rd_out, fctl_});
