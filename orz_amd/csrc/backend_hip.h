@@ -564,7 +564,6 @@ class HipBackend {
     // far-from-the-front limits: measured counter-productive on MI355X (every evaluation of a far segment
     // pre-converges state the front later flies through), so off by default; ORZ_NEAR / ORZ_FAR_DEADLINE_US /
     // ORZ_SKIP_US turn them on for experiments
-    bool far_cooperative() const { return true; }  // FastFarWave (sixteen lanes per position); FastFar is the emulation's form
     uint32_t near_blocks() const { return 0; }
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }

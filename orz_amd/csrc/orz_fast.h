@@ -31,7 +31,7 @@
 namespace orz {
 
 #if !defined(__HIPCC__)
-inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: evaluations, far searches, words walked, members examined)
+inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: list scans, records read, records that went to the window, -)
 #endif
 
 constexpr uint32_t kSub = 4096;                    // positions per ordinal subtile (= path chunk)
@@ -63,9 +63,14 @@ struct FastArgs {
                                 // gives a candidate's text and where it lies)
     const uint32_t* runstart;   // first slot of each (ctx, hash) run
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
-    uint32_t far;               // slots searched beyond the tabulated K when a long run shows too few item starts
-    uint32_t far2;              // (experiments) item starts a tile's SECOND-round far search looks at, 0 = as many as the last round's
-    uint32_t *farv, *farsrc;    // [n+8] what the last far search of a position found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
+    uint32_t far;               // slots the source assignment searches beyond the tabulated K (FastSource)
+    // compact lists: per (ctx, hash) run the records of its FINAL item starts (history, then the tiles that had their last
+    // round, appended by FastRetire) side by side from the run's first slot on, oldest first
+    uint64_t* cl;               // [nent][2] records like stext
+    uint32_t *ccnt, *cnew;      // [keys] records in each run's list / appended by the running FastRetire
+    uint32_t rounds;            // rounds per tile
+    uint32_t csched;            // bit 1: a tile's last round reads the lists again (every earlier tile is in them by then)
+    uint32_t *farv, *farsrc;    // [n+8] what a position's last list scan found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint64_t* v1;               // bit per non-zero word of vbits (V1Build once per parse, then kept in step by FastFlip)
@@ -76,7 +81,6 @@ struct FastArgs {
     uint8_t* dirty;             // [n+264] the position's candidates changed since it was last evaluated (set by FastFlip)
     uint32_t* hz;               // [kNSub][256][4] ring horizons per (subtile, ctx): oldest window offset still within 4094 / 510 item starts,
                                 // and the two values one step earlier (what the evaluations of the previous step saw)
-    uint8_t* fseen;             // [n+8] 0x80 | item starts seen in the tabulated window: the position needs the far search (FastEval -> FastFarWave)
     uint8_t *x0, *x1, *x2;      // path maps: per position, per (chunk, entry), per (tile, entry)
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
     uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
@@ -451,14 +455,20 @@ struct V1Build {  // thread per summary word: 64 words of the bitmap
 };
 
 // ---- one round: the positions of the active range decide from the snapshot ----------------------------
-// A position is evaluated in its tile's first round, and afterwards only when the item starts it looks at changed
-// (FastFlip marks it dirty) or when its tile's far search is due.  Everything a round needs per position is either
-// static and read in position order (its row of common prefixes, the distance codes of its run predecessors, the
-// word-predictor masks) or one window of a bitmap in slot order: no load depends on another one except bitmap <- idx,
-// so a launch is bound by HBM bandwidth, not by a chain of latencies.  The far search -- a real walk -- is not done
-// here: positions that need it are appended to a list and FastFar works the list off densely.
+// A position is evaluated in its tile's first two rounds, and afterwards only when the item starts it looks at changed
+// (FastFlip marks it dirty) or when its tile's list scan is due.  Its candidates, newest first (find_match walks the
+// hash chain of the item starts of (ctx, hash) newest first, src/matcher.rs:135-192), come from two places:
+//   * run predecessors inside the tiles that are still in their rounds: the window of the item-start bitmap (slot order)
+//     against the position's row of tabulated common prefixes -- everything static and read in position order, or one
+//     window of a bitmap: no load depends on another one except bitmap <- idx;
+//   * when the run is deeper than the tabulated K: the run's compact list -- the records of its FINAL item starts
+//     (history + tiles that had their last round) side by side, so the newest of them are one contiguous read whose
+//     address follows from the run's counter.  A tile reads the lists in its first round (what is final then stays so:
+//     the answer is remembered) and, with csched bit 1, again in its last round, when every earlier tile is in them.
+// The window counts from the first tile that is not in the lists yet (`line`), so the two parts never overlap; item
+// starts of the active tiles that lie beyond the K tabulated predecessors are the one thing neither part sees.
 #if !defined(__HIPCC__)
-inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / far-due)
+inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
 #endif
 struct FastEval {
     FastArgs a;
@@ -466,10 +476,21 @@ struct FastEval {
     uint32_t r1lo;      // positions >= r1lo have not been evaluated in this parse yet (the tile in its first round, and beyond)
     uint32_t r2lo;      // positions >= r2lo are evaluated whatever their flags say (the tiles in their first two rounds: after a
                         // tile's first round nearly every position with a predecessor inside the tile is dirty anyway)
-    // [fa0, fa1) and [fb0, fb1): the window offsets (two tiles) whose far search is due in this launch: the tile in its
-    // second round (the first one, against an empty tile, only sketches the path) and the tile in its last one (when
-    // every earlier tile is final); the other rounds merge the remembered answer.
-    uint32_t fa0, fa1, fb0, fb1;
+    uint32_t step;      // tile t runs its round step - t; the lists hold the tiles below max(0, step - rounds)
+    // newest run predecessors (of the first r) at or after `horizon`, from the distance bracket; an uncertain stretch is
+    // settled with the positions themselves (independent loads; validity is monotone, so counting is enough)
+    ORZ_D uint32_t count_from(DistBracket d, uint32_t r, uint32_t j, uint32_t horizon) const {
+        const uint32_t kend = fast_min(r, d.limit);
+        uint32_t v = d.sure;
+        for (uint32_t k0 = d.sure; k0 < kend; k0 += 8) {
+            uint32_t q[8];
+#pragma unroll
+            for (uint32_t b = 0; b < 8; b++) q[b] = k0 + b < kend ? a.epos[j - 1 - (k0 + b)] : 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; b++) v += k0 + b < kend && q[b] >= horizon;
+        }
+        return v;
+    }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
@@ -477,15 +498,21 @@ struct FastEval {
         const uint32_t i = p - kPre;
         const uint32_t rl = a.rlen[i];
         const bool first = p >= r1lo;
-        const bool fardue = (p >= fa0 && p < fa1) || (p >= fb0 && p < fb1);
+        const bool longrun = rl > kFastK;
+        // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules), whether its
+        // list scan is due, and the first tile that was not in the lists at its latest scan
+        const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
+        const bool scan = rnd <= 1 || (rnd == a.rounds && (a.csched & 2));
+        const uint32_t sstep = scan ? step : t + 1;
+        const uint32_t line = kPre + (sstep > a.rounds ? sstep - a.rounds : 0) * a.tile;
         const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
         const uint32_t h4 = hz[0], h4was = hz[2];
-        const bool need = p >= r2lo || dirty || (fardue && rl > kFastK && a.far);
+        const bool need = p >= r2lo || dirty || (scan && longrun);
 #if !defined(__HIPCC__)
         g_eval_stats[0]++;
-        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (fardue && rl > kFastK) g_eval_stats[4]++;
+        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (scan && longrun) g_eval_stats[4]++;
 #endif
         if (!need && h4was == h4) return;
         const uint64_t codes = a.rdist[i];
@@ -522,26 +549,13 @@ struct FastEval {
         }
         uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
         uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)kj - 64) : 0;
-        // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts
+        // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts / not in
+        // the lists yet (long runs only: a short run is all in the window, its lists are never read)
         const DistBracket d5 = dist_valid(codes, p > h5 ? p - h5 : 0);
-        uint32_t v4 = d4.sure;
-        {   // the ring ends inside the window (hot contexts): settle the uncertain stretch with the positions (independent loads)
-            const uint32_t kend = fast_min(r, d4.limit);
-#if !defined(__HIPCC__)
-            if (v4 < kend) g_eval_stats[5]++;
-#endif
-            uint32_t extra = 0;
-            for (uint32_t k0 = d4.sure; k0 < kend; k0 += 8) {  // (eight loads in flight; validity is monotone, so counting is enough)
-                uint32_t q[8];
-#pragma unroll
-                for (uint32_t b = 0; b < 8; b++) q[b] = k0 + b < kend ? a.epos[j - 1 - (k0 + b)] : 0;
-#pragma unroll
-                for (uint32_t b = 0; b < 8; b++) extra += k0 + b < kend && q[b] >= h4;
-            }
-            v4 += extra;
-        }
+        uint32_t v4 = count_from(d4, r, j, h4);
+        const uint32_t vl = longrun ? count_from(dist_valid(codes, p - line), r, j, line) : 64;
         if (a.dbg & 2) v4 = 64;
-        const uint32_t span = fast_min(r, v4);
+        const uint32_t span = fast_min(r, fast_min(v4, vl));
         if (span < 64) mask = span ? mask & (~0ull << (64 - span)) : 0;
         // the candidates, newest first, straight from the registers: no load in this loop
         uint32_t best = 0, bk = 0, m1 = 0, m2 = 0, seen = 0;
@@ -558,26 +572,72 @@ struct FastEval {
                 full = l == kMaxLen;
             }
         }
-        const bool stop = full || v4 < r;  // (the ring ends inside the window: nothing older counts either)
+        const bool stop = full || (v4 < r && v4 <= vl);  // (the ring ends inside the window: nothing older counts either)
         uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
-        uint32_t farflag = 0;
-        if (!stop && seen < a.depth && rl > kFastK && a.far) {
-            if (fardue) farflag = 0x80 | seen;  // FastFarWave continues from here and merges its answer
-            else if (!first) {  // (nothing remembered yet in a first evaluation)
-                const uint32_t fv = a.farv[i];
-                if (fv >> 25) {  // merge (a far candidate is older than every tabulated one: it wins only when strictly longer)
-                    if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
-                    if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
-                    if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
+        if (!stop && longrun) {
+            uint32_t fv = 0;
+            if (scan) {
+                // ---- the run's compact list, newest record first: contiguous, every address known up front
+                const uint32_t key = c * kHash + hash_entry(win + p);
+                const uint32_t cnt = a.ccnt[key];
+                const uint64_t* top = a.cl + 2 * ((size_t)a.runstart[key] + cnt);
+                const uint64_t a0 = ldu64(win + p), a1 = (uint64_t)ldu32(win + p + 8);
+                // (at least a few records whatever the window shows now: the answer is kept for the later rounds)
+                const uint32_t room = a.depth - fast_min(seen, a.depth - fast_min(a.depth, 4u));
+                const uint32_t want = fast_min(room, cnt);
+                uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0, s = seen;
+                bool fin = false;
+#if !defined(__HIPCC__)
+                g_far_stats[0]++;
+#endif
+                for (uint32_t k0 = 0; k0 < want && !fin; k0 += 4) {
+                    uint64_t x0[4], x1[4];
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; b++) {
+                        const uint32_t k = k0 + b < want ? k0 + b : k0;
+                        x0[b] = top[-2 * (int64_t)(k + 1)];
+                        x1[b] = top[-2 * (int64_t)(k + 1) + 1];
+                    }
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; b++) {
+                        if (k0 + b >= want || fin) break;
+                        const uint32_t q = rec_pos(x1[b]);
+                        uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
+                        if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
+#if !defined(__HIPCC__)
+                        g_far_stats[1]++;
+                        if (l >= kRecText) g_far_stats[2]++;
+#endif
+                        if (l > fbest || (s < a.lazy1 && l > fm1) || (s < a.lazy2 && l > fm2)) {
+                            if (q < h4) { fin = true; break; }  // left the ring (asked only for candidates that matter): so did everything older
+                            if (l > fbest) { fbest = l; fsrc = q; f510 = q >= h5; }
+                            if (s < a.lazy1 && l > fm1) fm1 = l;
+                            if (s < a.lazy2 && l > fm2) fm2 = l;
+                        }
+                        s++;
+                        if (l == kMaxLen) fin = true;
+                    }
                 }
+                fv = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+                a.farv[i] = fv;
+                a.farsrc[i] = fsrc;
+            } else {
+                fv = a.farv[i];
             }
+            if (fv >> 25) {  // merge (a list candidate is older than every one of the window: it wins only when strictly longer)
+                if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
+                if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
+                if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
+            }
+        } else if (scan && longrun) {
+            a.farv[i] = 0;  // (nothing beyond the window counts now; nothing is remembered)
         }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
         if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
         if (km & 0x80) kmask &= ~(1ull << 63);
         const uint32_t lwm = kmask ? (uint32_t)((wm >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
 #if !defined(__HIPCC__)
-        if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved && !(fardue && rl > kFastK && a.far)) {  // verify mode: would a skipped position have changed?
+        if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved && !(scan && longrun)) {  // verify mode: would a skipped position have changed?
             const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
             if ((o ^ nw) & ~(1u << 25)) {
                 g_eval_stats[6]++;
@@ -589,268 +649,87 @@ struct FastEval {
 #endif
         // ---- stores last: a load queued behind scattered stores would wait for them
         a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
-        if (first || fardue) a.fseen[i] = (uint8_t)farflag;  // (a position is flagged only by an evaluation in a far-due round)
-        if (first) a.farv[i] = 0;
         if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
     }
 };
-// Common prefix of a[0..) and b[0..), capped at `cap` (a multiple of 16 is not required), 64 bytes per trip with all
-// sixteen loads of a trip in flight: a long match costs a few memory latencies instead of one per eight bytes.
-ORZ_D uint32_t lcp_wide(const uint8_t* x, const uint8_t* y, uint32_t cap) {
-    for (uint32_t off = 0; off < cap; off += 64) {
-        uint64_t d[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) d[k] = ldu64(x + off + 8 * k) ^ ldu64(y + off + 8 * k);
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++)
-            if (d[k]) { const uint32_t l = off + 8 * k + ((uint32_t)ctz64(d[k]) >> 3); return l < cap ? l : cap; }
+// number of set bits among the `count` bits of a bitmap that start at bit `start`
+ORZ_D uint32_t popc_range(const uint64_t* bm, uint32_t start, uint32_t count) {
+    uint32_t n = 0;
+    while (count) {
+        const uint32_t sh = start & 63, take = fast_min(count, 64 - sh);
+        uint64_t w = bm[start >> 6] >> sh;
+        if (take < 64) w &= (1ull << take) - 1;
+        n += (uint32_t)popc64(w);
+        start += take; count -= take;
     }
-    return cap;
+    return n;
 }
-// The far search of the flagged positions: a long run whose tabulated K predecessors hold too few item starts (runs of
-// "interior" 4-grams, zero runs) -- the bitmap is searched further back (up to `far` slots) through its summary level and
-// the prefixes come from the text records.  One wavefront per 32 positions of the two far-due tiles: the flagged ones
-// are compacted in LDS, then sixteen lanes serve one position (four at a time).  A trip takes the sixteen newest
-// non-empty words of the range (found in the summary words: one load), then the up to sixteen newest item starts in
-// them are examined side by side -- text record, window bytes beyond it, ring position, all independent loads -- and
-// resolved in order by every lane of the group with the serial rules of find_match (src/matcher.rs:135-192).  No global
-// atomics, no list in memory; a thread-per-position form of this lasted as long as its longest chain of dependent
-// loads (~90 us a launch).
-struct FastFarWave {
+// A tile has had its last round: its item starts are final (its entry comes from tiles that were final before it).  Their
+// records go to the compact lists, behind what each run holds already, in position order: a run's slots ascend with the
+// position, so an item start's place among the tile's members of its run is the number of set bits between the run's
+// first slot inside the tile and its own (found by galloping down the slot positions; one or two loads on text).  The
+// counters move in a second launch (FastRetireDone), so every member of a run reads the same base: no order depends on
+// the scheduling of the threads.
+struct FastRetire {  // thread per position of the tile
     FastArgs a;
-    uint32_t fa0, fa1, fb0, fb1;  // the far-due ranges (window offsets)
-    static constexpr uint32_t kSeg = 32;   // positions per wavefront: ~7 flagged ones, two rounds of four
-    static size_t lds_bytes() { return kSeg * 4 + 16 + 64 * (8 + 4 + 4 + 4 + 4); }
-    ORZ_HD uint32_t nwaves() const { return (fa1 - fa0 + kSeg - 1) / kSeg + (fb1 - fb0 + kSeg - 1) / kSeg; }
-    // slot index of the n-th set bit (from the top) of the sixteen words w[0..16), word t standing for index top - t
-    ORZ_D static bool nth_from_top(const uint64_t* w, uint32_t n, uint32_t top, uint32_t* out) {
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < 16; t++) {
-            uint64_t mm = w[t];
-            const uint32_t cnt = (uint32_t)popc64(mm);
-            if (n < run + cnt) {
-                for (uint32_t k = n - run; k; k--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
-                *out = (top - t) * 64 + 63 - (uint32_t)clz64(mm);
-                return true;
-            }
-            run += cnt;
-        }
-        return false;
-    }
-    template <class W>
-    ORZ_D void operator()(W& w) const {
-        uint32_t* listL = (uint32_t*)w.lds();
-        uint32_t* cntL = listL + kSeg;
-        uint64_t* mL = (uint64_t*)(cntL + 4);
-        uint32_t* lenL = (uint32_t*)(mL + 64);
-        uint32_t* qL = lenL + 64;
-        uint32_t* sL = qL + 64;
-        uint32_t* wL = sL + 64;
-        const uint8_t* win = a.win;
-        const uint32_t lane = w.lane(), g = lane >> 4, sl = lane & 15, gb = g * 16;
-        // ---- this wavefront's 256 positions; the flagged ones into the LDS list
-        const uint32_t na = (fa1 - fa0 + kSeg - 1) / kSeg;
-        const uint32_t s0 = w.block() < na ? fa0 + w.block() * kSeg : fb0 + (w.block() - na) * kSeg;
-        const uint32_t s1 = fast_min(w.block() < na ? fa1 : fb1, s0 + kSeg);
-        if (lane == 0) *cntL = 0;
-        w.sync();
-        for (uint32_t pos = s0 + lane; pos < s1; pos += 64)
-            if (a.fseen[pos - kPre] & 0x80) listL[atom_fetch_add32(cntL, 1)] = pos - kPre;
-        w.sync();
-        const uint32_t nf = *cntL;
-        const bool st = (a.dbg & 64) && lane == 0;
-        unsigned long long tk0 = st ? w.wallclock() : 0, tk;
-        if (st) { atom_add64(&a.stats[0], 1); atom_add64(&a.stats[1], nf); }
-        for (uint32_t base = 0; base < nf; base += 4) {
-            const bool act = base + g < nf;
-            if (st) { tk = w.wallclock(); atom_add64(&a.stats[8], tk - tk0); tk0 = tk; atom_add64(&a.stats[2], 1); }
-            uint32_t i = 0, p = 0, h4 = 0, h5 = 0, e0 = 0, seen = 0, lo2 = 0, cur_top = 0;
-            uint64_t a0 = 0, a1 = 0;
-            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
-            if (act) {
-                i = listL[base + g]; p = kPre + i;
-                const uint32_t j = a.idx[p], c = hash1(win, p - 1);
-                const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
-                h4 = hz[0]; h5 = hz[1];
-                e0 = a.ev[i];
-                seen = a.fseen[i] & 0x7f;
-                const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
-                cur_top = j - kFastK;  // slots [lo2, cur_top) are searched, newest first
-                lo2 = cur_top - rs > a.far ? cur_top - a.far : rs;
-                a0 = a.stext[2 * (size_t)j]; a1 = a.stext[2 * (size_t)j + 1];
-            }
-            bool need = act && cur_top > lo2 && seen < a.depth;
-            // (a tile's second-round search looks at a few item starts only: its last-round search sees every earlier tile final)
-            uint32_t budget = a.far2 && w.block() >= na ? a.far2 : ~0u;
-            if (st) { tk = w.wallclock(); atom_add64(&a.stats[9], tk - tk0); tk0 = tk; }
-            while (w.ballot(need)) {
-                if (st) atom_add64(&a.stats[3], 1);
-                // ---- the summary words of the range (a word of v1 = 64 words of the bitmap), the newest in lane 0 of the group
-                const uint32_t wtop = need ? (cur_top - 1) >> 6 : 0, wlo = lo2 >> 6, gtop = wtop >> 6, glo = wlo >> 6;
-                uint64_t sm = 0;
-                if (need && gtop >= sl && gtop - sl >= glo) {
-                    const uint32_t gi = gtop - sl;
-                    sm = a.v1[gi];
-                    if (gi == gtop && (wtop & 63) != 63) sm &= (2ull << (wtop & 63)) - 1;
-                    if (gi == glo) sm &= ~0ull << (wlo & 63);
-                }
-                mL[lane] = sm;
-                w.sync();
-                // ---- the sixteen newest non-empty words of the bitmap, one per lane
-                uint32_t nwords = 0;
-                for (uint32_t t = 0; t < 16; t++) nwords += (uint32_t)popc64(mL[gb + t]);
-                uint32_t wi = 0;
-                uint64_t m = 0;
-                if (need && sl < nwords && nth_from_top(mL + gb, sl, gtop, &wi)) {
-                    m = a.vbits[wi];
-                    if (wi == wtop && (cur_top & 63)) m &= (1ull << (cur_top & 63)) - 1;
-                    if (wi == wlo) m &= ~0ull << (lo2 & 63);
-                }
-                w.sync();
-                mL[lane] = m; wL[lane] = wi;
-                w.sync();
-                if (st) { tk = w.wallclock(); atom_add64(&a.stats[10], tk - tk0); tk0 = tk; }
-                uint32_t tot = 0;
-                for (uint32_t t = 0; t < 16; t++) tot += (uint32_t)popc64(mL[gb + t]);
-                const uint32_t want = need ? fast_min(fast_min(fast_min(tot, 16u), a.depth - seen), budget) : 0;
-                // ---- member number sl of the trip: its slot, its common prefix with p, its position
-                uint32_t l = 0, q = 0, s2 = 0;
-                if (sl < want) {
-                    uint32_t run = 0;
-                    for (uint32_t t = 0; t < 16; t++) {
-                        uint64_t mm = mL[gb + t];
-                        const uint32_t cnt = (uint32_t)popc64(mm);
-                        if (sl < run + cnt) {
-                            for (uint32_t k = sl - run; k; k--) mm &= ~(1ull << (63 - (uint32_t)clz64(mm)));
-                            s2 = wL[gb + t] * 64 + 63 - (uint32_t)clz64(mm);
-                            break;
-                        }
-                        run += cnt;
-                    }
-                    const uint64_t rlo = a.stext[2 * (size_t)s2], rhi = a.stext[2 * (size_t)s2 + 1];  // one 16-byte record: text + position
-                    q = rec_pos(rhi);
-                    l = rec_lcp(rlo, rhi, a0, a1);
-                    if (l == kRecText) l += lcp_wide(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-                }
-                lenL[lane] = l; qL[lane] = q; sL[lane] = s2;
-                if ((a.dbg & 64) && sl < want) { atom_add64(&a.stats[4], 1); if (l >= kRecText) atom_add64(&a.stats[5], 1); }
-                w.sync();
-                if (st) { tk = w.wallclock(); atom_add64(&a.stats[11], tk - tk0); tk0 = tk; }
-                // ---- resolved in order by every lane of the group
-                if (need) {
-                    bool fin = false;
-                    for (uint32_t k = 0; k < want; k++) {
-                        const uint32_t ll = lenL[gb + k], qq = qL[gb + k];
-                        if (ll > fbest || (seen < a.lazy1 && ll > fm1) || (seen < a.lazy2 && ll > fm2)) {
-                            if (qq < h4) { fin = true; break; }  // left the ring (only candidates that matter are asked): so did everything older
-                            if (ll > fbest) { fbest = ll; fsrc = qq; f510 = qq >= h5; }
-                            if (seen < a.lazy1 && ll > fm1) fm1 = ll;
-                            if (seen < a.lazy2 && ll > fm2) fm2 = ll;
-                        }
-                        seen++;
-                        if (ll == kMaxLen || seen >= a.depth) { fin = true; break; }
-                    }
-                    budget -= budget == ~0u ? 0 : want;
-                    if (fin || budget == 0) need = false;
-                    else if (tot > 16) cur_top = sL[gb + 15];      // more item starts in these words: go on below the sixteenth
-                    else if (nwords > 16) cur_top = wL[gb + 15] * 64;  // these words are done, older non-empty ones exist
-                    else need = false;                              // the range is exhausted
-                    if (cur_top <= lo2) need = false;
-                }
-                w.sync();
-                if (st) { tk = w.wallclock(); atom_add64(&a.stats[12], tk - tk0); tk0 = tk; }
-            }
-            if (act && sl == 0) {
-                uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
-                a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
-                a.farsrc[i] = fsrc;
-                if (fbest > best) { best = fbest; b510 = f510; }
-                if (fm1 > m1) m1 = fm1;
-                if (fm2 > m2) m2 = fm2;
-                a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
-                a.fseen[i] = 0;
-            }
-        }
-    }
-};
-// The same search as one serial walk per flagged position (thread per position of the far-due ranges).  This is the form
-// the HOST EMULATION runs (tests/emu: every wave collective costs its SIMT emulator 64 context switches, FastFarWave has
-// seven a trip); the GPU never launches it.  tests/test_emu_fast.py runs both forms on the emulator: the same bytes.
-struct FastFar {
-    FastArgs a;
-    uint32_t fa0, fa1, fb0, fb1;  // the far-due ranges (window offsets); thread per position of both
+    uint32_t lo, hi;  // the tile, window offsets [lo, hi)
+    uint32_t* place;  // [n] 1 + place of each appended member among the tile's members of its run (cleared by FastRetireDone)
     ORZ_HD void operator()(size_t tid) const {
-        const uint8_t* win = a.win;
-        {
-            const uint32_t na = fa1 - fa0;
-            const uint32_t p = tid < na ? fa0 + (uint32_t)tid : fb0 + ((uint32_t)tid - na);
-            if (tid >= (size_t)na + (fb1 - fb0)) return;
-            const uint32_t i = p - kPre, j = a.idx[p];
-            if (!(a.fseen[i] & 0x80)) return;
-            const uint32_t c = hash1(win, p - 1);
-            const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
-            const uint32_t h4 = hz[0], h5 = hz[1];
-            const uint32_t e0 = a.ev[i];
-            uint32_t best = e0 & 0xff, m1 = (e0 >> 8) & 0xff, m2 = (e0 >> 16) & 0xff, b510 = (e0 >> 25) & 1;
-            uint32_t seen = a.fseen[i] & 0x7f;
-            const uint32_t rs = a.rlen[i] < 255 ? j - a.rlen[i] : a.runstart[bucket_key(win, p)];
-            const uint32_t top = j - kFastK;  // slots [lo2, top) are searched, newest first
-            const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-            const uint64_t a0 = a.stext[2 * (size_t)j], a1 = a.stext[2 * (size_t)j + 1];
-            uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0;
-#if !defined(__HIPCC__)
-            g_far_stats[1]++;
-#endif
-            constexpr uint32_t kBatch = 4;
-            uint32_t cur_top = top, looked = 0;
-            bool more = true;
-            while (more) {
-                uint32_t sl[kBatch], nb = 0;
-                far_walk(a, lo2, cur_top, [&](uint32_t s2) -> bool { sl[nb++] = s2; return nb < kBatch; });
-                if (nb == 0) break;
-                uint64_t x0[kBatch], x1[kBatch];
-#pragma unroll
-                for (uint32_t k = 0; k < kBatch; k++) {
-                    const uint32_t s2 = k < nb ? sl[k] : sl[0];
-                    x0[k] = a.stext[2 * (size_t)s2];
-                    x1[k] = a.stext[2 * (size_t)s2 + 1];
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < kBatch; k++) {
-                    if (k >= nb || !more) break;
-#if !defined(__HIPCC__)
-                    g_far_stats[3]++;
-#endif
-                    const uint32_t s2 = sl[k];
-                    (void)s2;
-                    const uint32_t q = rec_pos(x1[k]);
-                    uint32_t l = rec_lcp(x0[k], x1[k], a0, a1);
-                    if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-                    if (l > fbest || (seen < a.lazy1 && l > fm1) || (seen < a.lazy2 && l > fm2)) {
-                        // ring check, only for candidates that matter (validity is monotone)
-                        if (q < h4) { more = false; break; }
-                        if (l > fbest) { fbest = l; fsrc = q; f510 = q >= h5; }
-                        if (seen < a.lazy1 && l > fm1) fm1 = l;
-                        if (seen < a.lazy2 && l > fm2) fm2 = l;
-                    }
-                    seen++;
-                    if (l == kMaxLen) { more = false; break; }
-                    if (seen >= a.depth) { more = false; break; }
-                    if (a.far2 && p >= fb0 && p < fb1 && ++looked >= a.far2) { more = false; break; }
-                }
-                if (nb < kBatch) break;  // the range is exhausted
-                cur_top = sl[nb - 1];
-            }
-            a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
-            a.farsrc[i] = fsrc;
-            if (fbest > best) { best = fbest; b510 = f510; }
-            if (fm1 > m1) m1 = fm1;
-            if (fm2 > m2) m2 = fm2;
-            a.ev[i] = best | (m1 << 8) | (m2 << 16) | (e0 & (1u << 24)) | (b510 << 25);
-            a.fseen[i] = 0;
+        const uint32_t p = lo + (uint32_t)tid;
+        if (p >= hi) return;
+        const uint32_t i = p - kPre;
+        if (!a.mfb[i]) return;
+        const uint32_t j = a.idx[p], key = bucket_key(a.win, p), rl = a.rlen[i];
+        const uint32_t rs = a.runstart[key];
+        const uint32_t maxk = rl < 255 ? rl : j - rs;  // run slots below j
+        uint32_t good = 0, bad = maxk + 1;             // slots j - 1 .. j - good hold positions of this tile, slot j - bad does not
+        for (uint32_t k = 1; k <= maxk; k <<= 1) {
+            if (a.epos[j - k] >= lo) good = k; else { bad = k; break; }
         }
+        while (good + 1 < bad) {
+            const uint32_t mid = (good + bad) / 2;
+            if (a.epos[j - mid] >= lo) good = mid; else bad = mid;
+        }
+        const uint32_t at = popc_range(a.vbits, j - good, good);
+        const uint64_t t0 = a.stext[2 * (size_t)j], t1 = a.stext[2 * (size_t)j + 1];
+        uint64_t* dst = a.cl + 2 * ((size_t)rs + a.ccnt[key] + at);
+        dst[0] = t0; dst[1] = t1;
+        atom_add32(&a.cnew[key], 1);
+        place[i] = at + 1;
     }
 };
+struct FastRetireDone {  // the first member of each (run, tile) group moves the run's counter
+    FastArgs a;
+    uint32_t lo, hi;
+    uint32_t* place;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t p = lo + (uint32_t)tid;
+        if (p >= hi) return;
+        const uint32_t v = place[p - kPre];
+        if (!v) return;
+        place[p - kPre] = 0;
+        if (v != 1) return;
+        const uint32_t key = bucket_key(a.win, p);
+        a.ccnt[key] += a.cnew[key];
+        a.cnew[key] = 0;
+    }
+};
+struct FastListInit {  // thread per slot: the history slots of a run are final item starts -- the head of its list
+    const uint8_t* win;
+    const uint32_t* epos;
+    const uint64_t* stext;
+    uint32_t nent;
+    uint64_t* cl;
+    uint32_t* ccnt;  // (zeroed)
+    ORZ_HD void operator()(size_t j) const {
+        if (j >= nent) return;
+        const uint32_t q = epos[j];
+        if (q >= kPre) return;
+        cl[2 * j] = stext[2 * j]; cl[2 * j + 1] = stext[2 * j + 1];
+        atom_add32(&ccnt[bucket_key(win, q)], 1);
+    }
+};
+
 // Ring horizons of the subtiles [s0, s1] per context: the oldest window offset from which at most `limit` item starts of
 // the context lie before the END of the subtile -- candidates at or after it are inside the ring (limit 4094 - margin) /
 // cost fewer than 8 offset bits (510), whatever the position inside the subtile (conservative by the subtile's own

@@ -276,7 +276,7 @@ class StreamEncoder {
             if (frounds_ < 1 || frounds_ > 64) throw std::runtime_error("fast rounds must be in [1, 64]");
             // run predecessors tabulated per position: item starts are about a quarter of a run's positions on text and far
             // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
-            fK_ = kFastK;  // (deeper runs are searched through the bitmap + the text records: FastFar)
+            fK_ = kFastK;  // (deeper runs: the compact lists of final item starts, FastEval / FastRetire)
             if (const char* u = getenv("ORZ_FAST_UNIT")) unit_ = (uint32_t)atoi(u);
             if (unit_ < (1u << 20) || unit_ > kNewMax || unit_ % kSub) throw std::runtime_error("ORZ_FAST_UNIT must be a multiple of 4096 in [1 MiB, 16 MiB]");
             cur_unit_ = unit_;
@@ -345,7 +345,6 @@ class StreamEncoder {
                 fhcm_ = take<uint32_t>((size_t)kHistSub * 256);
                 fhpre_ = take<uint32_t>((size_t)(kHistSub + 1) * 256);
                 fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256 + 2 * 8192 + 64);
-                ffseen_ = take<uint8_t>(nn);
                 fx0_ = take<uint8_t>(nn);
                 fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
                 fx2_ = take<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
@@ -361,6 +360,9 @@ class StreamEncoder {
                 fcstart_ = take<uint32_t>(260);
                 ffarv_ = take<uint32_t>(nn, false);
                 ffarsrc_ = take<uint32_t>(nn, false);
+                fcl_ = take<uint64_t>((size_t)kWLen * 2, false);
+                fccnt_ = take<uint32_t>(kNumKeys + 1);
+                fcnew_ = take<uint32_t>(kNumKeys + 1);
             }
             f32_ = take<uint32_t>(kWLen, false);
             sc32_ = take<uint32_t>(kWLen, false);
@@ -667,9 +669,10 @@ class StreamEncoder {
         a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
         a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
-        a.fseen = ffseen_; a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
+        a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
+        a.csched = getenv("ORZ_FAST_CSCHED") ? (uint32_t)atoi(getenv("ORZ_FAST_CSCHED")) : 3;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
-        a.far2 = getenv("ORZ_FAST_FAR2") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR2")) : 4;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
         if (a.dbg & 64) be_.memset(a.stats, 0, 32 * 8);
@@ -701,6 +704,10 @@ class StreamEncoder {
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
+            // compact lists: every run starts with its history slots
+            be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
+            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);
+            be_.launch(nent, FastListInit{win, epos_, fstext_, nent, fcl_, fccnt_});
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
@@ -723,23 +730,13 @@ class StreamEncoder {
                 const uint32_t hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)kPre + (uint64_t)(t_hi + 1) * T);
                 const uint32_t hi2 = std::min(len, hi + 2);
                 be_.timed_begin();
-                // far searches: the tile in its last round, and the tile in its second round
-                uint32_t fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;
-                static const int far_sched = getenv("ORZ_FAST_FARSCHED") ? atoi(getenv("ORZ_FAST_FARSCHED")) : 3;  // bit 0: last round, bit 1: second round
-                if ((far_sched & 1) && step >= R && step - R < ntile) { fa0 = kPre + (step - R) * T; fa1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fa0 + T); }
-                if ((far_sched & 2) && R > 2 && step >= 2 && step - 2 < ntile) { fb0 = kPre + (step - 2) * T; fb1 = (uint32_t)std::min<uint64_t>(len, (uint64_t)fb0 + T); }
                 // the newest active tile is in its first round while tiles are still being started; the two positions behind
                 // the range (the lazy rules look ahead) have never been evaluated either
                 const uint32_t r1lo = step <= ntile ? kPre + t_hi * T : hi;
                 // the tiles in their first two rounds are evaluated in full; the flips of this step mark below the next step's line
                 const uint32_t r2lo = step >= 2 && step - 2 < ntile ? kPre + (step - 2) * T : (step < 2 ? kPre : hi);
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, fa0, fa1, fb0, fb1});
-                if (a.far && (fa1 > fa0 || fb1 > fb0)) {
-                    const FastFarWave ff{a, fa0, fa1, fb0, fb1};
-                    if (be_.far_cooperative()) be_.launch_waves(ff.nwaves(), ff, FastFarWave::lds_bytes());
-                    else be_.launch((size_t)(fa1 - fa0) + (fb1 - fb0), FastFar{a, fa0, fa1, fb0, fb1});  // (host emulation: see FastFar)
-                }
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -754,6 +751,12 @@ class StreamEncoder {
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
                 be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
+                // the tile that has just had its last round is final: its item starts join the compact lists
+                if (step >= R && step - R + 1 < ntile) {  // (every tile but the last: a later tile's scan will read it)
+                    const uint32_t rlo = kPre + (step - R) * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
+                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
+                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                }
                 stats.sweeps++;
             }
             capture.on = false;
@@ -797,11 +800,10 @@ class StreamEncoder {
             T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
             stats.seg_evals -= h.total;  // (count the repairs of the parse that is kept)
         }
-        if (a.dbg & 64) {  // diagnostics: counters and wall-clock ticks (10 ns) of kernel phases
+        if (a.dbg & 64) {  // diagnostics: counters of the flips
             unsigned long long h[32];
             be_.d2h(h, a.stats, sizeof h);
-            fprintf(stderr, "far: %llu waves, %llu flagged, %llu rounds, %llu trips, %llu members (%llu beyond 16 bytes); ticks: compaction+tail %llu, setup %llu, words %llu, members %llu, resolve %llu | flip: %llu item flips, %llu word flips, walk trips %llu / %llu\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[16], h[17], h[18], h[19]);
+            fprintf(stderr, "flip: %llu item flips, %llu word flips, walk trips %llu / %llu\n", h[16], h[17], h[18], h[19]);
         }
         // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
         be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
@@ -1035,13 +1037,14 @@ class StreamEncoder {
     uint32_t ftile_ = 131072, frounds_ = 4, fK_ = 64;
     bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
-            *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr, *ffseen_ = nullptr;
+            *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr;
     uint16_t *fkw_ = nullptr, *fkmeta_ = nullptr;
     uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
     uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr;
     uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
              *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
-    uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr;
+    uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr, *fcl_ = nullptr;
+    uint32_t *fccnt_ = nullptr, *fcnew_ = nullptr;
     FastCtl* fctl_ = nullptr;
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;

@@ -28,7 +28,6 @@ struct EmuBackend {
     void sync() {}
     uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
     uint32_t handoff_deadline() const { return 0; }
-    bool far_cooperative() const { return std::getenv("ORZ_EMU_FARWAVE") != nullptr; }
     uint32_t near_blocks() const { return 16; }  // small windows here: exercise the far-wave paths too
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }
@@ -178,8 +177,8 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
             std::fprintf(stderr, "eval: %llu positions visited, %llu evaluated (first round %llu, dirty %llu, far due %llu), %llu settled the ring end with positions; verify: %llu skipped would differ (%llu in lwm)\n", orz::g_eval_stats[0],
                          orz::g_eval_stats[1], orz::g_eval_stats[2], orz::g_eval_stats[3], orz::g_eval_stats[4], orz::g_eval_stats[5], orz::g_eval_stats[6], orz::g_eval_stats[7]);
         if (std::getenv("ORZ_FAR_STATS"))
-            std::fprintf(stderr, "far search: %llu evaluations, %llu far searches, %llu bitmap words, %llu members examined\n",
-                         orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2], orz::g_far_stats[3]);
+            std::fprintf(stderr, "compact lists: %llu scans, %llu records read, %llu of them continued in the window\n",
+                         orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2]);
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());

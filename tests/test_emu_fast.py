@@ -123,17 +123,13 @@ def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle):
     assert abs(len(big) - len(ref)) <= 0.003 * len(ref)
 
 
-
-def test_cooperative_far_search_gives_the_same_stream(emu, oracle, monkeypatch):
-    """FastFarWave (sixteen lanes per flagged position, what the GPU runs) against FastFar (one serial walk per position,
-    what the emulation runs by default because every wave collective is costly on the SIMT emulator): the very same
-    bytes -- on data whose runs are deep enough to need the far search (zero runs with noise, text)"""
+@pytest.mark.parametrize("sched", ["1", "3"])
+def test_compact_list_schedules(emu, oracle, monkeypatch, sched):
+    """deep runs take their older candidates from the compact lists of final item starts (FastEval / FastRetire): a tile
+    reads them in its first round and (schedule 3, the default) again in its last -- either way the stream is valid and
+    its size stays in the band, on data whose runs are deep (zero runs with noise, text)"""
     import corpus
 
-    for data in (_data.zeros_noise(300_000), corpus.enwik_like(700_000)):
-        a, _ = emu.fast(data, cfg=LEVELS[1])
-        monkeypatch.setenv("ORZ_EMU_FARWAVE", "1")
-        b, _ = emu.fast(data, cfg=LEVELS[1])
-        monkeypatch.delenv("ORZ_EMU_FARWAVE")
-        assert a == b
-        assert oracle.decode(b)[0] == data
+    monkeypatch.setenv("ORZ_FAST_CSCHED", sched)
+    _roundtrip(emu, oracle, _data.zeros_noise(300_000), 1, band=0.03)
+    _roundtrip(emu, oracle, corpus.enwik_like(700_000), 1, band=0.005)
