@@ -70,6 +70,8 @@ struct FastArgs {
     uint32_t *ccnt, *cnew;      // [keys] records in each run's list / appended by the running FastRetire
     uint32_t rounds;            // rounds per tile
     uint32_t csched;            // bit 1: a tile's last round reads the lists again (every earlier tile is in them by then)
+    uint32_t clag;              // a tile joins the lists this many steps after its last round (1: FastRetire runs beside the
+                                // next step instead of behind this one)
     uint32_t *farv, *farsrc;    // [n+8] what a position's last list scan found: len | lz1 << 8 | lz2 << 16 | ro510 << 24 | valid << 25
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
@@ -476,7 +478,7 @@ struct FastEval {
     uint32_t r1lo;      // positions >= r1lo have not been evaluated in this parse yet (the tile in its first round, and beyond)
     uint32_t r2lo;      // positions >= r2lo are evaluated whatever their flags say (the tiles in their first two rounds: after a
                         // tile's first round nearly every position with a predecessor inside the tile is dirty anyway)
-    uint32_t step;      // tile t runs its round step - t; the lists hold the tiles below max(0, step - rounds)
+    uint32_t step;      // tile t runs its round step - t; the lists hold the tiles below max(0, step - rounds - clag)
     // newest run predecessors (of the first r) at or after `horizon`, from the distance bracket; an uncertain stretch is
     // settled with the positions themselves (independent loads; validity is monotone, so counting is enough)
     ORZ_D uint32_t count_from(DistBracket d, uint32_t r, uint32_t j, uint32_t horizon) const {
@@ -504,7 +506,7 @@ struct FastEval {
         const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
         const bool scan = rnd <= 1 || (rnd == a.rounds && (a.csched & 2));
         const uint32_t sstep = scan ? step : t + 1;
-        const uint32_t line = kPre + (sstep > a.rounds ? sstep - a.rounds : 0) * a.tile;
+        const uint32_t line = kPre + (sstep > a.rounds + a.clag ? sstep - a.rounds - a.clag : 0) * a.tile;
         const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
@@ -1029,7 +1031,7 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
 // been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped word update
 // matters up to the next set bit above it.  Bits that flip concurrently are covered by their own walks: whichever state
 // a walk observes, the union of the marks contains every position whose answer can have changed.
-// A thread is one short chain: its loads first (the walks only COUNT the slots to mark, four slots per trip), then
+// A thread is one short chain: its loads first (the walks only COUNT the slots to mark, sixteen slots per trip), then
 // its stores and atomics -- on this hardware a load queued behind scattered stores waits for them.  All atomics are
 // fire-and-forget: the summary level v1 is only ever set here (a bit whose word went back to zero costs a walker one
 // wasted load; V1Build makes it exact again at the start of a parse).
@@ -1040,20 +1042,21 @@ struct FastFlip {
     uint32_t mark_hi;    // positions below this one are marked dirty: those beyond are evaluated in the next step whatever their
                          // flags say (FastEval r2lo); 0 = no marking (the repair passes)
     // slots above `slot` whose positions are to be marked
+    static constexpr uint32_t kTrip = 16;  // slots per trip: a walk is at most four rounds of independent loads
     ORZ_D uint32_t walk(bool words, uint32_t slot, uint32_t y) const {
         const uint32_t* pos = words ? a.kpos : a.epos;
         const uint64_t* bits = words ? a.kbits : a.vbits;
         const uint32_t lim = words ? 1u : a.dmax;
         const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
         uint32_t passed = 0, n = 0;
-        for (uint32_t s = slot + 1; s < end; s += 4) {
+        for (uint32_t s = slot + 1; s < end; s += kTrip) {
             if (a.dbg & 64) atom_add64(&a.stats[words ? 19 : 18], 1);
-            uint32_t q[4];
+            uint32_t q[kTrip];
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++) q[b] = s + b < end ? pos[s + b] : 0;
-            const uint64_t w0 = bits[s >> 6], w1 = bits[(s + 3) >> 6];
+            for (uint32_t b = 0; b < kTrip; b++) q[b] = s + b < end ? pos[s + b] : 0;
+            const uint64_t w0 = bits[s >> 6], w1 = bits[(s + kTrip - 1) >> 6];
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++) {
+            for (uint32_t b = 0; b < kTrip; b++) {
                 const uint32_t qq = q[b];
                 if (s + b >= end || qq <= y || qq >= mark_hi) return n;  // another run / evaluated anyway next step
                 n++;
@@ -1065,12 +1068,12 @@ struct FastFlip {
     }
     ORZ_D void mark(bool words, uint32_t slot, uint32_t n) const {
         const uint32_t* pos = words ? a.kpos : a.epos;
-        for (uint32_t k = 0; k < n; k += 4) {
-            uint32_t q[4];
+        for (uint32_t k = 0; k < n; k += kTrip) {
+            uint32_t q[kTrip];
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++) q[b] = k + b < n ? pos[slot + 1 + k + b] : 0;
+            for (uint32_t b = 0; b < kTrip; b++) q[b] = k + b < n ? pos[slot + 1 + k + b] : 0;
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++)
+            for (uint32_t b = 0; b < kTrip; b++)
                 if (k + b < n && q[b] >= kPre) a.dirty[q[b] - kPre] = 1;
         }
     }

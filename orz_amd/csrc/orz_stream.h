@@ -672,6 +672,7 @@ class StreamEncoder {
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
         a.csched = getenv("ORZ_FAST_CSCHED") ? (uint32_t)atoi(getenv("ORZ_FAST_CSCHED")) : 3;
+        a.clag = getenv("ORZ_FAST_CLAG") ? (uint32_t)(atoi(getenv("ORZ_FAST_CLAG")) != 0) : 0;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
@@ -738,6 +739,18 @@ class StreamEncoder {
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step});
                 be_.timed_end();
+                // A tile whose last round is over is final: its item starts join the compact lists (every tile a later scan
+                // will read).  With clag the tile of the step before is appended on a side branch beside this step's path
+                // extraction (FastEval above has read the lists; the next one waits for the branch).
+                const uint32_t rt = step - R - a.clag;  // (wraps below zero: no tile yet)
+                const bool retire = step >= R + a.clag && rt + a.clag + 2 <= ntile;
+                const uint32_t rlo = kPre + rt * T, rhi = retire ? (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T) : 0;
+                if (retire && a.clag) {
+                    be_.side_begin(1);
+                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
+                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                    be_.side_end();
+                }
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
@@ -745,18 +758,21 @@ class StreamEncoder {
                 be_.timed_end(3);
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
-                const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
-                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them
+                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them: a side
+                // branch beside the flips (both only need the path)
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
+                be_.side_begin(0);
                 be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
                 be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
-                // the tile that has just had its last round is final: its item starts join the compact lists
-                if (step >= R && step - R + 1 < ntile) {  // (every tile but the last: a later tile's scan will read it)
-                    const uint32_t rlo = kPre + (step - R) * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
+                be_.side_end();
+                const uint32_t fhi = std::min(len, hi + 240);
+                be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
+                if (retire && !a.clag) {
                     be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
                     be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
                 }
+                be_.side_join(0);
+                if (retire && a.clag) be_.side_join(1);
                 stats.sweeps++;
             }
             capture.on = false;
