@@ -359,7 +359,6 @@ class StreamEncoder {
                 fctl_ = take<FastCtl>(1);
                 fcstart_ = take<uint32_t>(260);
                 ffarv_ = take<uint32_t>(nn, false);
-                ffarsrc_ = take<uint32_t>(nn, false);
                 fcl_ = take<uint64_t>((size_t)kWLen * 2, false);
                 fccnt_ = take<uint32_t>(kNumKeys + 1);
                 fcnew_ = take<uint32_t>(kNumKeys + 1);
@@ -666,13 +665,11 @@ class StreamEncoder {
         a.lazy2 = (uint32_t)cfg_.lazy2; a.tile = ftile_; a.dmax = dmax_; a.nent = nent; a.nk = nk;
         a.idx = idx_; a.epos = epos_; a.kidx = kidx_; a.kpos = kpos_; a.krun = krun_; a.rows = frows_; a.rlen = frlen_;
         a.rdist = frdist_; a.wmask = fwmask_; a.kmeta = fkmeta_; a.hpre = fhpre_;
-        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_; a.farsrc = ffarsrc_;
+        a.kw = fkw_; a.wsnap = wsnap_; a.ORD = ORD_; a.stext = fstext_; a.runstart = runstart_; a.farv = ffarv_;
         a.far = getenv("ORZ_FAST_FAR") ? (uint32_t)atoi(getenv("ORZ_FAST_FAR")) : 16384; a.vbits = vbits_; a.kbits = kbits_; a.v1 = v1_; a.ev = fev_;
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
-        a.csched = getenv("ORZ_FAST_CSCHED") ? (uint32_t)atoi(getenv("ORZ_FAST_CSCHED")) : 3;
-        a.clag = getenv("ORZ_FAST_CLAG") ? (uint32_t)(atoi(getenv("ORZ_FAST_CLAG")) != 0) : 0;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
@@ -714,6 +711,12 @@ class StreamEncoder {
             // ring horizons of the first tile (no counts yet: the history alone)
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt});
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
+            // the compact lists' answers for the tile whose first round is step `nx` (FastListScan)
+            auto list_scan = [&](uint32_t nx) {
+                if (nx < 1 || nx - 1 >= ntile) return;
+                const uint32_t lo = kPre + (nx - 1) * T, hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T + 2);
+                be_.launch(hi - lo, FastListScan{a, lo, hi});
+            };
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
@@ -725,6 +728,8 @@ class StreamEncoder {
             } capture{be_, use_graph && !replayed};
             if (capture.on) be_.graph_capture_begin();
             if (replayed) stats.sweeps += ntile + R - 1;
+            if (!replayed) list_scan(1);  // (the first tile's first round: the history alone)
+            bool scan_pending = false;
             for (uint32_t step = 1; step <= ntile + R - 1 && !replayed; step++) {
                 const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
                 const uint32_t lo = kPre + t_lo * T;
@@ -739,18 +744,7 @@ class StreamEncoder {
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step});
                 be_.timed_end();
-                // A tile whose last round is over is final: its item starts join the compact lists (every tile a later scan
-                // will read).  With clag the tile of the step before is appended on a side branch beside this step's path
-                // extraction (FastEval above has read the lists; the next one waits for the branch).
-                const uint32_t rt = step - R - a.clag;  // (wraps below zero: no tile yet)
-                const bool retire = step >= R + a.clag && rt + a.clag + 2 <= ntile;
-                const uint32_t rlo = kPre + rt * T, rhi = retire ? (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T) : 0;
-                if (retire && a.clag) {
-                    be_.side_begin(1);
-                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
-                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
-                    be_.side_end();
-                }
+                if (scan_pending) { be_.side_join(1); scan_pending = false; }  // (the branch of the step before: see below)
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
@@ -767,12 +761,23 @@ class StreamEncoder {
                 be_.side_end();
                 const uint32_t fhi = std::min(len, hi + 240);
                 be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
-                if (retire && !a.clag) {
-                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
-                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
-                }
                 be_.side_join(0);
-                if (retire && a.clag) be_.side_join(1);
+                // The tile that has just had its last round is final: its item starts join the compact lists (while a later
+                // tile will still read them), then the lists' answers for the tile that starts next are worked out -- a side
+                // branch beside the next step's FastEval, which reads only the window; FastDecide waits for it.
+                const uint32_t rt = step - R;  // (wraps below zero: no tile yet)
+                const bool retire = step >= R && rt + R < ntile;  // (tile rt + R starts next and reads tiles <= rt)
+                if (step < ntile) {
+                    be_.side_begin(1);
+                    if (retire) {
+                        const uint32_t rlo = kPre + rt * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
+                        be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
+                        be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                    }
+                    list_scan(step + 1);
+                    be_.side_end();
+                    scan_pending = true;
+                }
                 stats.sweeps++;
             }
             capture.on = false;
@@ -1058,7 +1063,7 @@ class StreamEncoder {
     uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
     uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr;
     uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
-             *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr, *ffarsrc_ = nullptr;
+             *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr, *fcl_ = nullptr;
     uint32_t *fccnt_ = nullptr, *fcnew_ = nullptr;
     FastCtl* fctl_ = nullptr;

