@@ -676,7 +676,11 @@ class HipBackend {
     }
     template <class K>
     void launch_group(const K& k) {
-        const size_t lds = k.lds_bytes();
+        size_t lds = k.lds_bytes();
+        // more than 64 KB of dynamic LDS (a CU of gfx950 has 160 KB) has to be asked for once per kernel
+        static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&orz_group_kernel<K>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::kLdsMax) == hipSuccess;
+        if (lds > 64 * 1024 && !big_ok) lds = 0;  // (the kernel then works on global memory)
         hipLaunchKernelGGL(orz_group_kernel<K>, dim3(1), dim3(1024), lds, stream_, k, lds != 0);
         ORZ_HIP_CHECK(hipGetLastError());
     }

@@ -31,7 +31,7 @@
 namespace orz {
 
 #if !defined(__HIPCC__)
-inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: list scans, records read, records that went to the window, -)
+inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: list scans, records read, records that went to the window, item starts taken from below the window)
 #endif
 
 constexpr uint32_t kSub = 4096;                    // positions per ordinal subtile (= path chunk)
@@ -63,7 +63,8 @@ struct FastArgs {
                                 // gives a candidate's text and where it lies)
     const uint32_t* runstart;   // first slot of each (ctx, hash) run
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
-    uint32_t far;               // slots the source assignment searches beyond the tabulated K (FastSource)
+    uint32_t far;               // slots searched beyond the tabulated K through the bitmap (FastSource; FastEval for item starts not in the lists yet)
+    uint32_t near;              // item starts a scan takes from there (0 = none)
     // compact lists: per (ctx, hash) run the records of its FINAL item starts (history, then the tiles that had their last
     // round, appended by FastRetire) side by side from the run's first slot on, oldest first
     uint64_t* cl;               // [nent][2] records like stext
@@ -73,7 +74,7 @@ struct FastArgs {
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint64_t* v1;               // bit per non-zero word of vbits (V1Build once per parse, then kept in step by FastFlip)
-    uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25 | the run's list counts too << 26
+    uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
     uint64_t* sbits;            // [n/64+8] item starts of the current path, bit per new position
     uint8_t *mfb, *efb;         // [n+264] what vbits / kbits currently hold for each position
@@ -455,21 +456,20 @@ struct V1Build {  // thread per summary word: 64 words of the bitmap
 
 // ---- one round: the positions of the active range decide from the snapshot ----------------------------
 // A position is evaluated in its tile's first two rounds, and afterwards only when the item starts it looks at changed
-// (FastFlip marks it dirty).  Its candidates, newest first (find_match walks the
-// hash chain of the item starts of (ctx, hash) newest first, src/matcher.rs:135-192), come from two places:
-//   * run predecessors inside the tiles that are still in their rounds: the window of the item-start bitmap (slot order)
-//     against the position's row of tabulated common prefixes -- everything static and read in position order, or one
-//     window of a bitmap: no load depends on another one except bitmap <- idx;
-//   * when the run is deeper than the tabulated K: the run's compact list -- the records of its FINAL item starts
-//     (history + tiles that had their last round) side by side, so the newest of them are one contiguous read whose
-//     address follows from the run's counter.  The lists are read once per position, before its tile's first round
-//     (FastListScan: what is final then stays so, the answer is remembered and merged by FastDecide).  Reading them
-//     again in the last round, when every earlier tile is in them, measured worse (8 MB text: -0.07 % vs -0.20 % against
-//     the oracle): the window then counts from the tile's own start and shows fewer candidates.
-// The window counts from the first tile that was not in the lists (`line`), so the two parts never overlap; item
-// starts of the active tiles that lie beyond the K tabulated predecessors are the one thing neither part sees.  Both
-// parts together may look at more than `depth` candidates -- the depth is the reference's speed limit, not a rule of the
-// format -- which is why this parse can come out smaller than the reference's.
+// (FastFlip marks it dirty) or when its tile's scan is due.  Its candidates, newest first (find_match walks the hash
+// chain of the item starts of (ctx, hash) newest first, src/matcher.rs:135-192), come from three places:
+//   1. the K run predecessors tabulated in its row: the window of the item-start bitmap (slot order) against the row --
+//      static data read in position order and one window of a bitmap, no load depends on another one except bitmap <- idx;
+//   and, when the run is deeper than K (a scan: in the tile's first round and again in its last one, when every earlier
+//   tile is final; the answer is remembered in between),
+//   2. the next few item starts below the window that are not in the lists yet (tiles still in their rounds), found
+//      through the bitmap's summary level -- a short chain of dependent loads, which is what sparse deep runs (zero
+//      runs, long periods: an item start every few hundred slots) live on;
+//   3. the run's compact list -- the records of its FINAL item starts (history + tiles that had their last round) side
+//      by side, so the newest of them are one contiguous read whose address follows from the run's counter.  The records
+//      of item starts that the window shows as well (set bits of slots below `cline`) are skipped.
+// All parts together may look at more than `depth` candidates -- the depth is the reference's speed limit, not a rule of
+// the format -- which is why this parse can come out smaller than the reference's.
 #if !defined(__HIPCC__)
 inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
 #endif
@@ -479,7 +479,8 @@ struct FastEval {
     uint32_t r1lo;      // positions >= r1lo have not been evaluated in this parse yet (the tile in its first round, and beyond)
     uint32_t r2lo;      // positions >= r2lo are evaluated whatever their flags say (the tiles in their first two rounds: after a
                         // tile's first round nearly every position with a predecessor inside the tile is dirty anyway)
-    uint32_t step;      // tile t runs its round step - t; the lists hold the tiles below max(0, step - rounds)
+    uint32_t step;      // tile t runs its round step - t
+    uint32_t cline;     // window offset below which every item start is in the compact lists (the tiles retired so far)
     // newest run predecessors (of the first r) at or after `horizon`, from the distance bracket; an uncertain stretch is
     // settled with the positions themselves (independent loads; validity is monotone, so counting is enough)
     ORZ_D uint32_t count_from(DistBracket d, uint32_t r, uint32_t j, uint32_t horizon) const {
@@ -502,18 +503,17 @@ struct FastEval {
         const uint32_t rl = a.rlen[i];
         const bool first = p >= r1lo;
         const bool longrun = rl > kFastK;
-        // the first tile that was not in the lists when they were read for the position -- before its tile's first round
-        // (FastListScan; the two positions beyond the range, looked at by the lazy rules, a step earlier with their neighbours)
-        const uint32_t t = i / a.tile, sstep = step > t ? t + 1 : step;
-        const uint32_t line = kPre + (sstep > a.rounds ? sstep - a.rounds : 0) * a.tile;
+        // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules)
+        const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
+        const bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
         const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
         const uint32_t h4 = hz[0], h4was = hz[2];
-        const bool need = p >= r2lo || dirty;
+        const bool need = p >= r2lo || dirty || scan;
 #if !defined(__HIPCC__)
         g_eval_stats[0]++;
-        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++;
+        if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (scan) g_eval_stats[4]++;
 #endif
         if (!need && h4was == h4) return;
         const uint64_t codes = a.rdist[i];
@@ -550,13 +550,13 @@ struct FastEval {
         }
         uint64_t mask = r ? bits_at(a.vbits, (int64_t)j - 64) : 0;
         uint64_t kmask = rk ? bits_at(a.kbits, (int64_t)kj - 64) : 0;
-        // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts / not in
-        // the lists yet (long runs only: a short run is all in the window, its lists are never read)
+        if (r < 64) mask = r ? mask & (~0ull << (64 - r)) : 0;
+        const uint64_t wbits = mask;  // the item starts among the tabulated predecessors, wherever the ring ends
+        // run predecessors still inside the ring (4094 item starts of the context back) / within 510 item starts
         const DistBracket d5 = dist_valid(codes, p > h5 ? p - h5 : 0);
         uint32_t v4 = count_from(d4, r, j, h4);
-        const uint32_t vl = longrun ? count_from(dist_valid(codes, p - line), r, j, line) : 64;
         if (a.dbg & 2) v4 = 64;
-        const uint32_t span = fast_min(r, fast_min(v4, vl));
+        const uint32_t span = fast_min(r, v4);
         if (span < 64) mask = span ? mask & (~0ull << (64 - span)) : 0;
         // the candidates, newest first, straight from the registers: no load in this loop
         uint32_t best = 0, bk = 0, m1 = 0, m2 = 0, seen = 0;
@@ -573,16 +573,93 @@ struct FastEval {
                 full = l == kMaxLen;
             }
         }
-        const bool stop = full || (v4 < r && v4 <= vl);  // (the ring ends inside the window: nothing older counts either)
+        const bool stop = full || v4 < r;  // (the ring ends inside the window: nothing older counts either)
         uint32_t b510 = best && (bk < d5.sure || (bk < d5.limit && a.epos[j - 1 - bk] >= h5));
-        // (what the run's compact list holds for the position -- FastListScan, remembered in farv -- is merged by FastDecide)
-        const uint32_t older = !stop && longrun;
+        if (!stop && longrun) {
+            uint32_t fv;
+            if (scan) {
+                const uint64_t a0 = ldu64(win + p), a1 = (uint64_t)ldu32(win + p + 8);
+                uint32_t fbest = 0, f510 = 0, fm1 = 0, fm2 = 0, s = seen;
+                bool fin = false;
+                // one older candidate by the serial rules of find_match; false = nothing older matters
+                auto take = [&](uint32_t q, uint32_t l) -> bool {
+                    if (l > fbest || (s < a.lazy1 && l > fm1) || (s < a.lazy2 && l > fm2)) {
+                        if (q < h4) return false;  // left the ring (asked only for candidates that matter): so did everything older
+                        if (l > fbest) { fbest = l; f510 = q >= h5; }
+                        if (s < a.lazy1 && l > fm1) fm1 = l;
+                        if (s < a.lazy2 && l > fm2) fm2 = l;
+                    }
+                    s++;
+                    return l != kMaxLen;
+                };
+                const uint32_t key = c * kHash + hash_entry(win + p);
+                const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
+                // ---- 2. item starts below the window that are not in the lists yet
+                if (a.near && p > cline) {
+                    const uint32_t top = j - kFastK, lo2 = top - rs > a.far ? top - a.far : rs;
+                    uint32_t left = a.near;
+                    far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
+                        uint32_t q;
+                        const uint32_t l = far_lcp(a, p, a0, a1, sl, &q);
+                        if (q < cline) return false;  // from here on the lists have them
+#if !defined(__HIPCC__)
+                        g_far_stats[3]++;
+#endif
+                        if (!take(q, l)) { fin = true; return false; }
+                        return --left != 0;
+                    });
+                }
+                // ---- 3. the run's compact list, newest record first; the window's own item starts below the line lead it
+                if (!fin) {
+                    const uint32_t nabove = fast_min(r, dist_valid(codes, p > cline ? p - cline : 0).limit);  // tabulated predecessors at or after the line (never too few)
+                    const uint32_t skip = nabove < 64 ? (uint32_t)popc64(wbits & ((~0ull >> nabove) )) : 0;
+                    const uint32_t avail = cnt > skip ? cnt - skip : 0;
+                    const uint64_t* top = a.cl + 2 * ((size_t)rs + avail);
+                    const uint32_t want = fast_min(a.depth, avail);
+#if !defined(__HIPCC__)
+                    g_far_stats[0]++;
+#endif
+                    for (uint32_t k0 = 0; k0 < want && !fin; k0 += 4) {
+                        uint64_t x0[4], x1[4];
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) {
+                            const uint32_t k = k0 + b < want ? k0 + b : k0;
+                            x0[b] = top[-2 * (int64_t)(k + 1)];
+                            x1[b] = top[-2 * (int64_t)(k + 1) + 1];
+                        }
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) {
+                            if (k0 + b >= want || fin) break;
+                            const uint32_t q = rec_pos(x1[b]);
+                            uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
+                            if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
+#if !defined(__HIPCC__)
+                            g_far_stats[1]++;
+                            if (l >= kRecText) g_far_stats[2]++;
+#endif
+                            if (!take(q, l)) fin = true;
+                        }
+                    }
+                }
+                fv = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+                a.farv[i] = fv;
+            } else {
+                fv = first ? 0 : a.farv[i];
+            }
+            if (fv >> 25) {  // merge (these candidates are older than every one of the window: they win only when strictly longer)
+                if ((fv & 0xff) > best) { best = fv & 0xff; b510 = (fv >> 24) & 1; }
+                if (((fv >> 8) & 0xff) > m1) m1 = (fv >> 8) & 0xff;
+                if (((fv >> 16) & 0xff) > m2) m2 = (fv >> 16) & 0xff;
+            }
+        } else if (scan) {
+            a.farv[i] = 0;  // (nothing beyond the window counts now; nothing is remembered)
+        }
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
         if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
         if (km & 0x80) kmask &= ~(1ull << 63);
         const uint32_t lwm = kmask ? (uint32_t)((wm >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
 #if !defined(__HIPCC__)
-        if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved) {  // verify mode: would a skipped position have changed?
+        if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved && !scan) {  // verify mode: would a skipped position have changed?
             const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
             if ((o ^ nw) & ~(1u << 25)) {
                 g_eval_stats[6]++;
@@ -593,65 +670,8 @@ struct FastEval {
         }
 #endif
         // ---- stores last: a load queued behind scattered stores would wait for them
-        a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25) | (older << 26);
+        a.ev[i] = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
         if (dirty && !(a.dbg & 32)) a.dirty[i] = 0;
-    }
-};
-// The compact lists' part of an evaluation, for the tile whose first round comes next: thread per position of a deep run, the newest `depth` records of the run's list -- one contiguous read, every address known from the run's
-// counter -- against the position's own bytes, with the serial rules of find_match (src/matcher.rs:135-192).  The answer
-// does not depend on the item starts of the active tiles, so it is computed beside the evaluation of the window
-// (a side branch of the step) and remembered: farv = len | lazy1 max << 8 | lazy2 max << 16 | within 510 << 24 | valid << 25.
-struct FastListScan {
-    FastArgs a;
-    uint32_t lo, hi;  // window offsets: the tile and the two positions behind it (the lazy rules look ahead)
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t p = lo + (uint32_t)tid;
-        if (p >= hi) return;
-        const uint32_t i = p - kPre;
-        if (a.rlen[i] <= kFastK) return;
-        const uint8_t* win = a.win;
-        const uint32_t c = hash1(win, p - 1), key = c * kHash + hash_entry(win + p);
-        const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
-        const uint32_t h4 = hz[0], h5 = hz[1];
-        const uint32_t cnt = a.ccnt[key];
-        const uint64_t* top = a.cl + 2 * ((size_t)a.runstart[key] + cnt);
-        const uint64_t a0 = ldu64(win + p), a1 = (uint64_t)ldu32(win + p + 8);
-        const uint32_t want = fast_min(a.depth, cnt);
-        uint32_t fbest = 0, fsrc = 0, f510 = 0, fm1 = 0, fm2 = 0, s = 0;
-        bool fin = false;
-#if !defined(__HIPCC__)
-        g_far_stats[0]++;
-#endif
-        for (uint32_t k0 = 0; k0 < want && !fin; k0 += 4) {
-            uint64_t x0[4], x1[4];
-#pragma unroll
-            for (uint32_t b = 0; b < 4; b++) {
-                const uint32_t k = k0 + b < want ? k0 + b : k0;
-                x0[b] = top[-2 * (int64_t)(k + 1)];
-                x1[b] = top[-2 * (int64_t)(k + 1) + 1];
-            }
-#pragma unroll
-            for (uint32_t b = 0; b < 4; b++) {
-                if (k0 + b >= want || fin) break;
-                const uint32_t q = rec_pos(x1[b]);
-                uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
-                if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-#if !defined(__HIPCC__)
-                g_far_stats[1]++;
-                if (l >= kRecText) g_far_stats[2]++;
-#endif
-                if (l > fbest || (s < a.lazy1 && l > fm1) || (s < a.lazy2 && l > fm2)) {
-                    if (q < h4) { fin = true; break; }  // left the ring (asked only for candidates that matter): so did everything older
-                    if (l > fbest) { fbest = l; fsrc = q; f510 = q >= h5; }
-                    if (s < a.lazy1 && l > fm1) fm1 = l;
-                    if (s < a.lazy2 && l > fm2) fm2 = l;
-                }
-                s++;
-                if (l == kMaxLen) fin = true;
-            }
-        }
-        (void)fsrc;
-        a.farv[i] = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
     }
 };
 // number of set bits among the `count` bits of a bitmap that start at bit `start`
@@ -805,22 +825,7 @@ struct FastDecide {  // thread per position (measured: inside PathUpWave the fou
         const uint32_t p = lo + (uint32_t)tid;
         if (p >= hi) return;
         const uint32_t i = p - kPre;
-        uint32_t e = a.ev[i], e1 = p + 1 < a.len ? a.ev[i + 1] : 0, e2 = p + 2 < a.len ? a.ev[i + 2] : 0;
-        // what the compact lists hold (FastListScan): candidates older than every one of the window, so they win only when
-        // strictly longer
-        if ((e >> 26) & 1) {
-            const uint32_t fv = a.farv[i];
-            if ((fv >> 25) && (fv & 0xff) > (e & 0xff)) e = (e & ~0x20000ffu) | (fv & 0xff) | (((fv >> 24) & 1) << 25);
-        }
-        if ((e1 >> 26) & 1) {
-            const uint32_t fv = a.farv[i + 1];
-            if ((fv >> 25) && ((fv >> 8) & 0xff) > ((e1 >> 8) & 0xff)) e1 = (e1 & ~0xff00u) | (fv & 0xff00u);
-        }
-        if ((e2 >> 26) & 1) {
-            const uint32_t fv = a.farv[i + 2];
-            if ((fv >> 25) && ((fv >> 16) & 0xff) > ((e2 >> 16) & 0xff)) e2 = (e2 & ~0xff0000u) | (fv & 0xff0000u);
-        }
-        const uint32_t d = fast_decide(p, a.len, e, e1, e2);
+        const uint32_t d = fast_decide(p, a.len, a.ev[i], p + 1 < a.len ? a.ev[i + 1] : 0, p + 2 < a.len ? a.ev[i + 2] : 0);
         a.ty[i] = (uint8_t)d; a.nl[i] = (uint8_t)(d >> 8);
     }
 };
@@ -962,7 +967,7 @@ struct PathTileDown {
     FastArgs a;
     uint32_t t0, nt;
     static constexpr uint32_t kPhases = 3;
-    static constexpr size_t kLdsMax = 64 * 1024;
+    static constexpr size_t kLdsMax = 144 * 1024;  // (of the CU's 160 KB; three rounds of 512 KiB tiles need 93 KB)
     ORZ_HD uint32_t range_chunks() const {
         const uint32_t cpt = a.tile / kSub, c0 = t0 * cpt;
         const uint32_t end = kPre + (t0 + nt) * a.tile;

@@ -670,6 +670,7 @@ class StreamEncoder {
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
+        a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 4;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
@@ -711,12 +712,6 @@ class StreamEncoder {
             // ring horizons of the first tile (no counts yet: the history alone)
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt});
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
-            // the compact lists' answers for the tile whose first round is step `nx` (FastListScan)
-            auto list_scan = [&](uint32_t nx) {
-                if (nx < 1 || nx - 1 >= ntile) return;
-                const uint32_t lo = kPre + (nx - 1) * T, hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T + 2);
-                be_.launch(hi - lo, FastListScan{a, lo, hi});
-            };
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
@@ -728,8 +723,6 @@ class StreamEncoder {
             } capture{be_, use_graph && !replayed};
             if (capture.on) be_.graph_capture_begin();
             if (replayed) stats.sweeps += ntile + R - 1;
-            if (!replayed) list_scan(1);  // (the first tile's first round: the history alone)
-            bool scan_pending = false;
             for (uint32_t step = 1; step <= ntile + R - 1 && !replayed; step++) {
                 const uint32_t t_lo = step > R ? step - R : 0, t_hi = std::min(step - 1, ntile - 1);
                 const uint32_t lo = kPre + t_lo * T;
@@ -742,9 +735,10 @@ class StreamEncoder {
                 // the tiles in their first two rounds are evaluated in full; the flips of this step mark below the next step's line
                 const uint32_t r2lo = step >= 2 && step - 2 < ntile ? kPre + (step - 2) * T : (step < 2 ? kPre : hi);
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step});
+                // (the compact lists hold the tiles that had their last round before this step)
+                const uint32_t cline = kPre + (step > R ? step - R : 0) * T;
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
                 be_.timed_end();
-                if (scan_pending) { be_.side_join(1); scan_pending = false; }  // (the branch of the step before: see below)
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
@@ -762,21 +756,12 @@ class StreamEncoder {
                 const uint32_t fhi = std::min(len, hi + 240);
                 be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
                 be_.side_join(0);
-                // The tile that has just had its last round is final: its item starts join the compact lists (while a later
-                // tile will still read them), then the lists' answers for the tile that starts next are worked out -- a side
-                // branch beside the next step's FastEval, which reads only the window; FastDecide waits for it.
-                const uint32_t rt = step - R;  // (wraps below zero: no tile yet)
-                const bool retire = step >= R && rt + R < ntile;  // (tile rt + R starts next and reads tiles <= rt)
-                if (step < ntile) {
-                    be_.side_begin(1);
-                    if (retire) {
-                        const uint32_t rlo = kPre + rt * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
-                        be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
-                        be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
-                    }
-                    list_scan(step + 1);
-                    be_.side_end();
-                    scan_pending = true;
+                // the tile that has just had its last round is final: its item starts join the compact lists (while a later
+                // tile will still read them)
+                if (step >= R && step < ntile + R - 1) {
+                    const uint32_t rlo = kPre + (step - R) * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
+                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
+                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
                 }
                 stats.sweeps++;
             }

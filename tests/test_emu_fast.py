@@ -111,17 +111,19 @@ def test_incremental_repair_passes_change_nothing(emu, oracle, monkeypatch):
         assert out == full and st[2] == st2[2]
 
 
-def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle):
-    """PathTileDown stages the chunk maps of the active range in LDS when they fit (64 KiB); eight rounds of 256 KiB
-    tiles do not: the same walks through global memory must give a valid stream of about the same size"""
+def test_path_maps_too_large_for_lds_are_walked_in_global_memory(emu, oracle, monkeypatch):
+    """PathTileDown stages the chunk maps of the active range in LDS when they fit (144 KB); eight rounds of 512 KiB
+    tiles do not (1024 chunks x 240 entries): the same walks through global memory must give a valid stream of about
+    the same size.  (ORZ_FAST_TDIV=1: the tile size asked for, although the input is short.)"""
     import corpus
 
-    data = corpus.enwik_like(3_000_000)
-    big, _ = emu.fast(data, cfg=LEVELS[1], tile=262144, rounds=8)
+    data = corpus.enwik_like(5_000_000)
     ref, _ = emu.fast(data, cfg=LEVELS[1])
+    monkeypatch.setenv("ORZ_FAST_TDIV", "1")
+    big, _ = emu.fast(data, cfg=LEVELS[1], tile=524288, rounds=8)
     back, used = oracle.decode(big)
     assert used == len(big) and back == data
-    assert abs(len(big) - len(ref)) <= 0.003 * len(ref)
+    assert abs(len(big) - len(ref)) <= 0.006 * len(ref)
 
 
 def test_deep_runs_take_older_candidates_from_the_compact_lists(emu, oracle):
