@@ -75,7 +75,7 @@ struct orz_stream {
     orz::ItemTrace trace;
     bool tracing = false;
     bool fast = false;
-    unsigned ftile = 131072, frounds = 4;
+    unsigned ftile = orz::kFastTile, frounds = orz::kFastRounds;
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
     // Build the encoder for the current settings.  The new one is constructed BEFORE the old one is dropped (a constructor
@@ -150,8 +150,8 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
         s->win = env_u("ORZ_WIN", 0);
         s->fast = mode_from_env();
-        s->ftile = env_u("ORZ_FAST_TILE", 131072);
-        s->frounds = env_u("ORZ_FAST_ROUNDS", 4);
+        s->ftile = env_u("ORZ_FAST_TILE", orz::kFastTile);
+        s->frounds = env_u("ORZ_FAST_ROUNDS", orz::kFastRounds);
         s->be->set_graphs(env_u("ORZ_GRAPHS", 1) != 0);
         s->rebuild();
         return s.release();
@@ -451,7 +451,7 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
             e->cfg = *cfg;
             const bool fast = mode_from_env();
             e->enc.reset(new Enc(*e->be, to_cfg(cfg), e->seg, fast ? 64 : window_for(*e->be, *cfg, e->win), fast,
-                                 env_u("ORZ_FAST_TILE", 131072), env_u("ORZ_FAST_ROUNDS", 4)));
+                                 env_u("ORZ_FAST_TILE", orz::kFastTile), env_u("ORZ_FAST_ROUNDS", orz::kFastRounds)));
         } else if (!same_cfg) {
             return fail(ORZ_EINVAL, "LZCfg changed inside a stream");
         }

@@ -42,6 +42,8 @@ constexpr uint32_t kEntries = 240;                 // a path enters a chunk / ti
 constexpr uint32_t kFastK = 64;                    // run predecessors tabulated per position (one word of the member bitmap)
 constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the history: window offset x lies in subtile (x + 1) >> 12
 constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
+constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile: measured on a full block of
+constexpr uint32_t kFastRounds = 3;                // text, -l1 (emulator, vs the oracle): 128 K x 4: -0.19 %, 256 K x 3: -0.06 %, 512 K x 3: +0.10 %
 
 struct FastArgs {
     const uint8_t* win;
@@ -65,6 +67,8 @@ struct FastArgs {
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
     uint32_t far;               // slots searched beyond the tabulated K through the bitmap (FastSource; FastEval for item starts not in the lists yet)
     uint32_t near;              // item starts a scan takes from there (0 = none)
+    uint32_t kwin;              // (experiments) run predecessors the window shows: kFastK, or fewer
+    uint32_t extra;             // candidates a scan may look at beyond the reference's depth (window + below the window + lists)
     // compact lists: per (ctx, hash) run the records of its FINAL item starts (history, then the tiles that had their last
     // round, appended by FastRetire) side by side from the run's first slot on, oldest first
     uint64_t* cl;               // [nent][2] records like stext
@@ -454,6 +458,48 @@ struct V1Build {  // thread per summary word: 64 words of the bitmap
     }
 };
 
+// The newest item starts among the slots [lo, top) -- at most four, from the at most four newest non-empty bitmap words of
+// the two summary words that reach down from `top` (8192 slots at most): two independent summary loads, then four
+// independent bitmap loads -- a chain of two dependent rounds whatever the run looks like.  Returns how many were found;
+// slots[] newest first.
+ORZ_D uint32_t near_members(const FastArgs& a, uint32_t lo, uint32_t top, uint32_t want, uint32_t* slots) {
+    if (top <= lo || !want) return 0;
+    const uint32_t w_hi = (top - 1) >> 6, w_lo = lo >> 6, g_hi = w_hi >> 6, g_lo = w_lo >> 6;
+    uint64_t sm[2];
+    sm[0] = a.v1[g_hi];
+    sm[1] = g_hi > g_lo ? a.v1[g_hi - 1] : 0;
+    if ((w_hi & 63) != 63) sm[0] &= (2ull << (w_hi & 63)) - 1;
+    if (g_hi == g_lo) sm[0] &= ~0ull << (w_lo & 63);
+    else if (g_hi - 1 == g_lo) sm[1] &= ~0ull << (w_lo & 63);
+    uint32_t wi[4], nw = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {
+        uint64_t m = sm[h];
+        while (m && nw < 4) {
+            const uint32_t b = 63 - (uint32_t)clz64(m);
+            m &= ~(1ull << b);
+            wi[nw++] = (g_hi - h) * 64 + b;
+        }
+    }
+    uint64_t wv[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) wv[k] = k < nw ? a.vbits[wi[k]] : 0;
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k >= nw) break;
+        uint64_t m = wv[k];
+        if (wi[k] == w_hi && (top & 63)) m &= (1ull << (top & 63)) - 1;
+        if (wi[k] == w_lo) m &= ~0ull << (lo & 63);
+        while (m && n < want) {
+            const uint32_t b = 63 - (uint32_t)clz64(m);
+            m &= ~(1ull << b);
+            slots[n++] = wi[k] * 64 + b;
+        }
+    }
+    return n;
+}
+
 // ---- one round: the positions of the active range decide from the snapshot ----------------------------
 // A position is evaluated in its tile's first two rounds, and afterwards only when the item starts it looks at changed
 // (FastFlip marks it dirty) or when its tile's scan is due.  Its candidates, newest first (find_match walks the hash
@@ -502,7 +548,7 @@ struct FastEval {
         const uint32_t i = p - kPre;
         const uint32_t rl = a.rlen[i];
         const bool first = p >= r1lo;
-        const bool longrun = rl > kFastK;
+        const bool longrun = rl > a.kwin;
         // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules)
         const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
         const bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
@@ -530,7 +576,7 @@ struct FastEval {
         g_eval_stats[1]++;
 #endif
         // ---- everything the evaluation reads, asked for up front: position-ordered statics, then the two bitmap windows
-        const uint32_t j = a.idx[p], kj = a.kidx[p], r = fast_min(kFastK, rl);
+        const uint32_t j = a.idx[p], kj = a.kidx[p], r = fast_min(a.kwin, rl);
         const uint32_t km = a.kmeta[i], rk = km & 0x7f;
         const uint64_t wm = a.wmask[i];
         const uint32_t h5 = hz[1];
@@ -594,41 +640,54 @@ struct FastEval {
                 };
                 const uint32_t key = c * kHash + hash_entry(win + p);
                 const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
-                // ---- 2. item starts below the window that are not in the lists yet
+                // ---- 2. item starts below the window that are not in the lists yet: their slots from the bitmap, their
+                // records side by side, then in order
                 if (a.near && p > cline) {
-                    const uint32_t top = j - kFastK, lo2 = top - rs > a.far ? top - a.far : rs;
-                    uint32_t left = a.near;
-                    far_walk(a, lo2, top, [&](uint32_t sl) -> bool {
-                        uint32_t q;
-                        const uint32_t l = far_lcp(a, p, a0, a1, sl, &q);
-                        if (q < cline) return false;  // from here on the lists have them
+                    const uint32_t top = j - a.kwin, lo2 = top - rs > a.far ? top - a.far : rs;
+                    uint32_t sl[4];
+                    const uint32_t ns = near_members(a, lo2, top, fast_min(a.near, 4u), sl);
+                    uint64_t x0[4], x1[4];
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; b++) {
+                        const uint32_t s2 = b < ns ? sl[b] : j;
+                        x0[b] = a.stext[2 * (size_t)s2];
+                        x1[b] = a.stext[2 * (size_t)s2 + 1];
+                    }
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; b++) {
+                        if (b >= ns || fin) break;
+                        const uint32_t q = rec_pos(x1[b]);
+                        if (q < cline) break;  // from here on the lists have them
+                        uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
+                        if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
 #if !defined(__HIPCC__)
                         g_far_stats[3]++;
 #endif
-                        if (!take(q, l)) { fin = true; return false; }
-                        return --left != 0;
-                    });
+                        if (!take(q, l)) fin = true;
+                    }
                 }
                 // ---- 3. the run's compact list, newest record first; the window's own item starts below the line lead it
                 if (!fin) {
                     const uint32_t nabove = fast_min(r, dist_valid(codes, p > cline ? p - cline : 0).limit);  // tabulated predecessors at or after the line (never too few)
-                    const uint32_t skip = nabove < 64 ? (uint32_t)popc64(wbits & ((~0ull >> nabove) )) : 0;
+                    const uint32_t skip = nabove < 64 ? (uint32_t)popc64(wbits & (~0ull >> nabove)) : 0;
                     const uint32_t avail = cnt > skip ? cnt - skip : 0;
                     const uint64_t* top = a.cl + 2 * ((size_t)rs + avail);
-                    const uint32_t want = fast_min(a.depth, avail);
+                    const uint32_t room = a.depth + a.extra > s ? a.depth + a.extra - s : 0;
+                    const uint32_t want = fast_min(room, avail);
 #if !defined(__HIPCC__)
                     g_far_stats[0]++;
 #endif
-                    for (uint32_t k0 = 0; k0 < want && !fin; k0 += 4) {
-                        uint64_t x0[4], x1[4];
+                    constexpr uint32_t kB = 8;  // records per trip, all loads of a trip in flight
+                    for (uint32_t k0 = 0; k0 < want && !fin; k0 += kB) {
+                        uint64_t x0[kB], x1[kB];
 #pragma unroll
-                        for (uint32_t b = 0; b < 4; b++) {
+                        for (uint32_t b = 0; b < kB; b++) {
                             const uint32_t k = k0 + b < want ? k0 + b : k0;
                             x0[b] = top[-2 * (int64_t)(k + 1)];
                             x1[b] = top[-2 * (int64_t)(k + 1) + 1];
                         }
 #pragma unroll
-                        for (uint32_t b = 0; b < 4; b++) {
+                        for (uint32_t b = 0; b < kB; b++) {
                             if (k0 + b >= want || fin) break;
                             const uint32_t q = rec_pos(x1[b]);
                             uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);

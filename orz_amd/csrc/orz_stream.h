@@ -269,7 +269,7 @@ class StreamEncoder {
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
     // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
     StreamEncoder(BE& be, Cfg cfg, uint32_t seg_size = 62, uint32_t win_segs = 3072, bool fast = false,
-                  uint32_t fast_tile = 131072, uint32_t fast_rounds = 4)
+                  uint32_t fast_tile = kFastTile, uint32_t fast_rounds = kFastRounds)
         : be_(be), cfg_(cfg), seg_(seg_size), wsegs_(win_segs), fast_(fast), ftile_(fast_tile), frounds_(fast_rounds) {
         if (fast_) {
             if (ftile_ < kSub || ftile_ % kSub || ftile_ > kNewMax) throw std::runtime_error("fast tile must be a multiple of 4096 in [4096, 16777216]");
@@ -670,7 +670,11 @@ class StreamEncoder {
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
+        a.kwin = getenv("ORZ_FAST_KWIN") ? (uint32_t)atoi(getenv("ORZ_FAST_KWIN")) : kFastK;
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 4;
+        // (candidates beyond the reference's depth: half as many again keeps the sizes centred on the reference's -- text,
+        // 256 KiB tiles x 3 rounds: -l0 / -l1 / -l2 within 0.1 % of the oracle; the full depth again gives -0.4 ... -0.1 %)
+        a.extra = getenv("ORZ_FAST_EXTRA") ? (uint32_t)atoi(getenv("ORZ_FAST_EXTRA")) : (a.depth + 1) / 2;
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
@@ -1040,7 +1044,7 @@ class StreamEncoder {
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
-    uint32_t ftile_ = 131072, frounds_ = 4, fK_ = 64;
+    uint32_t ftile_ = kFastTile, frounds_ = kFastRounds, fK_ = 64;
     bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr;

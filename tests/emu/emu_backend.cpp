@@ -166,7 +166,7 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
     try {
         EmuBackend be;
         orz::Cfg cfg{depth, lazy1, lazy2};
-        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, tile ? tile : 131072, rounds ? rounds : 4);
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, tile ? tile : orz::kFastTile, rounds ? rounds : orz::kFastRounds);
         std::vector<uint8_t> out;
         orz::encode_stream(enc, be, src, n, false, out);
         *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);

@@ -8,7 +8,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "${2:-}" != "skip-tests" ]; then
-  eval "timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-}" > $OUT/${TAG}_pytest_gpu.log 2>&1
+  eval "timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_ARGS:-}" > $OUT/${TAG}_pytest_gpu.log 2>&1
   tail -5 $OUT/${TAG}_pytest_gpu.log
 fi
 bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1
