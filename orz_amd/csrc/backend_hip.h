@@ -526,7 +526,17 @@ class HipBackend {
    public:
     explicit HipBackend(int device) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
-        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+        // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream: 512 waves that must
+        // never wait for the parse kernels of the next block to finish dispatching (a 340,000-workgroup grid keeps its
+        // dispatch pipe for milliseconds), so it gets the highest priority the device offers.
+        int prio_low = 0, prio_high = 0;
+        ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        const char* rp = getenv("ORZ_RANK_PRIO");
+        const bool rank_prio = !(rp && atoi(rp) == 0);
+        for (int i = 0; i < kStreams; i++) {
+            if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio_high));
+            else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+        }
         stream_ = streams_[0];
         for (int i = 0; i < kEvents; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
         for (int i = 0; i < kSide; i++) {

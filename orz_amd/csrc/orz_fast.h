@@ -332,14 +332,20 @@ ORZ_D uint32_t rec_lcp(uint64_t lo_a, uint64_t hi_a, uint64_t lo_b, uint64_t hi_
 // four neighbouring lanes in one go (a lane storing its own row eight bytes at a time costs a partial line per store).
 struct FastText {  // the slot records, in slot order (one scattered read per slot, once per block)
     const uint8_t* win;
-    const uint32_t* epos;
+    const uint32_t *epos, *keys;
     uint32_t nent;
     uint64_t* stext;
+    uint64_t* cl;    // the history slots of a run are final item starts: the head of its compact list (FastRetire appends)
+    uint32_t* ccnt;  // (zeroed) records per list
     ORZ_HD void operator()(size_t j) const {
         if (j >= nent) return;
         const uint32_t q = epos[j];
-        stext[2 * j] = ldu64(win + q);
-        stext[2 * j + 1] = (uint64_t)ldu32(win + q + 8) | ((uint64_t)q << 32);
+        const uint64_t lo = ldu64(win + q), hi = (uint64_t)ldu32(win + q + 8) | ((uint64_t)q << 32);
+        stext[2 * j] = lo; stext[2 * j + 1] = hi;
+        if (q < kPre) {
+            cl[2 * j] = lo; cl[2 * j + 1] = hi;
+            atom_add32(&ccnt[keys[j]], 1);
+        }
     }
 };
 struct FastRowsWave {
@@ -795,19 +801,15 @@ struct FastRetireDone {  // the first member of each (run, tile) group moves the
         a.cnew[key] = 0;
     }
 };
-struct FastListInit {  // thread per slot: the history slots of a run are final item starts -- the head of its list
+struct FastListReset {  // a block parsed again (finer tiles): the lists go back to their history heads (thread per slot)
     const uint8_t* win;
     const uint32_t* epos;
-    const uint64_t* stext;
     uint32_t nent;
-    uint64_t* cl;
     uint32_t* ccnt;  // (zeroed)
     ORZ_HD void operator()(size_t j) const {
         if (j >= nent) return;
         const uint32_t q = epos[j];
-        if (q >= kPre) return;
-        cl[2 * j] = stext[2 * j]; cl[2 * j + 1] = stext[2 * j + 1];
-        atom_add32(&ccnt[bucket_key(win, q)], 1);
+        if (q < kPre) atom_add32(&ccnt[bucket_key(win, q)], 1);
     }
 };
 

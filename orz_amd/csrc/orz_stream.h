@@ -656,7 +656,8 @@ class StreamEncoder {
         be_.memset(fhpre_, 0, 256 * 4);
         col_scan(fhcm_, kHistSub, fhpre_);
         uint64_t* stext = fstext_;
-        be_.launch(nent, FastText{win, epos_, nent, stext});
+        be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
+        be_.launch(nent, FastText{win, epos_, slot_keys, nent, stext, fcl_, fccnt_});
         be_.timed_begin(2);
         be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_, frdist_}, FastRowsWave::lds_bytes(K));
         be_.timed_end(2);
@@ -693,11 +694,15 @@ class StreamEncoder {
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 2;
             if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
         }
-        for (;;) {
+        for (int attempt = 0;; attempt++) {
             a.tile = T;
-            be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
+            if (attempt) {  // (the first attempt finds the bitmap and the list counters as the prep left them)
+                be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
+                be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
+                be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
+                be_.launch(nent, FastListReset{win, epos_, nent, fccnt_});
+            }
             be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
-            be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
             be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             const size_t nn = (size_t)n + 264;
             // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
@@ -707,10 +712,7 @@ class StreamEncoder {
             be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
-            // compact lists: every run starts with its history slots
-            be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
-            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);
-            be_.launch(nent, FastListInit{win, epos_, fstext_, nent, fcl_, fccnt_});
+            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);  // (compact lists: every run starts with its history slots, FastText)
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)

@@ -33,10 +33,18 @@ def passes(db_path, needle="symrank", gap_ms=20.0):
             continue
         t0, t1 = p[0][0], max(e for _, e, _ in p)
         gaps = [chain[i + 1][0] - chain[i][1] for i in range(len(chain) - 1)]
+        # was the chain waiting for its input?  end of the last `ready` kernel (the per-context gather's run starts, the
+        # last kernel before a ranking launch) before each chain launch, relative to that launch's start
+        ready = sorted(e for _, e, n in p if "SymRunStart" in n)
+        waits = []
+        for s0, _ in chain:
+            prev = [e for e in ready if e <= s0]
+            waits.append(round((s0 - prev[-1]) / 1e6, 2) if prev else None)
         res.append({
             "kernels": len(p), "chain_launches": len(chain), "wall_ms": round((t1 - t0) / 1e6, 2),
             "lead_ms": round((chain[0][0] - t0) / 1e6, 2), "chain_busy_ms": round(sum(e - s for s, e in chain) / 1e6, 2),
             "gaps_ms": [round(g / 1e6, 2) for g in gaps], "after_last_ms": round((t1 - chain[-1][1]) / 1e6, 2),
+            "input_ready_before_start_ms": waits,
         })
     return res
 
