@@ -557,7 +557,7 @@ class HipBackend {
         ORZ_HIP_CHECK(rocprim::inclusive_scan(nullptr, s4, u, u, (size_t)kWLen, rocprim::maximum<uint32_t>(), stream_));
         if (s4 > s2) s2 = s4;
         tmp_bytes_ = (s1 > s2 ? s1 : s2) + 256;
-        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipMalloc(&tmps_[i], tmp_bytes_));
+        for (int i = 0; i < 3; i++) ORZ_HIP_CHECK(hipMalloc(&tmps_[i], tmp_bytes_));
         tmp_ = tmps_[0];
     }
     ~HipBackend() {
@@ -824,13 +824,13 @@ class HipBackend {
    private:
     int device_;
     hipStream_t stream_ = nullptr;
-    static constexpr int kStreams = 3, kEvents = 4;
-    hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr};
+    static constexpr int kStreams = 4, kEvents = 6;  // (stream 3 only copies finished output to the host: no temporary storage)
+    hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
     hipStream_t side_[kSide] = {nullptr, nullptr}, side_saved_ = nullptr;
     hipEvent_t side_fork_[kSide] = {nullptr, nullptr}, side_join_[kSide] = {nullptr, nullptr};
     int side_cur_ = 0;
-    void* tmps_[kStreams] = {nullptr, nullptr, nullptr};
+    void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     int cur_ = 0;
     void* tmp_ = nullptr;
     size_t tmp_bytes_ = 0;

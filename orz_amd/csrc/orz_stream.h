@@ -424,7 +424,7 @@ class StreamEncoder {
         be_.memset(LENMIN_, 0, kWLen);
         be_.memset(ctxcount_, 0, 256 * 4);
         be_.memset(wsnap_, 0, 65536);
-        be_.select(1); be_.sync(); be_.select(2); be_.sync(); be_.select(0);
+        be_.select(1); be_.sync(); be_.select(2); be_.sync(); be_.select(3); be_.sync(); be_.select(0);
         for (TailSet& t : ts_) t.pending = false;
         pend_order_.clear();
         cur_set_ = 0;
@@ -897,6 +897,7 @@ class StreamEncoder {
                                                   t.out, outoff_, t.hdrbits}, ChunkHeaderWave::lds_bytes());
         be_.launch(nitems, Pack{t.irank, t.ial, t.ienc, t.irob, t.hl, t.hc, t.bscan, t.hdrbits, outoff_, nitems, t.out});
         be_.launch(nchunks, ChunkTotals{t.bscan, t.blen, t.hdrbits, nitems, nchunks, t.tot});
+        be_.record(kEvTail + b);  // this block's bytes are ready
         be_.select(0);
         t.pending = true;
         t.nitems = nitems; t.nchunks = nchunks; t.len = len; t.block = (uint32_t)stats.blocks;
@@ -923,8 +924,13 @@ class StreamEncoder {
         pend_order_.erase(pend_order_.begin());
         t.pending = false;
         const uint32_t nitems = t.nitems, nchunks = t.nchunks, len = t.len;
+        // The copies run on a stream of their own behind THIS block's tail stage: on the tail stream they would queue behind
+        // the next block's tail, which waits for that block's symbol ranking -- and the host with them (3.3 ms a block of
+        // the ranking chain standing idle, measured).
         MainStreamGuard back_to_main{be_};
-        be_.select(2);
+        const int set = (int)(&t - ts_);
+        be_.select(3);
+        be_.wait(kEvTail + set);
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
         for (uint32_t i = 0; i < nchunks; i++) {
@@ -1073,7 +1079,7 @@ class StreamEncoder {
         bool pending = false;
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
-    static constexpr int kEvItems = 0, kEvRank = 2;  // event numbers (+ set index)
+    static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4;  // event numbers (+ set index)
     struct MainStreamGuard {  // whatever happens while a side stream is selected, the backend goes back to the main one
         BE& be;
         ~MainStreamGuard() { be.select(0); }
