@@ -539,11 +539,6 @@ class HipBackend {
         }
         stream_ = streams_[0];
         for (int i = 0; i < kEvents; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
-        for (int i = 0; i < kSide; i++) {
-            ORZ_HIP_CHECK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
-            ORZ_HIP_CHECK(hipEventCreateWithFlags(&side_fork_[i], hipEventDisableTiming));
-            ORZ_HIP_CHECK(hipEventCreateWithFlags(&side_join_[i], hipEventDisableTiming));
-        }
         // temp storage big enough for the largest sort / scan of a block
         size_t s1 = 0, s2 = 0;
         uint64_t* k = nullptr;
@@ -563,11 +558,6 @@ class HipBackend {
     ~HipBackend() {
         (void)hipSetDevice(device_);
         for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamSynchronize(streams_[i]);
-        for (int i = 0; i < kSide; i++) {
-            if (side_[i]) { (void)hipStreamSynchronize(side_[i]); (void)hipStreamDestroy(side_[i]); }
-            if (side_fork_[i]) (void)hipEventDestroy(side_fork_[i]);
-            if (side_join_[i]) (void)hipEventDestroy(side_join_[i]);
-        }
         for (int i = 0; i < kStreams; i++) (void)hipFree(tmps_[i]);
         for (int i = 0; i < kEvents; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
@@ -589,24 +579,6 @@ class HipBackend {
     uint32_t skip_after() const { return 0; }
     // streams 1 and 2: the tail stage of a block (symbol ranking; Huffman + packing) overlaps the next block's parse (orz_stream.h)
     void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
-    // Side branches of the current stream: the launches between side_begin(b) and side_end() depend on everything queued
-    // on the stream so far and run beside what is queued after them; side_join(b) makes the stream wait for the branch.
-    // Inside a graph capture the branch becomes a parallel path of the graph (the side stream joins the capture through
-    // the fork event and must be joined before the capture ends).  No sorts / scans on a branch (they use the stream's
-    // temporary storage).
-    static constexpr int kSide = 2;
-    void side_begin(int b) {
-        ORZ_HIP_CHECK(hipEventRecord(side_fork_[b], stream_));
-        ORZ_HIP_CHECK(hipStreamWaitEvent(side_[b], side_fork_[b], 0));
-        side_saved_ = stream_;
-        stream_ = side_[b];
-        side_cur_ = b;
-    }
-    void side_end() {
-        ORZ_HIP_CHECK(hipEventRecord(side_join_[side_cur_], stream_));
-        stream_ = side_saved_;
-    }
-    void side_join(int b) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, side_join_[b], 0)); }
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
     void wait(int ev) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, sev_[ev], 0)); }
     int device() const { return device_; }
@@ -827,9 +799,6 @@ class HipBackend {
     static constexpr int kStreams = 4, kEvents = 6;  // (stream 3 only copies finished output to the host: no temporary storage)
     hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
-    hipStream_t side_[kSide] = {nullptr, nullptr}, side_saved_ = nullptr;
-    hipEvent_t side_fork_[kSide] = {nullptr, nullptr}, side_join_[kSide] = {nullptr, nullptr};
-    int side_cur_ = 0;
     void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     int cur_ = 0;
     void* tmp_ = nullptr;

@@ -752,16 +752,14 @@ class StreamEncoder {
                 be_.timed_end(3);
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
-                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them: a side
-                // branch beside the flips (both only need the path)
-                const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
-                be_.side_begin(0);
-                be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
-                be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
-                be_.side_end();
                 const uint32_t fhi = std::min(len, hi + 240);
                 be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi});
-                be_.side_join(0);
+                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them.  (As a
+                // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
+                // hardware queues the runtime gave the two streams: one chain it is.)
+                const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
+                be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt});
+                be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
                 // the tile that has just had its last round is final: its item starts join the compact lists (while a later
                 // tile will still read them)
                 if (step >= R && step < ntile + R - 1) {

@@ -32,9 +32,6 @@ struct EmuBackend {
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }
     void select(int) {}
-    void side_begin(int) {}
-    void side_end() {}
-    void side_join(int) {}
     void record(int) {}
     void wait(int) {}
     bool graphs_enabled() const { return false; }
