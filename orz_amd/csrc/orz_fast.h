@@ -31,7 +31,7 @@
 namespace orz {
 
 #if !defined(__HIPCC__)
-inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: list scans, records read, records that went to the window, item starts taken from below the window)
+inline unsigned long long g_far_stats[4] = {0, 0, 0, 0};  // (host emulation only: list scans, records read, records that went to the window, trips of the walk below the window)
 #endif
 
 constexpr uint32_t kSub = 4096;                    // positions per ordinal subtile (= path chunk)
@@ -42,8 +42,10 @@ constexpr uint32_t kEntries = 240;                 // a path enters a chunk / ti
 constexpr uint32_t kFastK = 64;                    // run predecessors tabulated per position (one word of the member bitmap)
 constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the history: window offset x lies in subtile (x + 1) >> 12
 constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
-constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile: measured on a full block of
-constexpr uint32_t kFastRounds = 3;                // text, -l1 (emulator, vs the oracle): 128 K x 4: -0.19 %, 256 K x 3: -0.06 %, 512 K x 3: +0.10 %
+constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile.  Measured on a full block,
+constexpr uint32_t kFastRounds = 4;                // emulator, vs the oracle: text -l1 256 K x 3 / x 4: -0.00 / -0.04 %, 512 K x 3: +0.2 %;
+                                                   // zeros + noise -l2 (one hot context, item starts that depend on each other over long
+                                                   // distances): 256 K x 3 / x 4 / x 5: +0.81 / +0.46 / +0.40 %, 512 K x 4: +1.5 %
 
 struct FastArgs {
     const uint8_t* win;
@@ -464,6 +466,19 @@ struct V1Build {  // thread per summary word: 64 words of the bitmap
     }
 };
 
+// Common prefix of x[0..) and y[0..), capped at `cap`, 32 bytes per trip with the eight loads of a trip in flight: a match
+// of a few dozen bytes costs one or two memory round trips instead of one per eight bytes.
+ORZ_D uint32_t lcp_trips(const uint8_t* x, const uint8_t* y, uint32_t cap) {
+    for (uint32_t off = 0; off < cap; off += 32) {
+        uint64_t d[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) d[k] = ldu64(x + off + 8 * k) ^ ldu64(y + off + 8 * k);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (d[k]) { const uint32_t l = off + 8 * k + ((uint32_t)ctz64(d[k]) >> 3); return l < cap ? l : cap; }
+    }
+    return cap;
+}
 // The newest item starts among the slots [lo, top) -- at most four, from the at most four newest non-empty bitmap words of
 // the two summary words that reach down from `top` (8192 slots at most): two independent summary loads, then four
 // independent bitmap loads -- a chain of two dependent rounds whatever the run looks like.  Returns how many were found;
@@ -646,30 +661,40 @@ struct FastEval {
                 };
                 const uint32_t key = c * kHash + hash_entry(win + p);
                 const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
-                // ---- 2. item starts below the window that are not in the lists yet: their slots from the bitmap, their
-                // records side by side, then in order
+                // ---- 2. item starts below the window that are not in the lists yet: four at a time -- their slots from the
+                // bitmap, their records side by side, then in order -- until the lists take over (below `cline`), the budget
+                // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
+                // inside the tiles that are still in their rounds: the lists' records lie outside it and this walk is all.)
                 if (a.near && p > cline) {
-                    const uint32_t top = j - a.kwin, lo2 = top - rs > a.far ? top - a.far : rs;
-                    uint32_t sl[4];
-                    const uint32_t ns = near_members(a, lo2, top, fast_min(a.near, 4u), sl);
-                    uint64_t x0[4], x1[4];
+                    uint32_t top = j - a.kwin;
+                    const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+                    uint32_t left = fast_min(a.near, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
+                    bool more = left != 0;
+                    while (more && !fin) {
+                        uint32_t sl[4];
+                        const uint32_t ns = near_members(a, lo2, top, fast_min(left, 4u), sl);
+                        uint64_t x0[4], x1[4];
 #pragma unroll
-                    for (uint32_t b = 0; b < 4; b++) {
-                        const uint32_t s2 = b < ns ? sl[b] : j;
-                        x0[b] = a.stext[2 * (size_t)s2];
-                        x1[b] = a.stext[2 * (size_t)s2 + 1];
-                    }
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; b++) {
-                        if (b >= ns || fin) break;
-                        const uint32_t q = rec_pos(x1[b]);
-                        if (q < cline) break;  // from here on the lists have them
-                        uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
-                        if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
+                        for (uint32_t b = 0; b < 4; b++) {
+                            const uint32_t s2 = b < ns ? sl[b] : j;
+                            x0[b] = a.stext[2 * (size_t)s2];
+                            x1[b] = a.stext[2 * (size_t)s2 + 1];
+                        }
 #if !defined(__HIPCC__)
                         g_far_stats[3]++;
 #endif
-                        if (!take(q, l)) fin = true;
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) {
+                            if (b >= ns || fin || !more) break;
+                            const uint32_t q = rec_pos(x1[b]);
+                            if (q < cline) { more = false; break; }  // from here on the lists have them
+                            uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
+                            if (l == kRecText) l += lcp_trips(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
+                            if (!take(q, l)) fin = true;
+                            left--;
+                        }
+                        if (ns < 4 || left == 0) more = false;
+                        else top = sl[3];  // go on below the fourth
                     }
                 }
                 // ---- 3. the run's compact list, newest record first; the window's own item starts below the line lead it
@@ -697,7 +722,7 @@ struct FastEval {
                             if (k0 + b >= want || fin) break;
                             const uint32_t q = rec_pos(x1[b]);
                             uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
-                            if (l == kRecText) l += lcp240u(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
+                            if (l == kRecText) l += lcp_trips(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
 #if !defined(__HIPCC__)
                             g_far_stats[1]++;
                             if (l >= kRecText) g_far_stats[2]++;
@@ -1122,6 +1147,8 @@ struct FastFlip {
     uint32_t next_entry; // tile index whose entry position also counts as an item start (or ~0u)
     uint32_t mark_hi;    // positions below this one are marked dirty: those beyond are evaluated in the next step whatever their
                          // flags say (FastEval r2lo); 0 = no marking (the repair passes)
+    uint32_t last_hi;    // positions below this one are in their tile's last round: item starts that still change there are counted
+    uint32_t* lastflips;
     // slots above `slot` whose positions are to be marked
     static constexpr uint32_t kTrip = 16;  // slots per trip: a walk is at most four rounds of independent loads
     ORZ_D uint32_t walk(bool words, uint32_t slot, uint32_t y) const {
@@ -1176,6 +1203,7 @@ struct FastFlip {
         const uint32_t nk = de && y - 2 < mark_hi ? walk(true, ku, y - 2) : 0;
         // ---- stores
         if (dv) {
+            if (y < last_hi) atom_add32(lastflips, 1);
             if (a.dbg & 64) atom_add64(&a.stats[16], 1);
             atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
             if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
@@ -1216,15 +1244,24 @@ struct CountWave {
         for (uint32_t c = lane; c < 256; c += 64) a.cm[(size_t)s * 256 + c] = cnt[c];
     }
 };
-// cp[s][c] = cp[s0][c] + sum of cm[s0 .. s)[c] for s in (s0, s1 + ext]: thread per (s, ctx), independent loads.  The `ext`
-// subtiles behind s1 belong to the tile that starts next: it has no item starts yet, so its counts are taken from the
-// same places one tile (`cpt` subtiles) earlier -- the ring horizons of its first round need an estimate.
+// cp[s][c] = cp[s0][c] + sum of counts[s0 .. s)[c] for s in (s0, s1 + ext]: thread per (s, ctx), independent loads.
+// The counts are the path's own (cm) for the subtiles below `live_end` -- the tile in its last round, whose path is final
+// once this step has run -- and for the tiles behind it the counts of the same places in the newest tile below live_end:
+// the ring horizons of tiles that are still settling must not follow their own unsettled item counts (a sketch with too
+// many items pulls the horizon in, fewer candidates count, the next round makes too many items again: zeros with noise
+// came out 6 % larger that way).  While no tile is in its last round yet (the first steps) live_end = s0: nothing is
+// counted, the horizons lie in the history.  The `ext` subtiles behind s1 belong to the tile that starts next.
 struct FastPrefix {
     FastArgs a;
     uint32_t s0, s1, ext, cpt;
+    uint32_t live_end;
     ORZ_D uint32_t cmx(uint32_t t, uint32_t c) const {
-        if (t < s1) return a.cm[(size_t)t * 256 + c];
-        return t >= cpt ? a.cm[(size_t)(t - cpt) * 256 + c] : 0;
+        if (t >= live_end) {
+            const uint32_t back = ((t - live_end) / cpt + 1) * cpt;
+            if (back > t) return 0;
+            t -= back;
+        }
+        return a.cm[(size_t)t * 256 + c];
     }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t c = (uint32_t)(tid & 255), s = s0 + 1 + (uint32_t)(tid >> 8);
@@ -1271,13 +1308,13 @@ struct FastCtl {
     uint32_t nmem;     // item starts when the last pass began (FastItemTotal)
     uint32_t acc;
     uint32_t lt;       // type of the item that ended at the block end (carried to the next block)
-    uint32_t pad;
+    uint32_t lastflips;  // item starts that still changed in their tile's LAST round (FastFlip): the rounds had not settled
 };
 struct FastCtlReset {
     FastCtl* ctl;
     ORZ_HD void operator()(size_t tid) const {
         if (tid) return;
-        ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;
+        ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;  // (lastflips: reset before the rounds)
     }
 };
 struct FastPassEnd {
