@@ -1552,6 +1552,32 @@ struct FastWordCheck {  // a WORD item whose prediction the exact state does not
         a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
     }
 };
+// Diagnostics (ORZ_FAST_VERIFY): every match of the frozen parse against first principles -- the source is an item start of
+// the same context, lies inside the ring by the exact ordinals, and its bytes equal the item's -- independent of the
+// tables the source assignment used.  err[0..4] = matches checked, source not an item start, other context, outside the
+// ring, bytes differ; err[5] = position of the first offender.
+struct FastVerify {
+    FastArgs a;
+    const uint32_t* SRC;
+    const uint8_t* S;  // history item starts
+    unsigned long long* err;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
+        const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], q = SRC[p];
+        atom_add64(&err[0], 1);
+        bool bad = false;
+        const bool member = q < p && (q >= kPre ? ((a.sbits[(q - kPre) / 64] >> ((q - kPre) & 63)) & 1) != 0 : (q >= 1 && S[q] != 0));
+        if (!member) { atom_add64(&err[1], 1); bad = true; }
+        else {
+            if (hash1(a.win, q - 1) != hash1(a.win, p - 1)) { atom_add64(&err[2], 1); bad = true; }
+            if (a.ORD[p] - 1 - a.ORD[q] > kRing - 1) { atom_add64(&err[3], 1); bad = true; }
+            bool same = L >= kMinLen && L <= kMaxLen;
+            for (uint32_t k = 0; k < L && same; k++) same = a.win[q + k] == a.win[p + k];
+            if (!same) { atom_add64(&err[4], 1); bad = true; }
+        }
+        if (bad) err[5] = p;
+    }
+};
 struct FastCommit {  // per-position arrays the post stage reads (orz_stream.h)
     FastArgs a;
     const uint32_t* laste;

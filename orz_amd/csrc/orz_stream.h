@@ -820,6 +820,12 @@ class StreamEncoder {
             be_.d2h(h, a.stats, sizeof h);
             fprintf(stderr, "flip: %llu item flips, %llu word flips, walk trips %llu / %llu\n", h[16], h[17], h[18], h[19]);
         }
+        if (const char* fv = getenv("ORZ_FAST_VERIFY")) {  // diagnostics: the frozen parse against first principles (FastVerify)
+            unsigned long long* e = (unsigned long long*)fgsum_ + 8192 + 32;  // (1 = read back per block; 2 = counters kept on the device until the stream ends: no extra synchronisation)
+            if (atoi(fv) != 2 || stream_start_) be_.memset(e, 0, 6 * 8);
+            be_.launch(n, FastVerify{a, SRC_, S_, e});
+            if (atoi(fv) != 2) report_verify("block");
+        }
         // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
         be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
         be_.launch(1, FastLtCarry{fpt_, n, fctl_});
@@ -932,8 +938,8 @@ class StreamEncoder {
         // the ranking chain standing idle, measured).
         MainStreamGuard back_to_main{be_};
         const int set = (int)(&t - ts_);
-        be_.select(3);
-        be_.wait(kEvTail + set);
+        if (getenv("ORZ_COPY_STREAM") && atoi(getenv("ORZ_COPY_STREAM")) == 0) be_.select(2);  // (experiments)
+        else { be_.select(3); be_.wait(kEvTail + set); }
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
         for (uint32_t i = 0; i < nchunks; i++) {
@@ -982,7 +988,17 @@ class StreamEncoder {
         be_.select(0);
     }
     template <class OutT>
-    void finish(OutT& out) { collect(out, nullptr); }
+    void finish(OutT& out) {
+        collect(out, nullptr);
+        if (fast_ && getenv("ORZ_FAST_VERIFY") && atoi(getenv("ORZ_FAST_VERIFY")) == 2) report_verify("stream");
+    }
+    void report_verify(const char* what) {
+        unsigned long long h6[6];
+        be_.d2h(h6, (unsigned long long*)fgsum_ + 8192 + 32, sizeof h6);
+        if (h6[1] | h6[2] | h6[3] | h6[4])
+            fprintf(stderr, "ORZ_FAST_VERIFY: %s (%llu blocks so far): %llu matches, %llu sources not item starts, %llu in another context, %llu outside the ring, %llu with other bytes (e.g. at %llu)\n",
+                    what, (unsigned long long)stats.blocks, h6[0], h6[1], h6[2], h6[3], h6[4], h6[5]);
+    }
 
     // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
     // the last kPre bytes move to offset 0, every position is rebased by 2^24, position 0 dies.

@@ -18,7 +18,14 @@ namespace {
 struct EmuBackend {
     int order = 1;  // simt::Order for wave kernels
     uint64_t seed = 1;
-    template <class T> T* alloc(size_t n, bool = true) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
+    // (allocations the encoder asks for without a zero fill come back POISONED: the device hands out recycled memory, and
+    // whatever the kernels read before they have written it must not matter)
+    template <class T> T* alloc(size_t n, bool zero = true) {
+        if (zero) return (T*)std::calloc(n ? n : 1, sizeof(T));
+        T* p = (T*)std::malloc((n ? n : 1) * sizeof(T));
+        if (p) std::memset(p, std::getenv("ORZ_EMU_POISON") ? std::atoi(std::getenv("ORZ_EMU_POISON")) : 0xA5, (n ? n : 1) * sizeof(T));
+        return p;
+    }
     void free(void* p) { std::free(p); }
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }

@@ -64,9 +64,20 @@ def _members_case(oracle, name, data, level, single_stream_delta):
     pieces = od.split_members(container)
     assert len(pieces) == nm
     spans = [(i * MEMBER, min(len(data), (i + 1) * MEMBER)) for i in range(nm)]
+    def decode_one(k):
+        try:
+            return oracle.decode(pieces[k])
+        except ValueError:  # keep the evidence: the member's index, its size and (when gpurun_out is writable) its bytes
+            try:
+                with open(os.path.join(ROOT, "gpurun_out", "bad_member_%d_of_%s.orz" % (k, name.split(":")[0].replace(" ", "_"))), "wb") as f:
+                    f.write(pieces[k])
+            except OSError:
+                pass
+            raise AssertionError("%s: the oracle's decoder rejects member %d (%d bytes; sizes %r)" % (name, k, len(pieces[k]), [len(p) for p in pieces]))
+
     with _pool() as ex:
         # every member through the ORACLE's decoder
-        backs = list(ex.map(lambda p: oracle.decode(p), pieces))
+        backs = list(ex.map(decode_one, range(len(pieces))))
         for (a, b), (back, used), piece in zip(spans, backs, pieces):
             assert used == len(piece)
             assert back == data[a:b]
