@@ -235,9 +235,9 @@ class MemberEncoder:
         costs about 1.5 % of the size at 16 MiB members, a quarter of that at 64 MiB.  Members larger than one
         block (16 MiB) decode with the reference decoder and with `decode_members` (host); the DEVICE decoder
         (`decode_members_device`) takes members of at most one block and refuses larger ones with a clear error."""
-        data = bytes(data)
-        buf = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
-        return self._run(ctypes.cast(buf, ctypes.c_void_p), len(data), False, member_bytes)
+        data = bytes(data)  # (no copy when it is `bytes` already; the library reads the object's own buffer)
+        ptr = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p) if data else ctypes.cast(ctypes.create_string_buffer(1), ctypes.c_void_p)
+        return self._run(ptr, len(data), False, member_bytes)
 
     def encode_device(self, dev_ptr, nbytes, member_bytes=1 << 26):
         return self._run(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, member_bytes)

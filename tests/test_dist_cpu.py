@@ -45,6 +45,24 @@ def test_member_gather_world2():
     assert res[-1] == sum(1 + (m * 7) % 250 for m in range(n_members))
 
 
+def test_member_gather_world8():
+    """the shape of BASELINE configs[3] -- 8 ranks, 61 members (an 8 GB job in 128 MiB members + a short last one): ranks
+    hold 8 or 7 members, rank 0 posts the receives of all seven peers before it waits for any"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_members, world = 61, 8
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_members, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = q.get(timeout=10)
+    assert res[:-1] == [100 + 37 * m for m in range(n_members)]
+    assert res[-1] == sum(1 + (m * 7) % 250 for m in range(n_members))
+
+
 def _library_buffer(payload):
     """an api.OrzBuffer like the one orz_stream_encode's output arrives in: malloc'ed memory, released by orz_free"""
     import ctypes

@@ -242,3 +242,24 @@ def test_units_of_a_block_decode_with_the_reference_loop(oracle, monkeypatch):
     back, used = oracle.decode(out)
     assert used == len(out) and back == data
     assert abs(len(out) - len(whole)) <= 0.002 * len(whole)
+
+
+def test_members_on_two_devices(oracle):
+    """orz_members_new_multi with two HIP devices (one host thread per encoder, hipSetDevice per thread): the members come
+    back in order whichever device encoded them and decode with the oracle.  Skipped on a one-GPU box."""
+    import corpus
+    import orz_amd
+    from orz_amd import _native, dist as od
+
+    if _native.load().orz_device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    data = corpus.enwik_like(9_000_000)
+    enc = orz_amd.MemberEncoder(devices=[0, 1], level=1, jobs=2)
+    try:
+        container, nm = enc.encode(data, member_bytes=1 << 20)
+    finally:
+        enc.close()
+    pieces = od.split_members(container)
+    assert nm == len(pieces) == 9
+    back = b"".join(oracle.decode(p)[0] for p in pieces)
+    assert back == data
