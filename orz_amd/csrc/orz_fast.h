@@ -1386,45 +1386,6 @@ struct OrdWave {
     }
 };
 
-struct MemberFlags32 {
-    const uint64_t* sbits;
-    uint32_t n;
-    uint32_t* f;
-    ORZ_HD void operator()(size_t i) const {
-        if (i < n) f[i] = (uint32_t)((sbits[i / 64] >> (i & 63)) & 1);
-    }
-};
-struct CtxKeys {
-    const uint8_t* win;
-    const uint32_t* ipos;
-    uint32_t nitems;
-    uint32_t* keys;
-    ORZ_HD void operator()(size_t t) const {
-        if (t < nitems) keys[t] = hash1(win, ipos[t] - 1);
-    }
-};
-struct CtxStarts {  // first sorted index of each ctx (binary search), c in [0, 256]
-    const uint32_t* keys;
-    uint32_t n;
-    uint32_t* cstart;
-    ORZ_HD void operator()(size_t c) const {
-        if (c > 256) return;
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) / 2;
-            if (keys[mid] < c) lo = mid + 1; else hi = mid;
-        }
-        cstart[c] = lo;
-    }
-};
-struct OrdAssign {  // exact ring ordinals (Bucket.head arithmetic, src/matcher.rs:62-80) of the block's item starts
-    const uint32_t *keys, *pos, *cstart, *ctxcount;
-    uint32_t n;
-    uint32_t* ORD;
-    ORZ_HD void operator()(size_t t) const {
-        if (t < n) ORD[pos[t]] = ctxcount[keys[t]] + (uint32_t)t - cstart[keys[t]];
-    }
-};
 struct FastSource {
     FastArgs a;
     uint32_t* SRC;
@@ -1433,17 +1394,26 @@ struct FastSource {
     // a run is still the newest unless the run gained an item start in the previous pass (rdirty, set by FastRecut /
     // FastWordCheck -- a new item's own run is marked, so new items are walked too), and it is still a ring member unless
     // the ordinals between it and the item grew past the ring (checked here with the fresh ordinals).
+    // ... and the ring check costs two dependent scattered loads per match, so a pass notes for every source it assigns
+    // whether it lies within kEdgeMargin item starts of the ring's end (`edge`); a later pass looks at the ordinals only
+    // for those, or when the context has gained more than kEdgeMargin item starts since the first pass (`cok`, FastCtxOk).
     const uint64_t* rdirty;
     uint32_t cap;  // item starts examined beyond the tabulated window before the search gives up (the item is cut then)
     const FastCtl* ctl;
+    uint8_t* edge;         // [n] the match's source is near the end of the ring
+    const uint32_t* cok;   // [256] the context has gained at most kEdgeMargin item starts since the first pass
+    static constexpr uint32_t kEdgeMargin = 1024;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
         const uint32_t p = kPre + (uint32_t)i, L = a.nl[i], K = a.K;
-        const uint32_t op = a.ORD[p];
         if (rdirty) {
-            const uint32_t key = bucket_key(a.win, p);
-            if (!((rdirty[key >> 6] >> (key & 63)) & 1) && op - 1 - a.ORD[SRC[p]] <= kRing - 1) return;
+            const uint32_t c = hash1(a.win, p - 1), key = c * kHash + hash_entry(a.win + p);
+            if (!((rdirty[key >> 6] >> (key & 63)) & 1)) {
+                if (!edge[i] && cok[c]) return;
+                if (a.ORD[p] - 1 - a.ORD[SRC[p]] <= kRing - 1) return;
+            }
         }
+        const uint32_t op = a.ORD[p];
         const uint32_t j = a.idx[p], r = fast_min(K, a.rlen[i]);
         const uint8_t* row = a.rows + (size_t)i * K;
         uint32_t best = 0, bsrc = 0, seen = 0, found = 0;
@@ -1483,11 +1453,25 @@ struct FastSource {
                 return --left != 0;
             });
         }
-        if (found) { SRC[p] = found; return; }
+        if (found) { SRC[p] = found; edge[i] = op - 1 - a.ORD[found] > kRing - 1 - kEdgeMargin; return; }
         atom_add32(a.nchg, 1);
         cutend[i] = p + L;
-        if (best >= kMinLen) { a.nl[i] = (uint8_t)best; SRC[p] = bsrc; }
+        if (best >= kMinLen) { a.nl[i] = (uint8_t)best; SRC[p] = bsrc; edge[i] = op - 1 - a.ORD[bsrc] > kRing - 1 - kEdgeMargin; }
         else { a.ty[i] = kTyLit; a.nl[i] = 1; }
+    }
+};
+struct FastCtxOk {  // thread per ctx: item starts of the context now against the first pass's (FastSource's `cok`)
+    const uint32_t* cp;
+    uint32_t nsub;
+    uint32_t* tot0;  // [256] totals at the first pass
+    uint32_t* cok;   // [256]
+    int first;
+    const FastCtl* ctl;
+    ORZ_HD void operator()(size_t c) const {
+        if (c >= 256 || ctl->done) return;
+        const uint32_t t = cp[(size_t)nsub * 256 + c];
+        if (first) { tot0[c] = t; cok[c] = 1; }
+        else cok[c] = t - tot0[c] <= FastSource::kEdgeMargin;
     }
 };
 struct FastRecut {  // the rest of a shortened item's span, from the last round's decisions, cut at the old end

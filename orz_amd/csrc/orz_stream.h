@@ -357,7 +357,7 @@ class StreamEncoder {
                 frdirty_ = take<uint64_t>((size_t)2 * kDirtyWords);
                 flaste_ = take<uint32_t>(nn);
                 fctl_ = take<FastCtl>(1);
-                fcstart_ = take<uint32_t>(260);
+                fcok_ = take<uint32_t>(512);
                 ffarv_ = take<uint32_t>(nn, false);
                 fcl_ = take<uint64_t>((size_t)kWLen * 2, false);
                 fccnt_ = take<uint32_t>(kNumKeys + 1);
@@ -782,7 +782,7 @@ class StreamEncoder {
             be_.launch(1, FastCtlReset{fctl_});
             int pass = 0;
             for (int group = 0; group < 64 && !h.done; group++) {
-                const int todo = group == 0 ? 5 : 2;  // (text converges in ~6 passes)
+                const int todo = group == 0 ? 6 : 2;  // (text: five passes that repair something and one that finds nothing)
                 for (int k = 0; k < todo; k++, pass++) {
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
@@ -794,7 +794,9 @@ class StreamEncoder {
                     uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
                     uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
-                    be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_});
+                    be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
+                    // (the round loop's dirty flags are dead by now: their array holds the sources' ring-edge flags)
+                    be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256});
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
@@ -805,7 +807,7 @@ class StreamEncoder {
                 be_.d2h(&h, fctl_, sizeof h);
             }
             if (!h.done) throw std::runtime_error("fast parse: repairs did not converge");
-            if (getenv("ORZ_FAST_SHOWFLIPS")) fprintf(stderr, "T=%u: %u item starts changed in their last round, %u repairs, %u items\n", T, h.lastflips, h.total, h.nmem);
+            if (getenv("ORZ_FAST_SHOWFLIPS")) fprintf(stderr, "T=%u: %u item starts changed in their last round, %u repairs in %u passes, %u items\n", T, h.lastflips, h.total, h.passes, h.nmem);
             stats.seg_evals += h.total;  // (fast mode: repairs made)
             // unstable = more than 1 % of the items repaired AND more than one repair per 2000 input bytes (sparse item
             // streams -- long zero runs -- reach the first mark with a handful of repairs that cost nothing).  Match-dense
@@ -1079,7 +1081,7 @@ class StreamEncoder {
     uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
     uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr;
     uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
-             *flaste_ = nullptr, *fcstart_ = nullptr, *ffarv_ = nullptr;
+             *flaste_ = nullptr, *fcok_ = nullptr, *ffarv_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr, *fcl_ = nullptr;
     uint32_t *fccnt_ = nullptr, *fcnew_ = nullptr;
     FastCtl* fctl_ = nullptr;
