@@ -792,7 +792,8 @@ struct FastRetire {  // thread per position of the tile
         const uint32_t i = p - kPre;
         if (!a.mfb[i]) return;
         const uint32_t j = a.idx[p], key = bucket_key(a.win, p), rl = a.rlen[i];
-        const uint32_t rs = a.runstart[key];
+        const uint32_t rs = a.runstart[key], base = a.ccnt[key];
+        const uint64_t t0 = a.stext[2 * (size_t)j], t1 = a.stext[2 * (size_t)j + 1];  // (asked for before the walk down the slots)
         const uint32_t maxk = rl < 255 ? rl : j - rs;  // run slots below j
         uint32_t good = 0, bad = maxk + 1;             // slots j - 1 .. j - good hold positions of this tile, slot j - bad does not
         for (uint32_t k = 1; k <= maxk; k <<= 1) {
@@ -803,8 +804,7 @@ struct FastRetire {  // thread per position of the tile
             if (a.epos[j - mid] >= lo) good = mid; else bad = mid;
         }
         const uint32_t at = popc_range(a.vbits, j - good, good);
-        const uint64_t t0 = a.stext[2 * (size_t)j], t1 = a.stext[2 * (size_t)j + 1];
-        uint64_t* dst = a.cl + 2 * ((size_t)rs + a.ccnt[key] + at);
+        uint64_t* dst = a.cl + 2 * ((size_t)rs + base + at);
         dst[0] = t0; dst[1] = t1;
         atom_add32(&a.cnew[key], 1);
         place[i] = at + 1;
@@ -1244,7 +1244,7 @@ struct CountWave {
         for (uint32_t c = lane; c < 256; c += 64) a.cm[(size_t)s * 256 + c] = cnt[c];
     }
 };
-// cp[s][c] = cp[s0][c] + sum of counts[s0 .. s)[c] for s in (s0, s1 + ext]: thread per (s, ctx), independent loads.
+// cp[s][c] = cp[s0][c] + sum of counts[s0 .. s)[c] for s in (s0, s1 + ext].
 // The counts are the path's own (cm) for the subtiles below `live_end` -- the tile in its last round, whose path is final
 // once this step has run -- and for the tiles behind it the counts of the same places in the newest tile below live_end:
 // the ring horizons of tiles that are still settling must not follow their own unsettled item counts (a sketch with too
@@ -1263,17 +1263,20 @@ struct FastPrefix {
         }
         return a.cm[(size_t)t * 256 + c];
     }
-    ORZ_HD void operator()(size_t tid) const {
-        const uint32_t c = (uint32_t)(tid & 255), s = s0 + 1 + (uint32_t)(tid >> 8);
-        if (s > s1 + ext) return;
-        uint32_t v0 = a.cp[(size_t)s0 * 256 + c], v1 = 0, v2 = 0, v3 = 0;
-        uint32_t t = s0;
-        for (; t + 4 <= s; t += 4) {
-            v0 += cmx(t, c); v1 += cmx(t + 1, c);
-            v2 += cmx(t + 2, c); v3 += cmx(t + 3, c);
+    // thread per ctx: the column's counts sixteen loads at a time, then the chain of adds (a thread per (subtile, ctx) that
+    // sums its own prefix issues ~80 dependent rounds of loads: 31 us a step against ~10)
+    ORZ_HD void operator()(size_t c) const {
+        if (c >= 256) return;
+        uint32_t v = a.cp[(size_t)s0 * 256 + c];
+        const uint32_t end = s1 + ext;
+        for (uint32_t s = s0; s < end; s += 16) {
+            uint32_t m[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) m[k] = s + k < end ? cmx(s + k, (uint32_t)c) : 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++)
+                if (s + k < end) { v += m[k]; a.cp[(size_t)(s + k + 1) * 256 + c] = v; }
         }
-        for (; t < s; t++) v0 += cmx(t, c);
-        a.cp[(size_t)s * 256 + c] = v0 + v1 + v2 + v3;
     }
 };
 

@@ -718,7 +718,7 @@ class StreamEncoder {
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
-            be_.launch((size_t)std::min(cpt, nsub) * 256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt, 0});
+            be_.launch(256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt, 0});
             be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
@@ -760,7 +760,7 @@ class StreamEncoder {
                 // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
                 // hardware queues the runtime gave the two streams: one chain it is.)
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
-                be_.launch((size_t)(nc + ext) * 256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0});
+                be_.launch(256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0});
                 be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
                 // the tile that has just had its last round is final: its item starts join the compact lists (while a later
                 // tile will still read them)
