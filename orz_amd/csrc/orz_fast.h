@@ -1131,7 +1131,7 @@ struct PathMark {  // thread per segment: its item starts as a 64-bit mask; the 
         a.sbits[s] = m;
     }
 };
-// Bring the slot-order bitmaps in line with the path (thread per eight positions), and mark the positions whose next evaluation
+// Bring the slot-order bitmaps in line with the path (thread per position), and mark the positions whose next evaluation
 // would see the difference (dirty).  A flipped item start matters to the later positions of its run for which it is among
 // the newest `dmax` item starts below them: walk up the run (slots ascend with the position) until that many set bits have
 // been passed, the run ends or the range that is still being re-evaluated (< mark_hi) is left; a flipped word update
@@ -1185,47 +1185,36 @@ struct FastFlip {
                 if (k + b < n && q[b] >= kPre) a.dirty[q[b] - kPre] = 1;
         }
     }
-    // thread per 8 positions (`lo` is tile-aligned): what the bitmaps hold and what the path says as three 8-byte loads and
-    // a byte of the path bitmap; the few positions that differ take the slow way one after the other
-    ORZ_HD size_t threads() const { return ((size_t)hi - lo + 8) / 8; }
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t y0 = lo + (uint32_t)tid * 8;
-        if (y0 > hi) return;
-        const uint32_t i0 = y0 - kPre;
+        const uint32_t y = lo + (uint32_t)tid;
+        if (y > hi) return;
+        const uint32_t i = y - kPre;
         const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;  // where the path leaves the range / the block
-        const uint64_t mf8 = *reinterpret_cast<const uint64_t*>(a.mfb + i0), ef8 = *reinterpret_cast<const uint64_t*>(a.efb + i0);
-        const uint64_t pt8 = *reinterpret_cast<const uint64_t*>(a.pt + i0);
-        const uint32_t sb8 = (uint32_t)(a.sbits[i0 / 64] >> (i0 & 63)) & 0xff;
-#pragma unroll 1
-        for (uint32_t b = 0; b < 8; b++) {
-            const uint32_t y = y0 + b, i = i0 + b;
-            if (y > hi) return;
-            const uint32_t mf = (uint32_t)(mf8 >> (8 * b)) & 0xff, ef = (uint32_t)(ef8 >> (8 * b)) & 0xff;
-            const uint32_t s = (uint32_t)(y == exit_at) | (y < a.len ? (sb8 >> b) & 1 : 0);
-            const uint32_t sw = y < a.len ? s : mf;
-            // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
-            const uint32_t ew = y >= kPre + 1 ? (uint32_t)(s && ((uint32_t)(pt8 >> (8 * b)) & 0xff) != kTyWord) : ef;
-            const bool dv = sw != mf, de = ew != ef;
-            if (!dv && !de) continue;
-            // ---- loads
-            const uint32_t j = dv ? a.idx[y] : 0, ku = de ? a.kidx[y - 2] : 0;
-            const uint32_t nv = dv && y < mark_hi ? walk(false, j, y) : 0;
-            const uint32_t nk = de && y - 2 < mark_hi ? walk(true, ku, y - 2) : 0;
-            // ---- stores
-            if (dv) {
-                if (y < last_hi) atom_add32(lastflips, 1);
-                if (a.dbg & 64) atom_add64(&a.stats[16], 1);
-                atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
-                if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
-                a.mfb[i] = (uint8_t)sw;
-                mark(false, j, nv);
-            }
-            if (de) {
-                if (a.dbg & 64) atom_add64(&a.stats[17], 1);
-                atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-                a.efb[i] = (uint8_t)ew;
-                mark(true, ku, nk);
-            }
+        const uint32_t mf = a.mfb[i], ef = a.efb[i];
+        const uint32_t s = (uint32_t)(y == exit_at) | (y < a.len ? (uint32_t)((a.sbits[i / 64] >> (i & 63)) & 1) : 0);
+        const uint32_t sw = y < a.len ? s : mf;
+        // words[] update of the item ending at y (src/lz.rs:203,233): u = y - 2
+        const uint32_t ew = y >= kPre + 1 ? (uint32_t)(s && a.pt[i] != kTyWord) : ef;
+        const bool dv = sw != mf, de = ew != ef;
+        if (!dv && !de) return;
+        // ---- loads
+        const uint32_t j = dv ? a.idx[y] : 0, ku = de ? a.kidx[y - 2] : 0;
+        const uint32_t nv = dv && y < mark_hi ? walk(false, j, y) : 0;
+        const uint32_t nk = de && y - 2 < mark_hi ? walk(true, ku, y - 2) : 0;
+        // ---- stores
+        if (dv) {
+            if (y < last_hi) atom_add32(lastflips, 1);
+            if (a.dbg & 64) atom_add64(&a.stats[16], 1);
+            atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+            if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
+            a.mfb[i] = (uint8_t)sw;
+            mark(false, j, nv);
+        }
+        if (de) {
+            if (a.dbg & 64) atom_add64(&a.stats[17], 1);
+            atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+            a.efb[i] = (uint8_t)ew;
+            mark(true, ku, nk);
         }
     }
 };

@@ -755,7 +755,7 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                { const FastFlip ff{a, lo, fhi, t_hi + 1, mark_hi, step >= R ? (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T) : 0, &fctl_->lastflips}; be_.launch(ff.threads(), ff); }
+                be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi, step >= R ? (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T) : 0, &fctl_->lastflips});
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them.  (As a
                 // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
                 // hardware queues the runtime gave the two streams: one chain it is.)
@@ -784,7 +784,7 @@ class StreamEncoder {
             for (int group = 0; group < 64 && !h.done; group++) {
                 const int todo = group == 0 ? 6 : 2;  // (text: five passes that repair something and one that finds nothing)
                 for (int k = 0; k < todo; k++, pass++) {
-                    { const FastFlip ff{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips}; be_.launch(ff.threads(), ff); }
+                    be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
                     be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
                     col_scan(fcm_, nsub, fcp_);
@@ -798,7 +798,7 @@ class StreamEncoder {
                     // (the round loop's dirty flags are dead by now: their array holds the sources' ring-edge flags)
                     be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256});
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
-                    { const FastFlip ff{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips}; be_.launch(ff.threads(), ff); }
+                    be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
                     be_.inclusive_max_scan_u32(f32_, flaste_, nk);
                     be_.launch(n, FastWordCheck{a, flaste_, rd_out, fctl_});
