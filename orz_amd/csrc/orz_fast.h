@@ -39,7 +39,8 @@ constexpr uint32_t kSeg64 = 64;                    // positions per path segment
 constexpr uint32_t kNSub = kNewMax / kSub + 2;
 constexpr uint32_t kEntries = 240;                 // a path enters a chunk / tile within its first 240 positions
 
-constexpr uint32_t kFastK = 64;                    // run predecessors tabulated per position (one word of the member bitmap)
+constexpr uint32_t kFastK = 32;                    // run predecessors tabulated per position (half a word of the member bitmap; 64: twice the
+                                                   // table and its build for -0.05 % of output -- deeper candidates come from the lists)
 constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the history: window offset x lies in subtile (x + 1) >> 12
 constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
 constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile.  Measured on a full block,
@@ -69,7 +70,6 @@ struct FastArgs {
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
     uint32_t far;               // slots searched beyond the tabulated K through the bitmap (FastSource; FastEval for item starts not in the lists yet)
     uint32_t near;              // item starts a scan takes from there (0 = none)
-    uint32_t kwin;              // (experiments) run predecessors the window shows: kFastK, or fewer
     uint32_t extra;             // candidates a scan may look at beyond the reference's depth (window + below the window + lists)
     // compact lists: per (ctx, hash) run the records of its FINAL item starts (history, then the tiles that had their last
     // round, appended by FastRetire) side by side from the run's first slot on, oldest first
@@ -355,7 +355,7 @@ struct FastRowsWave {
     const uint32_t* epos;
     const uint64_t* stext;
     const uint8_t* rlen;
-    uint32_t nent, K;  // K is a multiple of 64
+    uint32_t nent, K;  // K = 32 or a multiple of 64
     uint8_t* rows;
     uint64_t* rdist;   // [n] distance codes of the sampled predecessors (dist_valid)
     static constexpr uint32_t kOutStride = 72;  // bytes per lane in the staging tile (64 + pad against bank conflicts)
@@ -388,8 +388,10 @@ struct FastRowsWave {
             }
             rdist[p - kPre] = codes;
         }
-        for (uint32_t c0 = 0; c0 < K; c0 += 64) {
-            for (uint32_t k0 = 0; k0 < 64; k0 += 8) {
+        const uint32_t cols = K < 64 ? K : 64;       // columns per pass (K = 32, or a multiple of 64)
+        const uint32_t parts = cols / 16;            // lanes that share one row's piece of a pass
+        for (uint32_t c0 = 0; c0 < K; c0 += cols) {
+            for (uint32_t k0 = 0; k0 < cols; k0 += 8) {
                 uint64_t pack = 0;
                 for (uint32_t kk = 0; kk < 8; kk++) {
                     const uint32_t k = c0 + k0 + kk;
@@ -405,10 +407,10 @@ struct FastRowsWave {
                 *reinterpret_cast<uint64_t*>(outL + lane * kOutStride + k0) = pack;
             }
             w.sync();
-            for (uint32_t it = 0; it < 4; it++) {  // 16 rows per pass, four lanes per 64-byte piece
-                const uint32_t row = it * 16 + (lane >> 2), part = lane & 3;
+            for (uint32_t it = 0; it < parts; it++) {  // 64 / parts rows per pass, `parts` lanes per row piece of 16 * parts bytes
+                const uint32_t row = it * (64 / parts) + lane / parts, part = lane % parts;
                 const uint32_t pr = rec_pos(t1[K + row]);
-                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {  // (whole 64-byte lines: pieces of a line cost a read-modify-write)
+                if ((int64_t)w.block() * 64 + row < (int64_t)nent && pr >= kPre) {  // (whole row pieces: parts of a line cost a read-modify-write)
                     const uint64_t v0 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16);
                     const uint64_t v1 = *reinterpret_cast<const uint64_t*>(outL + row * kOutStride + part * 16 + 8);
                     uint64_t* dst = reinterpret_cast<uint64_t*>(rows + (size_t)(pr - kPre) * K + c0 + part * 16);
@@ -569,7 +571,7 @@ struct FastEval {
         const uint32_t i = p - kPre;
         const uint32_t rl = a.rlen[i];
         const bool first = p >= r1lo;
-        const bool longrun = rl > a.kwin;
+        const bool longrun = rl > kFastK;
         // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules)
         const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
         const bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
@@ -597,15 +599,15 @@ struct FastEval {
         g_eval_stats[1]++;
 #endif
         // ---- everything the evaluation reads, asked for up front: position-ordered statics, then the two bitmap windows
-        const uint32_t j = a.idx[p], kj = a.kidx[p], r = fast_min(a.kwin, rl);
+        const uint32_t j = a.idx[p], kj = a.kidx[p], r = fast_min(kFastK, rl);
         const uint32_t km = a.kmeta[i], rk = km & 0x7f;
         const uint64_t wm = a.wmask[i];
         const uint32_t h5 = hz[1];
-        uint32_t rw[16];  // the row of common prefixes, in registers (only the 16-byte pieces the run depth reaches)
+        uint32_t rw[kFastK / 4];  // the row of common prefixes, in registers (only the 16-byte pieces the run depth reaches)
         {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(a.rows + (size_t)i * kFastK);
 #pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
+            for (uint32_t q = 0; q < kFastK / 16; q++) {
                 if (r > q * 16) {
 #pragma unroll
                     for (uint32_t d = 0; d < 4; d++) rw[q * 4 + d] = src[q * 4 + d];
@@ -629,7 +631,7 @@ struct FastEval {
         uint32_t best = 0, bk = 0, m1 = 0, m2 = 0, seen = 0;
         bool full = false;  // a candidate matched all 240 bytes: nothing older is looked at
 #pragma unroll
-        for (uint32_t k = 0; k < 64; k++) {
+        for (uint32_t k = 0; k < kFastK; k++) {
             if ((k & 15) == 0 && !(mask & (~0ull >> k))) break;  // no item start left in the window
             const uint32_t l = (rw[k >> 2] >> (8 * (k & 3))) & 0xff;
             if (((mask >> (63 - k)) & 1) && !full && seen < a.depth) {
@@ -666,7 +668,7 @@ struct FastEval {
                 // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
                 // inside the tiles that are still in their rounds: the lists' records lie outside it and this walk is all.)
                 if (a.near && p > cline) {
-                    uint32_t top = j - a.kwin;
+                    uint32_t top = j - kFastK;
                     const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
                     uint32_t left = fast_min(a.near, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
                     bool more = left != 0;
@@ -1155,7 +1157,7 @@ struct FastFlip {
         const uint32_t* pos = words ? a.kpos : a.epos;
         const uint64_t* bits = words ? a.kbits : a.vbits;
         const uint32_t lim = words ? 1u : a.dmax;
-        const uint32_t end = fast_min(words ? a.nk : a.nent, slot + 1 + 64);
+        const uint32_t end = words ? fast_min(a.nk, slot + 1 + 64) : fast_min(a.nent, slot + 1 + kFastK);  // (the windows that show the slot)
         uint32_t passed = 0, n = 0;
         for (uint32_t s = slot + 1; s < end; s += kTrip) {
             if (a.dbg & 64) atom_add64(&a.stats[words ? 19 : 18], 1);

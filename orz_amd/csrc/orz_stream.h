@@ -671,7 +671,6 @@ class StreamEncoder {
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
-        a.kwin = getenv("ORZ_FAST_KWIN") ? (uint32_t)atoi(getenv("ORZ_FAST_KWIN")) : kFastK;
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 16;
         // (candidates beyond the reference's depth: half as many again keeps the sizes centred on the reference's -- text,
         // 256 KiB tiles x 3 rounds: -l0 / -l1 / -l2 within 0.1 % of the oracle; the full depth again gives -0.4 ... -0.1 %)
@@ -1073,7 +1072,7 @@ class StreamEncoder {
     Cfg cfg_;
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
-    uint32_t ftile_ = kFastTile, frounds_ = kFastRounds, fK_ = 64;
+    uint32_t ftile_ = kFastTile, frounds_ = kFastRounds, fK_ = kFastK;
     bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr;
