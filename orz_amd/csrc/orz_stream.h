@@ -672,9 +672,10 @@ class StreamEncoder {
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 16;
-        // (candidates beyond the reference's depth: half as many again keeps the sizes centred on the reference's -- text,
-        // 256 KiB tiles x 3 rounds: -l0 / -l1 / -l2 within 0.1 % of the oracle; the full depth again gives -0.4 ... -0.1 %)
-        a.extra = getenv("ORZ_FAST_EXTRA") ? (uint32_t)atoi(getenv("ORZ_FAST_EXTRA")) : (a.depth + 1) / 2;
+        // (candidates beyond the reference's depth: half as many again -- a third at shallow depths -- keeps the sizes centred
+        // on the reference's: text, full block, -l0 / -l1 / -l2: -0.20 / 0.00 / +0.17 %; 6 MB at -l0: -0.53 / -0.36 / -0.18 %
+        // with 3 / 2 / 1 more than its 5; the full depth again gives -0.6 ... -0.1 %)
+        a.extra = getenv("ORZ_FAST_EXTRA") ? (uint32_t)atoi(getenv("ORZ_FAST_EXTRA")) : (a.depth + 1) / (a.depth < 10 ? 3 : 2);
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
