@@ -293,10 +293,10 @@ class StreamEncoder {
             ring_ = wsegs_ + 8;
             winbuf_ = take<uint8_t>((size_t)kBlock + 2 * kSent + 64);
             S_ = take<uint8_t>(kWLen);
-            E_ = take<uint8_t>(kWLen);
+            if (!fast_) E_ = take<uint8_t>(kWLen);  // (exact mode only, like LR_)
             ML_ = take<uint8_t>(kWLen);
             ORD_ = take<uint32_t>(kWLen);
-            LR_ = take<uint8_t>(kWLen);
+            if (!fast_) LR_ = take<uint8_t>(kWLen);
             SRC_ = take<uint32_t>(kWLen, false);
             W0_ = take<uint8_t>(kWLen);
             TY_ = take<uint8_t>(kWLen);
@@ -796,7 +796,9 @@ class StreamEncoder {
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
                     // (the round loop's dirty flags are dead by now: their array holds the sources' ring-edge flags)
-                    be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256});
+                    const FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
+                    if (fs.rdirty) be_.launch(((size_t)n + 63) / 64, FastSourceSweep{fs});
+                    else be_.launch(n, fs);
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
@@ -1117,7 +1119,7 @@ class StreamEncoder {
     uint32_t lead_unit_ = 0;       // unit size of a stream's lead block (0 = off)
     std::vector<int> pend_order_;  // sets whose output is still on the device, oldest first
     uint8_t* winbuf_;
-    uint8_t *S_, *E_, *ML_, *LR_, *W0_, *TY_, *LENMIN_, *LMV_;
+    uint8_t *S_, *E_ = nullptr, *ML_, *LR_ = nullptr, *W0_, *TY_, *LENMIN_, *LMV_;
     uint32_t *ORD_, *SRC_;
     uint32_t *idx_, *kidx_, *epos_, *kpos_, *runstart_, *krun_, *krunend_;
     uint64_t *entA_, *entB_, *vbits_, *v1_, *v2_, *kbits_, *k1_, *k2_;
