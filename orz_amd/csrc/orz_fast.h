@@ -1465,57 +1465,6 @@ struct FastSource {
         else { a.ty[i] = kTyLit; a.nl[i] = 1; }
     }
 };
-// A later pass of FastSource as a sweep: a thread per 64 positions takes their item-start word, the type and edge bytes
-// (sixteen 8-byte loads up front), settles in chunks of eight matches which of them need another look -- their run
-// gained an item start, or their source may have left the ring -- and only those go through FastSource proper.  (As a
-// thread per position the pass is 16.7 M threads of which nearly all load a few bytes and return: 350 us; text needs
-// five such passes a block.)
-struct FastSourceSweep {
-    FastSource f;
-    ORZ_HD void operator()(size_t t) const {
-        const FastArgs& a = f.a;
-        if (t * 64 >= a.n || f.ctl->done) return;
-        uint64_t m = a.sbits[t];
-        if (!m) return;
-        const size_t i0 = t * 64;
-        uint64_t ty8[8], ed8[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            ty8[k] = *reinterpret_cast<const uint64_t*>(a.ty + i0 + 8 * k);
-            ed8[k] = *reinterpret_cast<const uint64_t*>(f.edge + i0 + 8 * k);
-        }
-        // keep the matches only
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++)
-#pragma unroll
-            for (uint32_t b = 0; b < 8; b++)
-                if (((ty8[k] >> (8 * b)) & 0xff) != kTyMatch) m &= ~(1ull << (8 * k + b));
-        while (m) {
-            uint32_t pos[8], nb = 0;
-            uint64_t w8[8];
-            for (; nb < 8 && m; nb++) { pos[nb] = (uint32_t)ctz64(m); m &= m - 1; }
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) w8[k] = k < nb ? ldu64(a.win + kPre + i0 + pos[k] - 2) : 0;  // the bytes of hash1 and the hash entry
-            uint32_t key[8], ctx[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint8_t* bt = reinterpret_cast<const uint8_t*>(&w8[k]);
-                ctx[k] = (uint32_t)(bt[1] & 0x7f) | ((uint32_t)is_alnum(bt[0]) << 7);
-                key[k] = ctx[k] * kHash + hash_entry(bt + 2);
-            }
-            uint64_t rd[8];
-            uint32_t ok[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) { rd[k] = k < nb ? f.rdirty[key[k] >> 6] : 0; ok[k] = k < nb ? f.cok[ctx[k]] : 1; }
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                if (k >= nb) break;
-                const uint32_t e = (uint32_t)(ed8[pos[k] >> 3] >> (8 * (pos[k] & 7))) & 0xff;
-                if (((rd[k] >> (key[k] & 63)) & 1) || e || !ok[k]) f(i0 + pos[k]);
-            }
-        }
-    }
-};
 struct FastCtxOk {  // thread per ctx: item starts of the context now against the first pass's (FastSource's `cok`)
     const uint32_t* cp;
     uint32_t nsub;

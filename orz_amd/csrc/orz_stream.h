@@ -796,9 +796,10 @@ class StreamEncoder {
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
                     // (the round loop's dirty flags are dead by now: their array holds the sources' ring-edge flags)
-                    const FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
-                    if (fs.rdirty) be_.launch(((size_t)n + 63) / 64, FastSourceSweep{fs});
-                    else be_.launch(n, fs);
+                    // (a later pass as a sweep -- a thread per 64 positions that settles from the item-start word and the
+                    // type / edge bytes which matches need another look -- measured no faster: 330 vs 350 us, the threads
+                    // that do find work run it one match after the other)
+                    be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256});
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
