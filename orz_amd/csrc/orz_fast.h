@@ -91,6 +91,7 @@ struct FastArgs {
     uint32_t *centry, *tentry;  // path entry of each chunk / tile
     uint32_t *cm, *cp;          // [kNSub][256] item starts per (subtile, ctx) and their exclusive prefix (+ carried totals)
     uint32_t* nchg;
+    const uint32_t* nentp;      // -> FastCtl::nent
     uint32_t dbg;               // experiment switches (ORZ_FAST_DBG): 1 = evaluate every position every round, 64 = collect `stats`
     unsigned long long* stats;  // [32] counters / wall-clock ticks of kernel phases when dbg & 64 (diagnostics only)
 };
@@ -1157,7 +1158,7 @@ struct FastFlip {
         const uint32_t* pos = words ? a.kpos : a.epos;
         const uint64_t* bits = words ? a.kbits : a.vbits;
         const uint32_t lim = words ? 1u : a.dmax;
-        const uint32_t end = words ? fast_min(a.nk, slot + 1 + 64) : fast_min(a.nent, slot + 1 + kFastK);  // (the windows that show the slot)
+        const uint32_t end = words ? fast_min(a.nk, slot + 1 + 64) : fast_min(*a.nentp, slot + 1 + kFastK);  // (the windows that show the slot)
         uint32_t passed = 0, n = 0;
         for (uint32_t s = slot + 1; s < end; s += kTrip) {
             if (a.dbg & 64) atom_add64(&a.stats[words ? 19 : 18], 1);
@@ -1314,12 +1315,21 @@ struct FastCtl {
     uint32_t acc;
     uint32_t lt;       // type of the item that ended at the block end (carried to the next block)
     uint32_t lastflips;  // item starts that still changed in their tile's LAST round (FastFlip): the rounds had not settled
+    uint32_t nent;       // slots of the block's candidate lists -- read by the kernels of the round loop from HERE, not from their
+                         // arguments: the loop is replayed as a graph whose arguments are those of the block it was captured on
 };
 struct FastCtlReset {
     FastCtl* ctl;
     ORZ_HD void operator()(size_t tid) const {
         if (tid) return;
         ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;  // (lastflips: reset before the rounds)
+    }
+};
+struct FastSetNent {
+    FastCtl* ctl;
+    uint32_t nent;
+    ORZ_HD void operator()(size_t tid) const {
+        if (!tid) ctl->nent = nent;
     }
 };
 struct FastPassEnd {

@@ -676,7 +676,8 @@ class StreamEncoder {
         // on the reference's: text, full block, -l0 / -l1 / -l2: -0.20 / 0.00 / +0.17 %; 6 MB at -l0: -0.53 / -0.36 / -0.18 %
         // with 3 / 2 / 1 more than its 5; the full depth again gives -0.6 ... -0.1 %)
         a.extra = getenv("ORZ_FAST_EXTRA") ? (uint32_t)atoi(getenv("ORZ_FAST_EXTRA")) : (a.depth + 1) / (a.depth < 10 ? 3 : 2);
-        a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg;
+        a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg; a.nentp = &fctl_->nent;
+        be_.launch(1, FastSetNent{fctl_, nent});
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
         a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
         if (a.dbg & 64) be_.memset(a.stats, 0, 32 * 8);

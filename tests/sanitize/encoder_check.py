@@ -37,3 +37,12 @@ for name, data, lv, tile, rounds in [("mixed", _data.mixed(60_000, seed=2), 1, 4
                                      ("odd", _data.mixed(4097 + 63, seed=8), 1, 4096, 4)]:
     out = enc_fast(data, _oracle.LEVELS[lv], tile, rounds)
     print("fast", name, len(out), _oracle.decode(out)[0] == data)
+
+# two blocks + a short tail with the default schedule (history lists, window slide, retired tiles, graph-free launch order):
+# slow under the sanitizers (minutes); ORZ_SAN_BIG=0 skips it
+if os.environ.get("ORZ_SAN_BIG", "1") != "0":
+    import corpus  # noqa: E402
+
+    data = corpus.enwik_like(36_000_000)
+    out = enc_fast(data, _oracle.LEVELS[1])
+    print("fast two blocks + tail", len(out), _oracle.decode(out)[0] == data)
