@@ -56,12 +56,13 @@ struct Flags32 {
         if (tid < n) f[tid] = S[kPre + tid];
     }
 };
-struct SumLast {  // out[0] = scan[last] + flag[last]: the total of an exclusive scan, so that the host reads one word
+struct SumLast {  // out[0] = scan[last] + flag[last]: the total of an exclusive scan, so that the host reads one word;
+                  // out[1] = flag[1] (is the block's second position an item start: see hist_hint_)
     const uint32_t *scan, *flag;
     uint32_t last;
     uint32_t* out;
     ORZ_HD void operator()(size_t tid) const {
-        if (!tid) out[0] = scan[last] + flag[last];
+        if (!tid) { out[0] = scan[last] + flag[last]; out[1] = last >= 1 ? flag[1] : 0; }
     }
 };
 struct CompactPos32 {
@@ -367,7 +368,7 @@ class StreamEncoder {
             sc32_ = take<uint32_t>(kWLen, false);
             hpos_ = take<uint32_t>(kPre + 1);
             ctxcount_ = take<uint32_t>(256);
-            tailkey_ = take<uint32_t>(4);
+            tailkey_ = take<uint32_t>(8);
             wsnap_ = take<uint8_t>(65536);
             wlast_ = take<uint32_t>(32768);
             // items and tail-stage buffers: two sets, taken by the blocks alternately (see post_stage)
@@ -429,6 +430,7 @@ class StreamEncoder {
         pend_order_.clear();
         cur_set_ = 0;
         lt_carry_ = kTyLit;
+        hist_hint_ = ~0u;
         if (fast_) { const uint32_t lt = kTyLit; be_.h2d(&fctl_->lt, &lt, 4); }
         stream_start_ = true;
         stats = EncodeStats();
@@ -465,7 +467,15 @@ class StreamEncoder {
             be_.exclusive_scan_u32(f32_, sc32_, kPre);
             be_.launch(1, SumLast{sc32_, f32_, kPre - 1, tailkey_ + 3});
             be_.launch(kPre, CompactPos32{f32_, sc32_, kPre, 0, hpos_});
-            be_.d2h(&nhist, tailkey_ + 3, 4);
+            // After a slide by a whole block the history IS the block before: its items but the first (it left the window)
+            // and one at the second position (it sits at offset 0 now, which is dead, src/matcher.rs:85) -- the host knows
+            // that count since it read the block's item total: no read-back, no synchronisation here.
+            if (hist_hint_ != ~0u && !be_.check_hints()) nhist = hist_hint_;
+            else {
+                be_.d2h(&nhist, tailkey_ + 3, 4);
+                if (hist_hint_ != ~0u && hist_hint_ != nhist) throw std::runtime_error("history item count differs from the host's arithmetic");
+            }
+            hist_hint_ = ~0u;
         }
         // ---- candidate lists: stable radix sort of positions by (ctx8, hash) and by hash2
         const uint32_t nent = nhist + n;
@@ -859,7 +869,12 @@ class StreamEncoder {
         uint32_t nitems = 0;
         be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
         be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
-        be_.d2h(&nitems, tailkey_ + 3, 4);
+        {
+            uint32_t two[2] = {0, 0};
+            be_.d2h(two, tailkey_ + 3, 8);
+            nitems = two[0];
+            hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by)
+        }
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
         const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
@@ -1014,6 +1029,7 @@ class StreamEncoder {
     void slide(bool slide_window = true) { slide_by(last_n_, 0, slide_window); }
     // slide by `sh` positions; `extra` bytes behind the encoded region (the block's later units) move along
     void slide_by(uint32_t sh, uint32_t extra, bool slide_window = true) {
+        if (sh != kNewMax) hist_hint_ = ~0u;
         be_.launch(3, TailKeys{dwin(), kPre + sh, tailkey_});
         if (slide_window) be_.d2d(dwin(), dwin() + sh, (size_t)kPre + extra);
         for (uint32_t off = 0; off < kPre; off += sh) {
@@ -1112,6 +1128,7 @@ class StreamEncoder {
     TailSet ts_[2];
     int cur_set_ = 0;
     uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)
+    uint32_t hist_hint_ = ~0u;   // history item starts of the next block as the host computes them (~0 = ask the device)
     uint32_t unit_base_ = 0;     // bytes of the current block encoded by earlier units (chunk headers carry decoder positions)
     // fast mode: bytes per unit of a block (ORZ_FAST_UNIT; a multiple of 4096).  Measured on the 100 MB workload: 8 MiB units
     // fill the pipeline 18 ms sooner but cost 28 ms of parse (the history is sorted once per unit, the round pipeline and

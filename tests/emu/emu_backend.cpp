@@ -33,6 +33,7 @@ struct EmuBackend {
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
+    bool check_hints() const { return true; }  // (the emulation verifies every count the host derives)
     uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
     uint32_t handoff_deadline() const { return 0; }
     uint32_t near_blocks() const { return 16; }  // small windows here: exercise the far-wave paths too
