@@ -881,13 +881,14 @@ struct FastHorizon {
         if (m) h -= (uint32_t)(((uint64_t)fast_min(left, m) * kSub) / m);
         return h > 1 ? h : 1;
     }
+    // a thread per (subtile, ctx, which horizon): the two binary searches side by side instead of one after the other
+    ORZ_HD size_t threads() const { return (size_t)(s1 - s0 + 1) * 512; }
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t c = (uint32_t)(tid & 255), s = s0 + (uint32_t)(tid >> 8);
+        const uint32_t which = (uint32_t)(tid & 1), c = (uint32_t)((tid >> 1) & 255), s = s0 + (uint32_t)(tid >> 9);
         if (s > s1) return;
         uint32_t* hz = a.hz + ((size_t)s * 256 + c) * 4;
-        hz[2] = hz[0]; hz[3] = hz[1];
-        hz[0] = horizon(s, c, kRing - kRingMargin);
-        hz[1] = horizon(s, c, 510);
+        hz[2 + which] = hz[which];
+        hz[which] = horizon(s, c, which ? 510 : kRing - kRingMargin);
     }
 };
 // src/lz.rs:139-234 on the snapshot's answers: e = ev of the position, e1 / e2 = ev of the next two (0 past the end);
@@ -1266,19 +1267,23 @@ struct FastPrefix {
         }
         return a.cm[(size_t)t * 256 + c];
     }
-    // thread per ctx: the column's counts sixteen loads at a time, then the chain of adds (a thread per (subtile, ctx) that
-    // sums its own prefix issues ~80 dependent rounds of loads: 31 us a step against ~10)
-    ORZ_HD void operator()(size_t c) const {
-        if (c >= 256) return;
-        uint32_t v = a.cp[(size_t)s0 * 256 + c];
+    // one wavefront per ctx, lane = subtile: 64 counts per trip, an inclusive scan across the lanes, 64 prefixes out (a
+    // thread per ctx with sixteen loads a trip, or a thread per (subtile, ctx) that sums its own prefix: ~31 us a step)
+    static size_t lds_bytes() { return 0; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        const uint32_t c = w.block(), lane = w.lane();
+        uint32_t carry = a.cp[(size_t)s0 * 256 + c];
         const uint32_t end = s1 + ext;
-        for (uint32_t s = s0; s < end; s += 16) {
-            uint32_t m[16];
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) m[k] = s + k < end ? cmx(s + k, (uint32_t)c) : 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++)
-                if (s + k < end) { v += m[k]; a.cp[(size_t)(s + k + 1) * 256 + c] = v; }
+        for (uint32_t base = s0; base < end; base += 64) {
+            const uint32_t s = base + lane;
+            uint32_t v = s < end ? cmx(s, c) : 0;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t t = w.shfl(v, lane >= d ? lane - d : lane);
+                if (lane >= d) v += t;
+            }
+            if (s < end) a.cp[(size_t)(s + 1) * 256 + c] = carry + v;
+            carry += w.bcast(v, 63);
         }
     }
 };

@@ -729,8 +729,8 @@ class StreamEncoder {
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
-            be_.launch(256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt, 0});
-            be_.launch((size_t)std::min(cpt, nsub) * 256, FastHorizon{a, 0, std::min(cpt, nsub) - 1});
+            be_.launch_waves(256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt, 0}, 0);
+            { const FastHorizon fh{a, 0, std::min(cpt, nsub) - 1}; be_.launch(fh.threads(), fh); }
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
@@ -756,7 +756,9 @@ class StreamEncoder {
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
                 // (the compact lists hold the tiles that had their last round before this step)
                 const uint32_t cline = kPre + (step > R ? step - R : 0) * T;
-                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
+                static const bool w8 = getenv("ORZ_EVAL_W8") && atoi(getenv("ORZ_EVAL_W8")) != 0;  // (experiment: 64-VGPR build of FastEval, eight waves per SIMD at the price of spills)
+                if (w8) be_.launch_w8(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
+                else be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
@@ -771,8 +773,8 @@ class StreamEncoder {
                 // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
                 // hardware queues the runtime gave the two streams: one chain it is.)
                 const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
-                be_.launch(256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0});
-                be_.launch((size_t)(nc + ext) * 256, FastHorizon{a, c0, c0 + nc + ext - 1});
+                be_.launch_waves(256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0}, 0);
+                { const FastHorizon fh{a, c0, c0 + nc + ext - 1}; be_.launch(fh.threads(), fh); }
                 // the tile that has just had its last round is final: its item starts join the compact lists (while a later
                 // tile will still read them)
                 if (step >= R && step < ntile + R - 1) {
