@@ -33,14 +33,6 @@ __global__ __launch_bounds__(256) void orz_thread_kernel(F f, size_t n) {
     if (tid < n) f(tid);
 }
 
-// the same with the register budget of eight waves per SIMD (64 VGPRs): for kernels whose time is occupancy rounds x a
-// chain of dependent loads (FastEval)
-template <class F>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void orz_thread_kernel_w8(F f, size_t n) {
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < n) f(tid);
-}
-
 // wave-cooperative kernels: one 64-lane wavefront per block, dynamic LDS
 struct DevWave {
     uint8_t* lds_;
@@ -658,13 +650,6 @@ class HipBackend {
         if (!n) return;
         const unsigned grid = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(orz_thread_kernel<F>, dim3(grid), dim3(256), 0, stream_, f, n);
-        ORZ_HIP_CHECK(hipGetLastError());
-    }
-    template <class F>
-    void launch_w8(size_t n, const F& f) {
-        if (!n) return;
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(orz_thread_kernel_w8<F>, dim3(grid), dim3(256), 0, stream_, f, n);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     template <class K>

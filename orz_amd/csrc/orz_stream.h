@@ -756,9 +756,8 @@ class StreamEncoder {
                 const uint32_t mark_hi = step - 1 < ntile ? kPre + (step - 1) * T : len;
                 // (the compact lists hold the tiles that had their last round before this step)
                 const uint32_t cline = kPre + (step > R ? step - R : 0) * T;
-                static const bool w8 = getenv("ORZ_EVAL_W8") && atoi(getenv("ORZ_EVAL_W8")) != 0;  // (experiment: 64-VGPR build of FastEval, eight waves per SIMD at the price of spills)
-                if (w8) be_.launch_w8(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
-                else be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
+                // (a 64-register build of FastEval -- eight waves per SIMD instead of six, 41 registers spilled -- measured 134 vs 124 us)
+                be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
                 be_.timed_end();
                 be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;

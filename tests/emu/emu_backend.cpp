@@ -59,7 +59,6 @@ struct EmuBackend {
     template <class F> void launch(size_t n, const F& f) {
         for (size_t i = 0; i < n; i++) f(i);
     }
-    template <class F> void launch_w8(size_t n, const F& f) { launch(n, f); }
     template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, seed++);
     }
