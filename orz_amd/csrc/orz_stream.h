@@ -1039,7 +1039,7 @@ class StreamEncoder {
             be_.launch(sh, SlideArray<uint32_t>{ORD_, off, sh, kPre});
             be_.launch(sh, SlideArray<uint8_t>{LENMIN_, off, sh, kPre});
         }
-        be_.sync();
+        // (no synchronisation: whatever fills the window next is queued on this stream behind the slide)
     }
     // Encode the `take` new bytes at dwin()[kPre, kPre + take) -- one block of the stream loop (src/lib.rs:72-84).  The exact
     // mode takes them as one block, like the reference.  The fast mode can cut the block into units (ORZ_FAST_UNIT; off by
