@@ -605,6 +605,7 @@ class HipBackend {
         return (T*)p;
     }
     void free(void* p) { (void)hipFree(p); }
+    void poison(void*, size_t) {}  // (the emulation backend fills state that must never be read before it is written)
     void memset(void* p, int v, size_t n) {
         if (n) ORZ_HIP_CHECK(hipMemsetAsync(p, v, n, stream_));
     }

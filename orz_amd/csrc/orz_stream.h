@@ -429,6 +429,16 @@ class StreamEncoder {
         for (TailSet& t : ts_) t.pending = false;
         pend_order_.clear();
         cur_set_ = 0;
+        if (fast_) {
+            // Round state that no parse resets because every entry is written before it is read: the emulation fills it
+            // with garbage here (HIP: nothing), so that a read of something left over by an earlier stream cannot hide --
+            // a reused encoder must write what a fresh one writes (tests/test_emu_fast.py)
+            const size_t nn = (size_t)kNewMax + 512;
+            be_.poison(fhz_, (size_t)(kNSub + 2) * 256 * 4 * 4);
+            be_.poison(fdirty_, nn);
+            be_.poison(ffarv_, nn * 4);
+            be_.poison(fev_, nn * 4);
+        }
         lt_carry_ = kTyLit;
         hist_hint_ = ~0u;
         if (fast_) { const uint32_t lt = kTyLit; be_.h2d(&fctl_->lt, &lt, 4); }
@@ -729,8 +739,9 @@ class StreamEncoder {
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
-            be_.launch_waves(256, FastPrefix{a, 0, 0, std::min(cpt, nsub), cpt, 0}, 0);
-            { const FastHorizon fh{a, 0, std::min(cpt, nsub) - 1}; be_.launch(fh.threads(), fh); }
+            // (one subtile more than the tile: the first step also evaluates the two positions behind it for the lazy rules)
+            be_.launch_waves(256, FastPrefix{a, 0, 0, std::min(cpt + 1, nsub), cpt, 0}, 0);
+            { const FastHorizon fh{a, 0, std::min(cpt + 1, nsub) - 1}; be_.launch(fh.threads(), fh); }
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
@@ -771,7 +782,8 @@ class StreamEncoder {
                 // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them.  (As a
                 // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
                 // hardware queues the runtime gave the two streams: one chain it is.)
-                const uint32_t ext = std::min(cpt, nsub - std::min(nsub, c0 + nc));
+                // (... and one subtile more: the next step also evaluates the two positions behind its newest tile)
+                const uint32_t ext = std::min(cpt + 1, nsub - std::min(nsub, c0 + nc));
                 be_.launch_waves(256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0}, 0);
                 { const FastHorizon fh{a, c0, c0 + nc + ext - 1}; be_.launch(fh.threads(), fh); }
                 // the tile that has just had its last round is final: its item starts join the compact lists (while a later

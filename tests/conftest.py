@@ -68,7 +68,20 @@ def emu():
         lib.emu_free(dst)
         return out, list(st)
 
+    def encode_fast_reused(first, data, cfg=(15, 9, 6)):
+        """`data` through an encoder that encoded `first` before: the second stream"""
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        first, data = bytes(first), bytes(data)
+        rc = lib.emu_encode_fast_reused(first, ctypes.c_size_t(len(first)), data, ctypes.c_size_t(len(data)), cfg[0], cfg[1], cfg[2],
+                                        ctypes.byref(dst), ctypes.byref(n))
+        assert rc == 0
+        out = ctypes.string_at(dst, n.value)
+        lib.emu_free(dst)
+        return out
+
     encode.fast = encode_fast
+    encode.fast_reused = encode_fast_reused
     return encode
 
 

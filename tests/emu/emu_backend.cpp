@@ -28,6 +28,7 @@ struct EmuBackend {
     }
     void free(void* p) { std::free(p); }
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
+    void poison(void* p, size_t n) { std::memset(p, 0xA5, n); }
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void h2d_pinned(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
@@ -190,6 +191,26 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
+        return -1;
+    }
+}
+// two inputs through ONE encoder, the second stream returned: a reused encoder must write what a fresh one writes
+extern "C" int emu_encode_fast_reused(const uint8_t* first, size_t n_first, const uint8_t* src, size_t n, int depth, int lazy1, int lazy2,
+                                      uint8_t** dst, size_t* dst_len) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        std::vector<uint8_t> out;
+        orz::encode_stream(enc, be, first, n_first, false, out);
+        out.clear();
+        orz::encode_stream(enc, be, src, n, false, out);
+        *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_encode_fast_reused: %s\n", e.what());
         return -1;
     }
 }

@@ -133,3 +133,20 @@ def test_deep_runs_take_older_candidates_from_the_compact_lists(emu, oracle):
 
     _roundtrip(emu, oracle, _data.zeros_noise(300_000), 1, band=0.03)
     _roundtrip(emu, oracle, corpus.enwik_like(700_000), 1, band=0.005)
+
+
+def test_a_reused_encoder_writes_what_a_fresh_one_writes(emu, oracle):
+    """members are handed to whichever worker is free, so the bytes of a member must not depend on what its encoder
+    encoded before.  The emulation fills the round state that no parse resets (ring horizons, dirty flags, remembered
+    scan answers, evaluations) with garbage at every stream start: reading any of it before it is written shows here.
+    (Round 3 found the ring horizons of the two positions a step evaluates beyond its newest tile left over from the
+    stream before: valid streams, but a 64 MiB member came out 364 bytes different on a reused encoder.)"""
+    import corpus
+
+    text = corpus.enwik_like(6_000_000)
+    for data in (text[3_000_000:], _data.mixed(700_000, seed=5), _data.zeros_noise(600_000)):
+        fresh, _ = emu.fast(data, cfg=LEVELS[1])
+        for first in (text[:2_500_000], _data.zeros_noise(500_000), b"abc"):
+            again = emu.fast_reused(first, data, cfg=LEVELS[1])
+            assert again == fresh
+        assert oracle.decode(fresh)[0] == bytes(data)
