@@ -210,20 +210,24 @@ __device__ __forceinline__ uint32_t orz_sub_sat(uint32_t a, uint32_t b) {  // ma
     asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(r) : "s"(a), "s"(b) : "scc");
     return r;
 }
+// `state_in` / `only_if`: the guarded second run of a block (HipBackend::symrank) -- it starts from the saved tables and
+// does nothing unless the check of the first run's ranks raised *only_if.
 __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank,
-                                                         const uint32_t* rstart) {
+                                                         const uint32_t* rstart, const uint16_t* state_in, const uint32_t* only_if) {
     __shared__ uint16_t val[kSyms + 3];
     __shared__ uint16_t idx[kSyms + 3];
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (only_if && *only_if == 0) return;
     const uint32_t a = rstart[c], e = rstart[c + 1];
     if (a >= e) return;
     __builtin_amdgcn_s_setprio(3);  // one serial chain per wave: issue ahead of the parse kernels' waves sharing the SIMD
     uint16_t* state = srstate + (size_t)c * kSrWords;
-    for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = state[i]; idx[i] = state[kSyms + i]; }
+    const uint16_t* sin = state_in ? state_in + (size_t)c * kSrWords : state;
+    for (uint32_t i = lane; i < kSyms; i += 64) { val[i] = sin[i]; idx[i] = sin[kSyms + i]; }
     __syncthreads();
     int v0 = val[lane], v1 = val[64 + lane], v2 = val[128 + lane];  // ranks 0..63, 64..127 and 128..191 live in three registers
-    uint32_t cnt = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms] | ((uint32_t)state[2 * kSyms + 1] << 16)));
-    uint32_t sum = __builtin_amdgcn_readfirstlane((int)(state[2 * kSyms + 2] | ((uint32_t)state[2 * kSyms + 3] << 16)));
+    uint32_t cnt = __builtin_amdgcn_readfirstlane((int)(sin[2 * kSyms] | ((uint32_t)sin[2 * kSyms + 1] << 16)));
+    uint32_t sum = __builtin_amdgcn_readfirstlane((int)(sin[2 * kSyms + 2] | ((uint32_t)sin[2 * kSyms + 3] << 16)));
     // reciprocals of the steady-state counts 327 + lane: floor(n / d) == mulhi(n, floor(2^32 / d) + 1) for n < 2^17
     const int mreg = (int)(0xffffffffu / (327 + lane) + 1);
     // value of rank r / store x at rank r, wherever that rank lives
@@ -526,13 +530,13 @@ class HipBackend {
    public:
     explicit HipBackend(int device) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
-        // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream: 512 waves that must
-        // never wait for the parse kernels of the next block to finish dispatching (a 340,000-workgroup grid keeps its
-        // dispatch pipe for milliseconds), so it gets the highest priority the device offers.
+        // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream.  Giving it the
+        // device's highest priority (ORZ_RANK_PRIO=1) measured nothing (296.1 vs 296.2 MB/s) and is off: eight encoders
+        // then hold eight high-priority queues beside twenty-four others, one variable less around the guarded kernel.
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         const char* rp = getenv("ORZ_RANK_PRIO");
-        const bool rank_prio = !(rp && atoi(rp) == 0);
+        const bool rank_prio = rp && atoi(rp) != 0;
         for (int i = 0; i < kStreams; i++) {
             if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio_high));
             else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
@@ -789,11 +793,29 @@ class HipBackend {
     void set_profile(bool on) { profile_ = on; }
     bool profile() const { return profile_; }
 
-    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
+    // Symbol ranking of one block, guarded.  The ranks of the hand-scheduled kernel are checked against the one property
+    // that needs no table -- rank 388 exactly where the symbol is the excluded one (SymCheck) -- and when the check fails
+    // the block is ranked again from the tables saved before the first run; what the second run left is checked again into
+    // flags[1], which the host reads with the block's output (a set flags[1] fails the encode: no stream is better than a
+    // wrong one).  Twice in this round a finished stream carried one such rank (a WORD item coded as "the excluded
+    // symbol") -- out of ~10^10 ranked items, never reproduced, cause not found.
+    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags,
+                 uint16_t* backup) {
+        ORZ_HIP_CHECK(hipMemcpyAsync(backup, srstate, (size_t)512 * kSrWords * 2, hipMemcpyDeviceToDevice, stream_));
+        ORZ_HIP_CHECK(hipMemsetAsync(flags, 0, 8, stream_));
         timed_begin(1);
-        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart);
+        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)nullptr,
+                           (const uint32_t*)nullptr);
         ORZ_HIP_CHECK(hipGetLastError());
         timed_end(1);
+        const char* inj = getenv("ORZ_SYMRANK_INJECT");  // (tests: a wrong rank at item k of every block)
+        const long inject = inj ? atol(inj) : -1;
+        if (inject >= 0 && (uint32_t)inject < nitems) launch(1, SymInject{gsym, grank, (uint32_t)inject});
+        launch(nitems, SymCheck{gsym, grank, nitems, flags, nullptr});
+        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)backup,
+                           (const uint32_t*)flags);
+        ORZ_HIP_CHECK(hipGetLastError());
+        launch(nitems, SymCheck{gsym, grank, nitems, flags + 1, flags});
     }
 
    private:

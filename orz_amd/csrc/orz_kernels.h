@@ -147,6 +147,29 @@ struct CensusCount {
 };
 // symrank table state: per context {value[389], index[389], cnt, sum}
 constexpr uint32_t kSrWords = kSyms * 2 + 4;
+// The one property of a block's ranks that can be checked without the tables (src/symrank.rs:38-47): rank 388 is written
+// exactly where the symbol IS the excluded one, and no rank exceeds it.  gsym = symbol | excluded symbol << 16, in the
+// order the ranks were produced in.
+struct SymCheck {
+    const uint32_t* gsym;
+    const uint16_t* grank;
+    uint32_t nitems;
+    uint32_t* flag;           // += violations
+    const uint32_t* only_if;  // (second check: nothing to do unless the first one found something)
+    ORZ_HD void operator()(size_t k) const {
+        if (k >= nitems || (only_if && *only_if == 0)) return;
+        const uint32_t g = gsym[k], r = grank[k];
+        if (r > kSyms - 1 || ((r == kSyms - 1) != ((g & 0xffff) == (g >> 16)))) ORZ_ATOMIC_ADD(flag, 1u);
+    }
+};
+struct SymInject {  // (tests) the failure the guard exists for: item k's rank reads "excluded symbol" although it is not
+    const uint32_t* gsym;
+    uint16_t* grank;
+    uint32_t k;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid == 0 && (gsym[k] & 0xffff) != (gsym[k] >> 16)) grank[k] = (uint16_t)(kSyms - 1);
+    }
+};
 // Stable order by descending max(count, 1) (src/lz.rs:247-250): thread per symbol, its place is the
 // number of symbols that sort before it.
 struct CensusOrder {

@@ -37,6 +37,7 @@ struct ItemTrace {
 
 struct EncodeStats {
     uint64_t blocks = 0, sweeps = 0, seg_evals = 0, items = 0, chunks = 0, in_bytes = 0, out_bytes = 0;
+    uint64_t rank_redos = 0;  // blocks whose symbol ranking was repeated by the guard (backend symrank)
     double t_prep = 0, t_parse = 0, t_post = 0;  // seconds (host clock around device syncs)
 };
 
@@ -394,12 +395,14 @@ class StreamEncoder {
                 t.hscr = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
                 t.hdrbits = take<uint32_t>(kMaxChunks);
                 t.tot = take<uint32_t>(kMaxChunks);
+                t.srflags = take<uint32_t>(2);
                 t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords, false);
             }
             counts_ = take<uint32_t>(kSyms + 3);
             order_ = take<uint16_t>(kSyms + 3);
             ncounted_ = take<uint32_t>(4);
             srstate_ = take<uint16_t>((size_t)512 * kSrWords);
+            srbackup_ = take<uint16_t>((size_t)512 * kSrWords);
             outoff_ = take<uint64_t>(kMaxChunks);
             {
                 std::vector<uint64_t> off(kMaxChunks);
@@ -924,7 +927,7 @@ class StreamEncoder {
         MainStreamGuard back_to_main{be_};
         be_.select(1);
         be_.wait(kEvItems + b);
-        be_.symrank(srstate_, t.gsym, t.grank, t.rstart);
+        be_.symrank(srstate_, t.gsym, t.grank, t.rstart, nitems, t.srflags, srbackup_);
         be_.record(kEvRank + b);
         // ---- static Huffman per chunk and bit packing on stream 2
         be_.select(2);
@@ -976,6 +979,15 @@ class StreamEncoder {
         else { be_.select(3); be_.wait(kEvTail + set); }
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
+        {   // the guard of the block's symbol ranking (backend symrank): repeated? still impossible ranks?
+            uint32_t f[2] = {0, 0};
+            be_.d2h(f, t.srflags, 8);
+            if (f[0]) {
+                stats.rank_redos++;
+                fprintf(stderr, "orz: the symbol ranking of block %u was repeated (%u impossible ranks in its first run; %u after the second)\n", t.block, f[0], f[1]);
+            }
+            if (f[1]) throw std::runtime_error("symbol ranking produced impossible ranks twice: no stream written");
+        }
         for (uint32_t i = 0; i < nchunks; i++) {
             size_t tb = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
             if (tb / 4 > kChunkCapWords) throw std::runtime_error("chunk payload overflow");
@@ -1129,7 +1141,7 @@ class StreamEncoder {
         uint32_t* hw = nullptr;
         uint8_t* hl = nullptr;
         uint16_t* hc = nullptr;
-        uint32_t *hscr = nullptr, *hdrbits = nullptr, *tot = nullptr, *out = nullptr;
+        uint32_t *hscr = nullptr, *hdrbits = nullptr, *tot = nullptr, *out = nullptr, *srflags = nullptr;
         bool pending = false;
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
@@ -1168,6 +1180,7 @@ class StreamEncoder {
     uint16_t* order_;
     uint32_t* ncounted_;
     uint16_t* srstate_;
+    uint16_t* srbackup_ = nullptr;  // the tables before the running block's ranking (the guard's second run starts from them)
     uint64_t* outoff_;
 };
 

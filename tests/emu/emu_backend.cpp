@@ -134,11 +134,13 @@ struct EmuBackend {
         uint32_t run = 0;
         for (size_t i = 0; i < n; i++) { if (in[i] > run) run = in[i]; out[i] = run; }
     }
-    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart) {
+    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags, uint16_t*) {
+        flags[0] = flags[1] = 0;  // (the reference loop below needs no second run; the check runs all the same)
         for (uint32_t c = 0; c < 512; c++) {
             uint16_t value[orz::kSyms], index[orz::kSyms];
             orz::symrank_run(value, index, srstate + (size_t)c * orz::kSrWords, gsym, grank, rstart[c], rstart[c + 1]);
         }
+        launch(nitems, orz::SymCheck{gsym, grank, nitems, flags + 1, nullptr});
     }
 };
 }  // namespace

@@ -305,3 +305,28 @@ def test_graph_replay_changes_nothing(oracle, monkeypatch):
             enc.close()
     assert outs[0] == outs[1]
     assert oracle.decode(outs[0])[0] == data
+
+
+def test_symbol_ranking_guard_repeats_a_block_with_an_impossible_rank(oracle, monkeypatch, capfd):
+    """the guard around the hand-scheduled symbol-ranking kernel (HipBackend::symrank): a rank that reads "the excluded
+    symbol" where the symbol is another one -- injected after the first run -- is found by the check, the block is ranked
+    again from the saved tables, and the stream is the very stream of an undisturbed encode"""
+    import corpus
+    import orz_amd
+
+    data = corpus.enwik_like(20_000_000)  # (two blocks: the second run must also leave the right tables behind)
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        clean = enc.encode(data)
+    finally:
+        enc.close()
+    monkeypatch.setenv("ORZ_SYMRANK_INJECT", "123457")
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        out = enc.encode(data)
+    finally:
+        enc.close()
+    monkeypatch.delenv("ORZ_SYMRANK_INJECT")
+    assert "was repeated" in capfd.readouterr().err
+    assert out == clean
+    assert oracle.decode(out)[0] == data

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 4; rep++) {
         hipMemcpy(ds, state.data(), state.size() * 2, hipMemcpyHostToDevice);
         hipEventRecord(a);
-        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, 0, ds, dg, dk, dr);
+        hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, 0, ds, dg, dk, dr, (const uint16_t*)nullptr, (const uint32_t*)nullptr);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
     }
