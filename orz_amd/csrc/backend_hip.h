@@ -528,15 +528,18 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
 
 class HipBackend {
    public:
-    explicit HipBackend(int device) : device_(device) {
+    // `lone`: the encoder has the GPU to itself (a single stream: bench.py, orz_stream_new, bin/orz without --jobs); the
+    // workers of a members job are not lone
+    explicit HipBackend(int device, bool lone = true) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
-        // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream.  Giving it the
-        // device's highest priority (ORZ_RANK_PRIO=1) measured nothing (296.1 vs 296.2 MB/s) and is off: eight encoders
-        // then hold eight high-priority queues beside twenty-four others, one variable less around the guarded kernel.
+        // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream.  A lone encoder
+        // gives it the device's highest priority: without, a ranking launch queues 1...5 ms behind the dispatch of the next
+        // block's parse grids (298 vs 303 MB/s).  The workers of a members job do not: eight high-priority queues beside
+        // twenty-four others cost the job 15 % (557 vs 477 MB/s with eight encoders).  ORZ_RANK_PRIO=0/1 overrides.
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         const char* rp = getenv("ORZ_RANK_PRIO");
-        const bool rank_prio = rp && atoi(rp) != 0;
+        const bool rank_prio = rp ? atoi(rp) != 0 : lone;
         for (int i = 0; i < kStreams; i++) {
             if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio_high));
             else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));

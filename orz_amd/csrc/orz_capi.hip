@@ -140,12 +140,12 @@ int orz_lzcfg_from_level(int level, orz_lzcfg* out) {  // src/main.rs:97-102
 void orz_free(void* p) { std::free(p); }
 
 // ------------------------------------------------------------------------------ orz_stream
-orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
+static orz_stream* stream_new(int device, const orz_lzcfg* cfg, bool lone) {
     if (!cfg_ok(cfg)) { fail(ORZ_EINVAL, "bad LZCfg"); return nullptr; }
     try {
         if (device < 0 || device >= orz_device_count()) { fail(ORZ_ENODEV, "no such HIP device"); return nullptr; }
         std::unique_ptr<orz_stream> s(new orz_stream);
-        s->be.reset(new orz::HipBackend(device));
+        s->be.reset(new orz::HipBackend(device, lone));
         s->cfg = *cfg;
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
         s->win = env_u("ORZ_WIN", 0);
@@ -160,6 +160,7 @@ orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) {
         return nullptr;
     }
 }
+orz_stream* orz_stream_new(int device, const orz_lzcfg* cfg) { return stream_new(device, cfg, true); }
 void orz_stream_free(orz_stream* s) {
     if (!s) return;
     s->enc.reset();
@@ -299,7 +300,7 @@ orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_
     auto drop = [&]() { for (orz_stream* w : m->workers) orz_stream_free(w); m->workers.clear(); };
     for (int d = 0; d < n_devices; d++)
         for (int i = 0; i < jobs_per_device; i++) {
-            orz_stream* s = orz_stream_new(devices[d], cfg);
+            orz_stream* s = stream_new(devices[d], cfg, n_devices * jobs_per_device == 1);
             if (!s) { drop(); return nullptr; }
             if (jobs_per_device > 1 && !s->fast) {  // exact mode: several streams share the GPU: a smaller speculative window each
                 s->win = env_u("ORZ_MEMBER_WIN", std::max(256u, window_for(*s->be, *cfg, 0) / (unsigned)jobs_per_device));
