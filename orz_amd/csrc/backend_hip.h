@@ -814,11 +814,11 @@ class HipBackend {
         const char* inj = getenv("ORZ_SYMRANK_INJECT");  // (tests: a wrong rank at item k of every block)
         const long inject = inj ? atol(inj) : -1;
         if (inject >= 0 && (uint32_t)inject < nitems) launch(1, SymInject{gsym, grank, (uint32_t)inject});
-        launch(nitems, SymCheck{gsym, grank, nitems, flags, nullptr});
+        launch(SymCheck::kThreads, SymCheck{gsym, grank, nitems, flags, nullptr});
         hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)backup,
                            (const uint32_t*)flags);
         ORZ_HIP_CHECK(hipGetLastError());
-        launch(nitems, SymCheck{gsym, grank, nitems, flags + 1, flags});
+        launch(SymCheck::kThreads, SymCheck{gsym, grank, nitems, flags + 1, flags});
     }
 
    private:

@@ -156,10 +156,16 @@ struct SymCheck {
     uint32_t nitems;
     uint32_t* flag;           // += violations
     const uint32_t* only_if;  // (second check: nothing to do unless the first one found something)
-    ORZ_HD void operator()(size_t k) const {
-        if (k >= nitems || (only_if && *only_if == 0)) return;
-        const uint32_t g = gsym[k], r = grank[k];
-        if (r > kSyms - 1 || ((r == kSyms - 1) != ((g & 0xffff) == (g >> 16)))) ORZ_ATOMIC_ADD(flag, 1u);
+    static constexpr uint32_t kThreads = 65536;  // a small grid that strides over the items: these launches sit on the
+                                                 // ranking chain and must not queue behind the parse kernels' dispatch
+    ORZ_HD void operator()(size_t t) const {
+        if (t >= kThreads || (only_if && *only_if == 0)) return;
+        uint32_t bad = 0;
+        for (size_t k = t; k < nitems; k += kThreads) {
+            const uint32_t g = gsym[k], r = grank[k];
+            bad += r > kSyms - 1 || ((r == kSyms - 1) != ((g & 0xffff) == (g >> 16)));
+        }
+        if (bad) ORZ_ATOMIC_ADD(flag, bad);
     }
 };
 struct SymInject {  // (tests) the failure the guard exists for: item k's rank reads "excluded symbol" although it is not

@@ -140,7 +140,7 @@ struct EmuBackend {
             uint16_t value[orz::kSyms], index[orz::kSyms];
             orz::symrank_run(value, index, srstate + (size_t)c * orz::kSrWords, gsym, grank, rstart[c], rstart[c + 1]);
         }
-        launch(nitems, orz::SymCheck{gsym, grank, nitems, flags + 1, nullptr});
+        launch(orz::SymCheck::kThreads, orz::SymCheck{gsym, grank, nitems, flags + 1, nullptr});
     }
 };
 }  // namespace
