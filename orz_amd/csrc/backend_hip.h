@@ -804,8 +804,9 @@ class HipBackend {
     // symbol") -- out of ~10^10 ranked items, never reproduced, cause not found.
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags,
                  uint16_t* backup) {
-        ORZ_HIP_CHECK(hipMemcpyAsync(backup, srstate, (size_t)512 * kSrWords * 2, hipMemcpyDeviceToDevice, stream_));
-        ORZ_HIP_CHECK(hipMemsetAsync(flags, 0, 8, stream_));
+        static_assert((512 * kSrWords * 2) % 8 == 0, "the tables are copied in 8-byte words");
+        const uint32_t nw = 512 * kSrWords * 2 / 8;
+        launch(nw, SymGuardBegin{reinterpret_cast<const uint64_t*>(srstate), reinterpret_cast<uint64_t*>(backup), nw, flags});
         timed_begin(1);
         hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)nullptr,
                            (const uint32_t*)nullptr);

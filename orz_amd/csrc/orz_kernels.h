@@ -168,6 +168,16 @@ struct SymCheck {
         if (bad) ORZ_ATOMIC_ADD(flag, bad);
     }
 };
+struct SymGuardBegin {  // the tables as they are before a block's ranking -> backup; flags cleared (a kernel, not a copy engine)
+    const uint64_t* state;
+    uint64_t* backup;
+    uint32_t nwords;  // 8-byte words
+    uint32_t* flags;
+    ORZ_HD void operator()(size_t t) const {
+        if (t < nwords) backup[t] = state[t];
+        if (t == 0) { flags[0] = 0; flags[1] = 0; }
+    }
+};
 struct SymInject {  // (tests) the failure the guard exists for: item k's rank reads "excluded symbol" although it is not
     const uint32_t* gsym;
     uint16_t* grank;
