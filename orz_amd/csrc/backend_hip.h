@@ -533,9 +533,9 @@ class HipBackend {
     explicit HipBackend(int device, bool lone = true) : device_(device) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
         // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream.  A lone encoder
-        // gives it the device's highest priority: without, a ranking launch queues 1...5 ms behind the dispatch of the next
-        // block's parse grids (298 vs 303 MB/s).  The workers of a members job do not: eight high-priority queues beside
-        // twenty-four others cost the job 15 % (557 vs 477 MB/s with eight encoders).  ORZ_RANK_PRIO=0/1 overrides.
+        // gives it the device's highest priority so that a ranking launch does not queue behind the dispatch of the next
+        // block's parse grids; the workers of a members job leave it at the default.  Neither choice moved a measurement
+        // beyond the run-to-run spread (bench 298...303 MB/s, eight encoders 454...557).  ORZ_RANK_PRIO=0/1 overrides.
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         const char* rp = getenv("ORZ_RANK_PRIO");
