@@ -183,6 +183,15 @@ typedef struct {
 int orz_decode_members_device(int device, const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len,
                               size_t* n_members_out, orz_decode_stats* stats);
 
+/* The Huffman tables of `nchunks` chunks on the device, in the layout the encoder keeps them: a chunk is
+ * orz_huffman_stride() = 389 + 389 + 240 entries (symbol ranks after a match / after a literal, long match lengths:
+ * /root/reference/src/lz.rs:272-273,298-305), each of the three built as HuffmanTable::new_from_sym_weights(weights, 15)
+ * (src/huffman.rs:27-111) followed by HuffmanEncoding::from_huffman_table (src/huffman.rs:118-141).  `lens` and `codes`
+ * receive nchunks * stride entries.  Weights must be below 2^23 (a chunk holds at most 2^20 items, src/lib.rs:32);
+ * ORZ_EINVAL otherwise.  `elapsed_us`, when not NULL, receives the HIP-event time of the one kernel launch. */
+size_t orz_huffman_stride(void);
+int orz_huffman_tables(int device, const uint32_t* weights, size_t nchunks, uint8_t* lens, uint16_t* codes, double* elapsed_us);
+
 int orz_device_count(void);
 const char* orz_last_error(void);
 const char* orz_version(void);

@@ -148,6 +148,12 @@ SYMBOLS = [
     ),
     ("orz_stream_set_item_trace", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("orz_stream_get_item_trace", ctypes.c_long, [ctypes.c_void_p, ctypes.POINTER(Item), ctypes.c_size_t]),
+    ("orz_huffman_stride", ctypes.c_size_t, []),
+    (
+        "orz_huffman_tables",
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)],
+    ),
     ("orz_device_count", ctypes.c_int, []),
     ("orz_last_error", ctypes.c_char_p, []),
     ("orz_version", ctypes.c_char_p, []),

@@ -291,6 +291,26 @@ def decode_members_device(container, device=0, stats=False):
     return (out, nm.value, st.as_dict()) if stats else (out, nm.value)
 
 
+def huffman_tables(weights, device=0):
+    """Huffman code lengths and canonical codes of every table of `weights` ON THE GPU -- an array of shape
+    [nchunks, orz_huffman_stride()] of symbol weights below 2^23 in the encoder's layout (389 + 389 + 240 symbols a chunk;
+    HuffmanTable::new_from_sym_weights + HuffmanEncoding::from_huffman_table, src/huffman.rs:27-141)
+    -> (lens uint8 array, codes uint16 array, microseconds of the kernel launch)."""
+    import numpy as np
+
+    lib = _native.load()
+    w = np.ascontiguousarray(weights, dtype=np.uint32)
+    stride = lib.orz_huffman_stride()
+    if w.ndim != 2 or w.shape[1] != stride:
+        raise ValueError("weights must have shape [nchunks, %d]" % stride)
+    lens = np.zeros(w.shape, dtype=np.uint8)
+    codes = np.zeros(w.shape, dtype=np.uint16)
+    us = ctypes.c_double()
+    rc = lib.orz_huffman_tables(device, w.ctypes.data, w.shape[0], lens.ctypes.data, codes.ctypes.data, ctypes.byref(us))
+    _check(rc, "orz_huffman_tables")
+    return lens, codes, us.value
+
+
 def decode_bytes(stream):
     """orz stream -> (bytes, consumed).  Host decoder of the library (orz::decode, src/lib.rs:94-129);
     stops after the first stream's EOF chunk like the reference."""

@@ -86,108 +86,6 @@ __global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchu
         rebuild_summaries(a.kbits, a.k1, a.k2, a.nkwords, blockIdx.x - nchunks - nvblk, threadIdx.x, (uint64_t*)rows, sync);
 }
 
-// Huffman code lengths + canonical codes (src/huffman.rs:27-141): one wavefront per (chunk, table), everything in LDS.
-// The reference builds the tree with a min-heap on (weight, index) whose keys are unique, so the pop order is fully
-// determined; the same order comes out of the two-queue construction: leaves sorted by (weight, index) -- every lane
-// ranks its symbols by counting -- merged with the queue of internal nodes, whose weights never decrease and whose
-// indices (>= the symbol count) grow with creation.  A leaf wins a weight tie against an internal node (smaller index).
-// The merge and the depth pass are serial (lane 0, <= 388 steps each on LDS); ranking, length statistics and the
-// canonical code assignment (src/huffman.rs:118-141: first code of a length + rank among the symbols of that length)
-// are spread over the 64 lanes.
-__global__ __launch_bounds__(64) void orz_huff_kernel(HuffBuild f) {
-    __shared__ uint32_t w[kSyms], w0[kSyms], nodew[2 * kSyms];
-    __shared__ uint16_t order[kSyms], c1[2 * kSyms], c2[2 * kSyms], cl[2 * kSyms];
-    __shared__ uint32_t cntL[17], firstL[17], sh_m, sh_max;
-    const uint32_t tid = blockIdx.x, ch = tid / 3, t = tid % 3, lane = threadIdx.x;
-    const uint32_t n = HuffBuild::table_syms(t), off = HuffBuild::table_off(t);
-    const uint32_t* src = f.hw + (size_t)ch * kHwStride + off;
-    uint8_t* lens = f.hl + (size_t)ch * kHwStride + off;
-    uint16_t* codes = f.hc + (size_t)ch * kHwStride + off;
-    for (uint32_t i = lane; i < n; i += 64) { w0[i] = src[i]; w[i] = src[i]; }
-    __syncthreads();
-    for (;;) {
-        // rank of every used symbol among the used symbols by (current weight, index)
-        if (lane == 0) sh_m = 0;
-        __syncthreads();
-        uint32_t mine = 0;
-        for (uint32_t s = lane; s < n; s += 64) {
-            if (!w0[s]) continue;  // filter on the ORIGINAL weights (src/huffman.rs:58)
-            const uint32_t ws = w[s];
-            uint32_t r = 0;
-            for (uint32_t u = 0; u < n; u++) r += (w0[u] != 0) & ((w[u] < ws) | ((w[u] == ws) & (u < s)));
-            order[r] = (uint16_t)s;
-            mine++;
-        }
-        atomicAdd(&sh_m, mine);
-        __syncthreads();
-        const uint32_t m = sh_m;
-        if (m <= 1) {
-            for (uint32_t i = lane; i < n; i += 64) { lens[i] = (m == 1 && w0[i]) ? 1 : 0; codes[i] = 0; }
-            return;
-        }
-        if (lane == 0) {
-            uint32_t qa = 0, qb = n, nodes = n;
-            for (uint32_t step = 0; step + 1 < m; step++) {
-                uint32_t pick[2];
-                for (int k = 0; k < 2; k++) {
-                    const bool has_leaf = qa < m, has_node = qb < nodes;
-                    bool take_leaf = has_leaf;
-                    if (has_leaf && has_node) take_leaf = w[order[qa]] <= nodew[qb];  // equal weights: the leaf's index is smaller
-                    pick[k] = take_leaf ? order[qa++] : qb++;
-                }
-                const uint32_t wa = pick[0] < n ? w[pick[0]] : nodew[pick[0]], wb = pick[1] < n ? w[pick[1]] : nodew[pick[1]];
-                nodew[nodes] = wa + wb;
-                c1[nodes] = (uint16_t)pick[0];
-                c2[nodes] = (uint16_t)pick[1];
-                nodes++;
-            }
-            cl[nodes - 1] = 0;
-            for (uint32_t i = nodes; i-- > n;) {
-                cl[c1[i]] = cl[i] + 1;
-                cl[c2[i]] = cl[i] + 1;
-            }
-            uint32_t mx = 0;
-            for (uint32_t k = 0; k < m; k++) mx = cl[order[k]] > mx ? cl[order[k]] : mx;
-            sh_max = mx;
-        }
-        __syncthreads();
-        const uint32_t cur_max = sh_max;
-        if (cur_max > 15) {  // src/huffman.rs:99-108: cumulative shrink of the leaf weights, then again
-            const uint32_t shrink = 1u << (cur_max - 15);
-            for (uint32_t i = lane; i < n; i += 64)
-                if (w[i] > 0) { const uint32_t v = w[i] / shrink; w[i] = v > 1 ? v : 1; }
-            __syncthreads();
-            continue;
-        }
-        break;
-    }
-    // lengths + canonical codes in (len, sym) order
-    if (lane < 17) cntL[lane] = 0;
-    __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t L = w0[i] ? cl[i] : 0;
-        lens[i] = (uint8_t)L;
-        if (L) atomicAdd(&cntL[L], 1u);
-    }
-    __syncthreads();
-    if (lane == 0) {
-        uint32_t bits = 0, cur = 1;
-        for (uint32_t L = 1; L <= 15; L++) {
-            if (!cntL[L]) { firstL[L] = 0; continue; }
-            if (L > cur) { bits <<= (L - cur); cur = L; }
-            firstL[L] = bits;
-            bits += cntL[L];
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t L = w0[i] ? cl[i] : 0;
-        uint32_t r = 0;
-        if (L) for (uint32_t u = 0; u < i; u++) r += (w0[u] != 0) & (cl[u] == L);
-        codes[i] = L ? (uint16_t)(firstL[L] + r) : 0;
-    }
-}
-
 // SymRankCoder chains (src/symrank.rs:38-97): one wavefront per context.  The chain is serial by definition and a
 // lone wavefront issues one instruction every four cycles, so what counts is the number of instructions per item.
 // The 64 best-ranked symbols live in ONE vector register (lane r holds value[r]): "which rank has symbol v" is a
@@ -677,9 +575,7 @@ class HipBackend {
         ORZ_HIP_CHECK(hipGetLastError());
     }
     void huffbuild(const HuffBuild& f) {
-        if (!f.nchunks) return;
-        hipLaunchKernelGGL(orz_huff_kernel, dim3(f.nchunks * 3), dim3(64), 0, stream_, f);
-        ORZ_HIP_CHECK(hipGetLastError());
+        if (f.nchunks) launch_waves((size_t)f.nchunks * 3, HuffWave{f}, HuffWave::lds_bytes());
     }
     void rank(const RankArgs& a, uint32_t nchunks) {
         const uint32_t nvblk = (a.nvwords + 4095) / 4096, nkblk = (a.nkwords + 4095) / 4096;

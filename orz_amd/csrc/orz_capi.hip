@@ -421,6 +421,47 @@ int orz_decode_members_device(int device, const uint8_t* src, size_t n, uint8_t*
     }
 }
 
+// ------------------------------------------------------------------------------ Huffman tables alone
+size_t orz_huffman_stride(void) { return orz::kHwStride; }
+int orz_huffman_tables(int device, const uint32_t* weights, size_t nchunks, uint8_t* lens, uint16_t* codes, double* elapsed_us) {
+    if (!weights || !lens || !codes || nchunks > (1u << 20)) return fail(ORZ_EINVAL, "bad argument");
+    if (device < 0 || device >= orz_device_count()) return fail(ORZ_ENODEV, "no such HIP device");
+    const size_t n = nchunks * orz::kHwStride;
+    for (size_t i = 0; i < n; i++)
+        if (weights[i] > orz::HuffBuild::kMaxWeight) return fail(ORZ_EINVAL, "symbol weight of 2^23 or more");
+    if (!n) return ORZ_OK;
+    try {
+        orz::HipBackend be(device);
+        struct Bufs {
+            orz::HipBackend& be;
+            uint32_t* w = nullptr; uint8_t* l = nullptr; uint16_t* c = nullptr;
+            ~Bufs() { be.free(w); be.free(l); be.free(c); }
+        } b{be};
+        b.w = be.alloc<uint32_t>(n, false);
+        b.l = be.alloc<uint8_t>(n);
+        b.c = be.alloc<uint16_t>(n);
+        be.h2d(b.w, weights, n * 4);
+        const orz::HuffBuild f{b.w, (uint32_t)nchunks, b.l, b.c};
+        be.huffbuild(f);  // (warm: code object load)
+        hipEvent_t e0, e1;
+        ORZ_HIP_CHECK(hipEventCreate(&e0));
+        ORZ_HIP_CHECK(hipEventCreate(&e1));
+        ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
+        be.huffbuild(f);
+        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
+        be.d2h(lens, b.l, n);
+        be.d2h(codes, b.c, n * 2);
+        float ms = 0;
+        ORZ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (elapsed_us) *elapsed_us = (double)ms * 1000.0;
+        return ORZ_OK;
+    } catch (const std::exception& e) {
+        return fail(ORZ_EINVAL, e.what());
+    }
+}
+
 // ------------------------------------------------------------------------------ orz_lz_encoder
 orz_lz_encoder* orz_lz_encoder_new(int device) {
     try {

@@ -365,117 +365,237 @@ struct HistWave {
     }
 };
 
-// HuffmanTable::new_from_sym_weights (src/huffman.rs:27-111) + canonical codes (:118-141).
-// One thread per (chunk, table).  The heap is a binary min-heap on (weight, index): keys are
-// unique, so the pop order -- hence the tree -- is fully determined.
+// HuffmanTable::new_from_sym_weights (src/huffman.rs:27-111) + canonical codes (:118-141): the argument block and the
+// wave kernel that builds the tables, one wavefront per (chunk, table).
 struct HuffBuild {
-    const uint32_t* hw;  // [nchunks][kHwStride]
+    const uint32_t* hw;  // [nchunks][kHwStride] symbol weights (< 2^23 each: a chunk has at most 2^20 items)
     uint32_t nchunks;
     uint8_t* hl;         // [nchunks][kHwStride] code lengths
     uint16_t* hc;        // [nchunks][kHwStride] codes
-    uint32_t* scratch;   // [nchunks*3][kHuffScratch] u32
-    static constexpr uint32_t kHuffScratch = 4 * 2 * kSyms + kSyms;
-
-    ORZ_HD static bool less(uint32_t wa, uint32_t ia, uint32_t wb, uint32_t ib) {
-        return wa < wb || (wa == wb && ia < ib);
-    }
+    static constexpr uint32_t kMaxWeight = (1u << 23) - 1;
     ORZ_HD static uint32_t table_off(uint32_t t) { return t == 0 ? 0 : (t == 1 ? kSyms : 2 * kSyms); }
     ORZ_HD static uint32_t table_syms(uint32_t t) { return t == 2 ? kLenSyms : kSyms; }
-    ORZ_HD void operator()(size_t tid) const {  // scratch in global memory (host emulation; any backend)
-        if (tid >= (size_t)nchunks * 3) return;
-        const uint32_t ch = (uint32_t)(tid / 3), t = (uint32_t)(tid % 3);
-        build(tid, hw + (size_t)ch * kHwStride + table_off(t), scratch + tid * kHuffScratch);
+};
+
+// The reference builds the tree with a min-heap on (weight, index).  Its keys are unique, so the pop order -- hence the
+// tree -- is fully determined, and the two-queue construction pops in the same order: the used symbols sorted by
+// (weight, index), merged with the queue of internal nodes, whose weights never decrease and whose indices (above every
+// symbol's) grow with creation; a leaf wins a weight tie against an internal node (smaller index).
+//   sort        every lane ranks its <= 7 symbols by counting smaller keys (weight << 9 | symbol) over the table in LDS
+//   merge       serial by definition, <= 388 steps on wave-uniform values: both queues are spread over the lanes of a few
+//               registers and a queue head is fetched with v_readlane; leaves are named by their place in the sorted order
+//   depths      pointer jumping over the parent links: <= 9 rounds of 13 elements a lane instead of a serial walk
+//   length cap  src/huffman.rs:99-108: deeper than 15 -> the leaf weights shrink (cumulatively) and the tree is built again
+//   codes       src/huffman.rs:118-141: first code of a length + the symbol's place among the symbols of that length,
+//               counted with one ballot per (block of 64 symbols, length)
+struct HuffWave {
+    HuffBuild f;
+    static constexpr uint32_t kSlots = (kSyms + 63) / 64;          // symbols per lane
+    static constexpr uint32_t kElems = (2 * kSyms - 1 + 63) / 64;  // tree nodes per lane
+    struct Lds {
+        uint32_t key[kSyms];    // weight << 9 | symbol of the used symbols, ~0 for the others
+        uint32_t sw[kSyms];     // leaf weights in sorted order
+        uint16_t par[2 * kSyms], dep[2 * kSyms];  // leaves 0..m-1 by sorted place, internal nodes m..2m-2
+        uint32_t first[16];
+    };
+    static size_t lds_bytes() { return sizeof(Lds); }
+    ORZ_HD static uint32_t popc64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__popcll(v);
+#else
+        return (uint32_t)__builtin_popcountll(v);
+#endif
     }
-    // table `tid` = (chunk, table) from the weights at w0, with kHuffScratch words of scratch at sc: the HIP
-    // backend runs this with both in LDS (the heap is ~35 K dependent accesses: 16 ms from HBM, < 1 ms from LDS)
-    ORZ_HD void build(size_t tid, const uint32_t* w0, uint32_t* sc) const {
-        uint32_t ch = (uint32_t)(tid / 3), t = (uint32_t)(tid % 3);
-        uint32_t off = table_off(t);
-        uint32_t n = table_syms(t);
-        uint8_t* lens = hl + (size_t)ch * kHwStride + off;
-        uint16_t* codes = hc + (size_t)ch * kHwStride + off;
-        uint32_t* w = sc;                  // [2n] node weights
-        uint32_t* c1 = sc + 2 * kSyms;     // [2n]
-        uint32_t* c2 = sc + 4 * kSyms;     // [2n]
-        uint32_t* cl = sc + 6 * kSyms;     // [2n] depths
-        uint32_t* heap = sc + 8 * kSyms;   // [n] node ids
-        for (uint32_t i = 0; i < n; i++) w[i] = w0[i];
-        for (;;) {
-            uint32_t hn = 0, nodes = n;
-            for (uint32_t i = 0; i < n; i++)
-                if (w0[i] > 0) {  // filter on the ORIGINAL weights (src/huffman.rs:58)
-                    uint32_t k = hn++;
-                    heap[k] = i;
-                    while (k > 0) {
-                        uint32_t pa = (k - 1) / 2;
-                        if (!less(w[heap[k]], heap[k], w[heap[pa]], heap[pa])) break;
-                        uint32_t tmp = heap[k]; heap[k] = heap[pa]; heap[pa] = tmp;
-                        k = pa;
-                    }
-                }
-            if (hn <= 1) {
-                for (uint32_t i = 0; i < n; i++) { lens[i] = 0; codes[i] = 0; }
-                if (hn == 1) lens[heap[0]] = 1;
-                return;
-            }
-            while (hn > 1) {
-                uint32_t pick[2];
-                for (int r = 0; r < 2; r++) {
-                    pick[r] = heap[0];
-                    heap[0] = heap[--hn];
-                    uint32_t k = 0;
-                    for (;;) {
-                        uint32_t l = 2 * k + 1, rr = l + 1, m = k;
-                        if (l < hn && less(w[heap[l]], heap[l], w[heap[m]], heap[m])) m = l;
-                        if (rr < hn && less(w[heap[rr]], heap[rr], w[heap[m]], heap[m])) m = rr;
-                        if (m == k) break;
-                        uint32_t tmp = heap[k]; heap[k] = heap[m]; heap[m] = tmp;
-                        k = m;
-                    }
-                }
-                w[nodes] = w[pick[0]] + w[pick[1]];
-                c1[nodes] = pick[0];
-                c2[nodes] = pick[1];
-                uint32_t k = hn++;
-                heap[k] = nodes;
-                nodes++;
-                while (k > 0) {
-                    uint32_t pa = (k - 1) / 2;
-                    if (!less(w[heap[k]], heap[k], w[heap[pa]], heap[pa])) break;
-                    uint32_t tmp = heap[k]; heap[k] = heap[pa]; heap[pa] = tmp;
-                    k = pa;
-                }
-            }
-            for (uint32_t i = 0; i < nodes; i++) cl[i] = 0;
-            for (uint32_t i = nodes; i-- > n;) {
-                cl[c1[i]] = cl[i] + 1;
-                cl[c2[i]] = cl[i] + 1;
-            }
-            uint32_t cur_max = 0;
-            for (uint32_t i = 0; i < n; i++)
-                if (cl[i] > cur_max) cur_max = cl[i];
-            if (cur_max > 15) {  // src/huffman.rs:99-108: cumulative shrink of leaf weights
-                uint32_t shrink = 1u << (cur_max - 15);
-                for (uint32_t i = 0; i < n; i++)
-                    if (w[i] > 0) {
-                        uint32_t v = w[i] / shrink;
-                        w[i] = v > 1 ? v : 1;
-                    }
-                continue;
-            }
-            for (uint32_t i = 0; i < n; i++) lens[i] = (uint8_t)cl[i];
-            break;
+    // slot i (wave-uniform) of a register array without indexing it dynamically
+    ORZ_HD static uint32_t slot_get(const uint32_t (&a)[kSlots], uint32_t i) {
+        uint32_t v = a[0];
+#pragma unroll
+        for (uint32_t k = 1; k < kSlots; k++) v = i == k ? a[k] : v;
+        return v;
+    }
+    ORZ_HD static void slot_set(uint32_t (&a)[kSlots], uint32_t i, uint32_t v) {
+#pragma unroll
+        for (uint32_t k = 0; k < kSlots; k++) a[k] = i == k ? v : a[k];
+    }
+    template <class W>
+    ORZ_D void operator()(W& wv) const {
+        Lds& L = *reinterpret_cast<Lds*>(wv.lds());
+        const uint32_t tid = wv.block(), ch = tid / 3, t = tid % 3, lane = wv.lane();
+        const uint32_t n = HuffBuild::table_syms(t), off = HuffBuild::table_off(t);
+        const uint32_t* src = f.hw + (size_t)ch * kHwStride + off;
+        uint8_t* lens = f.hl + (size_t)ch * kHwStride + off;
+        uint16_t* codes = f.hc + (size_t)ch * kHwStride + off;
+        uint32_t w0[kSlots], wc[kSlots];  // original / current weight of symbol lane + 64 k
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kSlots; k++) {
+            const uint32_t s = lane + 64 * k;
+            w0[k] = s < n ? src[s] : 0;
+            wc[k] = w0[k];
+            m += popc64(wv.ballot(w0[k] != 0));  // the ORIGINAL weights decide who takes part (src/huffman.rs:58)
         }
-        // canonical codes in (len, sym) order (src/huffman.rs:118-141)
-        uint32_t bits = 0, cur = 1;
-        for (uint32_t i = 0; i < n; i++) codes[i] = 0;
-        for (uint32_t L = 1; L <= 15; L++)
-            for (uint32_t sy = 0; sy < n; sy++) {
-                if (lens[sy] != L) continue;
-                if (L > cur) { bits <<= (L - cur); cur = L; }
-                codes[sy] = (uint16_t)bits;
-                bits++;
+        if (m <= 1) {
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++) {
+                const uint32_t s = lane + 64 * k;
+                if (s < n) { lens[s] = (m == 1 && w0[k]) ? 1 : 0; codes[s] = 0; }
             }
+            return;
+        }
+        const uint32_t nelem = 2 * m - 1, root = nelem - 1;
+        uint32_t r[kSlots], len[kSlots];
+        for (;;) {
+            uint32_t mykey[kSlots];
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++) {
+                const uint32_t s = lane + 64 * k;
+                mykey[k] = w0[k] ? (wc[k] << 9) | s : 0xffffffffu;
+                if (s < n) L.key[s] = mykey[k];
+                r[k] = 0;
+            }
+            wv.sync();
+            for (uint32_t u = 0; u < n; u++) {
+                const uint32_t ku = L.key[u];
+#pragma unroll
+                for (uint32_t k = 0; k < kSlots; k++) r[k] += ku < mykey[k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++)
+                if (w0[k]) L.sw[r[k]] = wc[k];
+            wv.sync();
+            // The merge.  Both queues live in registers across the wave -- place q of the sorted leaves (and internal node q in
+            // creation order) in lane q & 63 of slot q >> 6 -- so a queue head is one v_readlane away instead of an LDS round
+            // trip, and the loop runs on uniform values; only the parent links go to LDS.
+            const uint32_t kInf = 0xffffffffu;
+            uint32_t swr[kSlots], nwr[kSlots];
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++) {
+                swr[k] = lane + 64 * k < m ? L.sw[lane + 64 * k] : kInf;
+                nwr[k] = kInf;
+            }
+            {
+                uint32_t qa = 0, qb = 0, made = 0;  // leaves taken, internal nodes taken / made
+                uint32_t lcur = swr[0], rcur = kInf, wcur = kInf;  // slots under the leaf head / the node head / the newest node
+                uint32_t la = wv.bcast(lcur, 0), lb = kInf;
+                for (uint32_t step = 0; step + 1 < m; step++) {
+                    uint32_t wsum = 0;
+                    for (int pick = 0; pick < 2; pick++) {
+                        if (la <= lb) {  // equal weights: the leaf's index is the smaller one
+                            if (lane == 0) L.par[qa] = (uint16_t)(m + made);
+                            wsum += la;
+                            qa++;
+                            if ((qa & 63) == 0) lcur = slot_get(swr, qa >> 6);
+                            la = wv.bcast(lcur, qa & 63);  // (kInf behind the last leaf)
+                        } else {
+                            if (lane == 0) L.par[m + qb] = (uint16_t)(m + made);
+                            wsum += lb;
+                            qb++;
+                            if ((qb & 63) == 0) rcur = slot_get(nwr, qb >> 6);
+                            const uint32_t from = (qb >> 6) == (made >> 6) ? wcur : rcur;
+                            const uint32_t v = wv.bcast(from, qb & 63);
+                            lb = qb < made ? v : kInf;
+                        }
+                    }
+                    if (lane == (made & 63)) wcur = wsum;
+                    if (qb == made) lb = wsum;  // the queue of internal nodes was empty
+                    made++;
+                    if ((made & 63) == 0) {  // the slot is full: file it (the node head may still be inside it)
+                        slot_set(nwr, (made >> 6) - 1, wcur);
+                        if ((qb >> 6) == (made >> 6) - 1) rcur = wcur;
+                        wcur = kInf;
+                    }
+                }
+            }
+            wv.sync();
+            // depth of x = hops to the root: d[x] += d[p[x]], p[x] = p[p[x]] until every link points at the root
+            uint32_t pp[kElems], dd[kElems];
+#pragma unroll
+            for (uint32_t j = 0; j < kElems; j++) {
+                const uint32_t x = lane + 64 * j;
+                pp[j] = x < root ? L.par[x] : root;
+                dd[j] = x < root ? 1 : 0;
+            }
+            wv.sync();
+            for (uint32_t round = 0; round < 10; round++) {
+#pragma unroll
+                for (uint32_t j = 0; j < kElems; j++) {
+                    const uint32_t x = lane + 64 * j;
+                    if (x < nelem) { L.par[x] = (uint16_t)pp[j]; L.dep[x] = (uint16_t)dd[j]; }
+                }
+                wv.sync();
+                bool moved = false;
+#pragma unroll
+                for (uint32_t j = 0; j < kElems; j++) {
+                    const uint32_t x = lane + 64 * j;
+                    if (x < nelem) {
+                        const uint32_t q = pp[j];
+                        dd[j] += L.dep[q];
+                        pp[j] = L.par[q];
+                        moved |= pp[j] != q;
+                    }
+                }
+                const bool more = wv.ballot(moved) != 0;
+                wv.sync();
+                if (!more) break;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kElems; j++) {
+                const uint32_t x = lane + 64 * j;
+                if (x < nelem) L.dep[x] = (uint16_t)dd[j];
+            }
+            wv.sync();
+            uint32_t cur_max = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++) {
+                len[k] = w0[k] ? L.dep[r[k]] : 0;
+                cur_max = len[k] > cur_max ? len[k] : cur_max;
+            }
+            for (uint32_t o = 32; o; o >>= 1) {
+                const uint32_t v = wv.shfl(cur_max, lane ^ o);
+                cur_max = v > cur_max ? v : cur_max;
+            }
+            wv.sync();
+            if (cur_max <= 15) break;
+            const uint32_t sh = cur_max - 15;  // src/huffman.rs:99-108: weights / 2^sh, at least 1, on top of earlier shrinks
+#pragma unroll
+            for (uint32_t k = 0; k < kSlots; k++)
+                if (wc[k]) { const uint32_t v = wc[k] >> sh; wc[k] = v > 1 ? v : 1; }
+        }
+        // canonical codes in (length, symbol) order
+        uint32_t cnt[16], rnk[kSlots];
+#pragma unroll
+        for (uint32_t l = 0; l < 16; l++) cnt[l] = 0;
+        const uint64_t below = (1ull << lane) - 1;
+#pragma unroll
+        for (uint32_t k = 0; k < kSlots; k++) {
+            rnk[k] = 0;
+#pragma unroll
+            for (uint32_t l = 1; l <= 15; l++) {
+                const uint64_t b = wv.ballot(len[k] == l);
+                if (len[k] == l) rnk[k] = cnt[l] + popc64(b & below);
+                cnt[l] += popc64(b);
+            }
+        }
+        if (lane == 0) {
+            uint32_t bits = 0, cur = 1;
+#pragma unroll
+            for (uint32_t l = 1; l <= 15; l++) {
+                L.first[l] = 0;
+                if (!cnt[l]) continue;
+                if (l > cur) { bits <<= (l - cur); cur = l; }
+                L.first[l] = bits;
+                bits += cnt[l];
+            }
+        }
+        wv.sync();
+#pragma unroll
+        for (uint32_t k = 0; k < kSlots; k++) {
+            const uint32_t s = lane + 64 * k;
+            if (s < n) {
+                lens[s] = (uint8_t)len[k];
+                codes[s] = len[k] ? (uint16_t)(L.first[len[k]] + rnk[k]) : 0;
+            }
+        }
     }
 };
 

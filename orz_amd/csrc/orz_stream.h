@@ -392,7 +392,6 @@ class StreamEncoder {
                 t.hw = take<uint32_t>((size_t)kMaxChunks * kHwStride);
                 t.hl = take<uint8_t>((size_t)kMaxChunks * kHwStride);
                 t.hc = take<uint16_t>((size_t)kMaxChunks * kHwStride);
-                t.hscr = take<uint32_t>((size_t)kMaxChunks * 3 * HuffBuild::kHuffScratch);
                 t.hdrbits = take<uint32_t>(kMaxChunks);
                 t.tot = take<uint32_t>(kMaxChunks);
                 t.srflags = take<uint32_t>(2);
@@ -935,7 +934,7 @@ class StreamEncoder {
         be_.launch(nitems, SymScatter{t.sperm, t.grank, nitems, t.irank});
         be_.memset(t.hw, 0, (size_t)nchunks * kHwStride * 4);
         be_.launch_waves(((size_t)nitems + 4095) / 4096, HistWave{t.irank, t.ial, t.ienc, nitems, t.hw}, HistWave::lds_bytes());
-        be_.huffbuild(HuffBuild{t.hw, nchunks, t.hl, t.hc, t.hscr});
+        be_.huffbuild(HuffBuild{t.hw, nchunks, t.hl, t.hc});
         be_.launch(nitems, ItemBits{t.irank, t.ial, t.ienc, t.irob, t.hl, nitems, t.blen});
         be_.exclusive_scan_u32(t.blen, t.bscan, nitems);
         be_.memset(t.out, 0, (size_t)nchunks * kChunkCapWords * 4);
@@ -1141,7 +1140,7 @@ class StreamEncoder {
         uint32_t* hw = nullptr;
         uint8_t* hl = nullptr;
         uint16_t* hc = nullptr;
-        uint32_t *hscr = nullptr, *hdrbits = nullptr, *tot = nullptr, *out = nullptr, *srflags = nullptr;
+        uint32_t *hdrbits = nullptr, *tot = nullptr, *out = nullptr, *srflags = nullptr;
         bool pending = false;
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };

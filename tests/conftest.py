@@ -80,6 +80,7 @@ def emu():
         lib.emu_free(dst)
         return out
 
+    encode.lib = lib
     encode.fast = encode_fast
     encode.fast_reused = encode_fast_reused
     return encode

@@ -69,7 +69,7 @@ struct EmuBackend {
         for (uint32_t ph = 0; ph < K::kPhases; ph++)
             for (uint32_t t = 0; t < 1024; t++) k.phase(ph, t, 1024, mem.data(), lds != 0);
     }
-    void huffbuild(const orz::HuffBuild& f) { launch((size_t)f.nchunks * 3, f); }
+    void huffbuild(const orz::HuffBuild& f) { if (f.nchunks) launch_waves((size_t)f.nchunks * 3, orz::HuffWave{f}, orz::HuffWave::lds_bytes()); }
     void rank(const orz::RankArgs& a, uint32_t nchunks) {
         // one block per chunk, 256 threads around one barrier: run each block as two thread loops
         std::vector<uint32_t> rows((orz::kRankChunk + 1) * 256);
@@ -217,6 +217,12 @@ extern "C" int emu_encode_fast_reused(const uint8_t* first, size_t n_first, cons
     }
 }
 extern "C" void emu_free(void* p) { std::free(p); }
+// the Huffman table kernel alone (orz_kernels.h, HuffWave): nchunks x kHwStride weights in, lengths and codes out
+extern "C" int emu_huff_build(const uint32_t* hw, unsigned nchunks, uint8_t* hl, uint16_t* hc) {
+    EmuBackend be;
+    be.huffbuild(orz::HuffBuild{hw, nchunks, hl, hc});
+    return (int)orz::kHwStride;
+}
 
 // the hand-off word of the parse kernel (orz_parse.h, ExitPair): pack, then unpack into out[4] = entry, exit, settled, sweep
 extern "C" unsigned long long emu_exitpair(unsigned sweep, int settled, unsigned entry, unsigned exit, unsigned* out) {

@@ -86,3 +86,25 @@ def test_handoff_word_packs_and_unpacks(emu):
         sweep, settled = rnd.choice([0, 1, 4, (1 << 25) - 1, rnd.randrange(1 << 25)]), rnd.randrange(2)
         lib.emu_exitpair(sweep, settled, entry, exit_, out)
         assert list(out) == [entry, exit_, settled, sweep]
+
+
+def test_huffman_kernel_matches_the_oracle(emu, oracle):
+    """HuffWave (sort by counting, two-queue merge, depths by pointer jumping, ballot-counted canonical codes) on the host
+    emulation == HuffmanTable::new_from_sym_weights + HuffmanEncoding (src/huffman.rs:27-141) for every table of
+    tests/_huffcases.py: unused / single / tied symbols, weights that hit the 15-bit cap once and repeatedly"""
+    import ctypes
+
+    import numpy as np
+
+    import _huffcases
+
+    hw = _huffcases.weight_tables()
+    hl, hc = _huffcases.oracle_tables(oracle, hw)
+    assert hl.max() == 15 and any(hl[c].max() < 15 for c in range(hw.shape[0]))
+    el, ec = np.zeros(hw.shape, np.uint8), np.zeros(hw.shape, np.uint16)
+    emu.lib.emu_huff_build.restype = ctypes.c_int
+    stride = emu.lib.emu_huff_build(hw.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(hw.shape[0]), el.ctypes.data_as(ctypes.c_void_p),
+                                    ec.ctypes.data_as(ctypes.c_void_p))
+    assert stride == _huffcases.STRIDE
+    assert (el == hl).all()
+    assert (ec == hc).all()

@@ -236,3 +236,38 @@ def test_randomised_settings_do_not_change_the_stream():
                        timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 mismatches" in r.stdout
+
+
+def test_huffman_kernel_matches_the_oracle(oracle):
+    """orz_huffman_tables (the encoder's HuffWave kernel alone, through the C ABI) == the oracle's
+    HuffmanTable::new_from_sym_weights + HuffmanEncoding (src/huffman.rs:27-141) on every table of tests/_huffcases.py;
+    weights the keys cannot hold are refused.  The launch time goes to gpurun_out/r03_huffman_kernel.json."""
+    import json
+
+    import numpy as np
+
+    import _huffcases
+    import orz_amd
+
+    hw = _huffcases.weight_tables()
+    hl, hc = _huffcases.oracle_tables(oracle, hw)
+    lens, codes, us = orz_amd.huffman_tables(hw)
+    assert (lens == hl).all()
+    assert (codes == hc).all()
+    # the encoder's own shape: the 5 chunks (15 tables) of a 16 MiB block of text
+    five = np.ascontiguousarray(hw[:5])
+    l5, c5, us5 = orz_amd.huffman_tables(five)
+    assert (l5 == hl[:5]).all() and (c5 == hc[:5]).all()
+    row = {"kernel": "HuffWave", "tables": int(hw.shape[0]) * 3, "launch_us": round(us, 1), "tables_of_one_block": 15, "launch_us_one_block": round(us5, 1)}
+    print(json.dumps(row))
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "r03_huffman_kernel.json"), "w") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+    bad = hw.copy()
+    bad[3, 7] = 1 << 23
+    with pytest.raises(Exception):
+        orz_amd.huffman_tables(bad)
