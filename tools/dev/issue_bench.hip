@@ -1,0 +1,96 @@
+// dev: what does ONE wavefront pay per instruction on gfx950?  The symbol-ranking chain (orz_symrank_kernel) is a lone wave
+// per context running ~30 scalar / lane-access instructions per item; this measures the building blocks of that loop in
+// isolation: cycles per instruction for dependent / independent SALU and VALU streams, the VALU -> SGPR -> SALU and
+// VALU -> SGPR -> lane-select hops, v_readlane / v_writelane pairs, a taken branch.
+//   hipcc --offload-arch=gfx950 -O2 tools/dev/issue_bench.hip -o /tmp/issue_bench && /tmp/issue_bench [GHz=2.4]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(r_)); exit(1); } } while (0)
+
+constexpr int kIters = 1 << 20;
+
+#define REP4(x) x x x x
+#define REP8(x) REP4(x) REP4(x)
+
+// every kernel: one wave, kIters trips of a body of `n` instructions of interest (+ s_sub, s_cmp, s_cbranch = 3 of loop)
+#define KERNEL(name, body, clobbers...)                                                                   \
+    __global__ __launch_bounds__(64) void name(int* out) {                                                  \
+        int v0 = threadIdx.x, v1 = threadIdx.x * 3, v2 = 7, v3 = 9;                                         \
+        int s0 = 1, s1 = 2, s2 = 3, s3 = 5;                                                                 \
+        unsigned it = kIters;                                                                               \
+        asm volatile("s_mov_b32 m0, 3\n\t"                                                                  \
+                     "1:\n\t" body                                                                          \
+                     "s_sub_u32 %[it], %[it], 1\n\ts_cmp_lg_u32 %[it], 0\n\ts_cbranch_scc1 1b\n\t"         \
+                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [v3] "+v"(v3), [s0] "+s"(s0), [s1] "+s"(s1), [s2] "+s"(s2), [s3] "+s"(s3), [it] "+s"(it) \
+                     :                                                                                      \
+                     : "scc", "vcc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", ##clobbers);           \
+        out[threadIdx.x] = v0 + v1 + v2 + v3 + s0 + s1 + s2 + s3;                                           \
+    }
+
+KERNEL(k_empty, "")
+KERNEL(k_salu_dep8, REP8("s_add_u32 %[s0], %[s0], 1\n\t"))
+KERNEL(k_salu_ind8, REP4("s_add_u32 %[s0], %[s0], 1\n\ts_add_u32 %[s1], %[s1], 1\n\t"))
+KERNEL(k_valu_dep8, REP8("v_add_u32 %[v0], %[v0], 1\n\t"))
+KERNEL(k_valu_ind8, REP4("v_add_u32 %[v0], %[v0], 1\n\tv_add_u32 %[v1], %[v1], 1\n\t"))
+KERNEL(k_mix_ind8, REP4("v_add_u32 %[v0], %[v0], 1\n\ts_add_u32 %[s0], %[s0], 1\n\t"))
+KERNEL(k_snop8, REP8("s_nop 0\n\t"))
+// VALU compare -> SGPR pair -> s_ff1 -> (SALU) -> back into the VALU as an operand: 4 dependent hops of 3 instructions
+KERNEL(k_cmp_ff1_x4, REP4("v_cmp_eq_u32 s[40:41], %[v0], %[v1]\n\ts_ff1_i32_b64 %[s0], s[40:41]\n\tv_add_u32 %[v0], %[s0], %[v0]\n\t"))
+// the same with four independent instructions between the compare and its consumer
+KERNEL(k_cmp_4_ff1_x4, REP4("v_cmp_eq_u32 s[40:41], %[v0], %[v1]\n\ts_add_u32 %[s1], %[s1], 1\n\ts_add_u32 %[s2], %[s2], 1\n\ts_add_u32 %[s3], %[s3], 1\n\ts_add_u32 %[s1], %[s1], 1\n\t"
+                             "s_ff1_i32_b64 %[s0], s[40:41]\n\tv_add_u32 %[v0], %[s0], %[v0]\n\t"))
+// v_readlane (SGPR result) -> v_writelane using it as the value: dependent pairs
+KERNEL(k_rl_wl_x4, REP4("v_readlane_b32 s42, %[v0], 5\n\ts_nop 0\n\tv_writelane_b32 %[v0], s42, m0\n\t"))
+// v_readlane whose result is the lane select of the next v_readlane (4 wait states required), result written back
+KERNEL(k_rl_sel_rl_x2, REP4("v_readlane_b32 s42, %[v2], 5\n\ts_nop 3\n\tv_readlane_b32 s43, %[v0], s42\n\ts_nop 0\n\tv_writelane_b32 %[v2], s43, m0\n\t"))
+// s_mov m0 + v_writelane pairs (independent values)
+KERNEL(k_m0_wl_x4, REP4("s_mov_b32 m0, %[s1]\n\tv_writelane_b32 %[v0], %[s2], m0\n\t"))
+// a taken branch in the body (besides the loop's own)
+KERNEL(k_branch_x4, REP4("s_cmp_eq_u32 %[s0], %[s0]\n\ts_cbranch_scc1 2f\n\ts_nop 0\n\t2:\n\t") )
+// independent readlanes
+KERNEL(k_rl_ind8, REP4("v_readlane_b32 s42, %[v0], 5\n\tv_readlane_b32 s43, %[v1], 6\n\t"))
+// sdwa compare as the kernel uses it
+KERNEL(k_sdwa_cmp_ind4, REP4("v_cmp_eq_u32_sdwa s[40:41], %[v0], %[v1] src0_sel:WORD_0 src1_sel:WORD_0\n\t"))
+
+struct Test { const char* name; void (*fn)(int*); int n; };
+
+int main(int argc, char** argv) {
+    const double ghz = argc > 1 ? atof(argv[1]) : 2.4;
+    int* out;
+    CHECK(hipMalloc(&out, 256));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    std::vector<Test> tests = {
+        {"loop alone (s_sub, s_cmp, s_cbranch taken)", k_empty, 0},
+        {"8 dependent s_add", k_salu_dep8, 8}, {"8 s_add, two chains", k_salu_ind8, 8},
+        {"8 dependent v_add", k_valu_dep8, 8}, {"8 v_add, two chains", k_valu_ind8, 8},
+        {"4 x (v_add, s_add) independent", k_mix_ind8, 8}, {"8 s_nop 0", k_snop8, 8},
+        {"4 x (v_cmp -> s_ff1 -> v_add) dependent", k_cmp_ff1_x4, 12}, {"4 x (v_cmp, 4 s_add, s_ff1, v_add)", k_cmp_4_ff1_x4, 28},
+        {"4 x (v_readlane, s_nop 0, v_writelane) dependent", k_rl_wl_x4, 12},
+        {"4 x (v_readlane, s_nop 3, v_readlane by it, s_nop 0, v_writelane)", k_rl_sel_rl_x2, 20},
+        {"4 x (s_mov m0, v_writelane)", k_m0_wl_x4, 8}, {"4 x (s_cmp, taken s_cbranch over one s_nop)", k_branch_x4, 8},
+        {"8 independent v_readlane", k_rl_ind8, 8}, {"4 independent v_cmp_sdwa to an SGPR pair", k_sdwa_cmp_ind4, 4},
+    };
+    double base = 0;
+    for (const Test& t : tests) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(t.fn, dim3(1), dim3(64), 0, 0, out);
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        const double cyc = best * 1e6 * ghz / kIters;  // cycles per trip at `ghz`
+        if (t.n == 0) base = cyc;
+        printf("{\"test\": \"%s\", \"instructions\": %d, \"ns_per_trip\": %.2f, \"cycles_per_trip_at_%.1fGHz\": %.1f, \"cycles_per_instruction_net_of_loop\": %.2f}\n", t.name,
+               t.n, best * 1e6 / kIters, ghz, cyc, t.n ? (cyc - base) / t.n : 0.0);
+    }
+    return 0;
+}
