@@ -55,6 +55,23 @@ KERNEL(k_rl_ind8, REP4("v_readlane_b32 s42, %[v0], 5\n\tv_readlane_b32 s43, %[v1
 // sdwa compare as the kernel uses it
 KERNEL(k_sdwa_cmp_ind4, REP4("v_cmp_eq_u32_sdwa s[40:41], %[v0], %[v1] src0_sel:WORD_0 src1_sel:WORD_0\n\t"))
 
+// compare variants: where does the mask go, how wide is the compare
+KERNEL(k_cmp_e64_ind4, REP4("v_cmp_eq_u32_e64 s[40:41], %[s0], %[v1]\n\t"))
+KERNEL(k_cmp_u16_e64_ind4, REP4("v_cmp_eq_u16_e64 s[40:41], %[s0], %[v1]\n\t"))
+KERNEL(k_cmp_vcc_ind4, REP4("v_cmp_eq_u32_e32 vcc, %[s0], %[v1]\n\t"))
+KERNEL(k_cmp_u16_vcc_ind4, REP4("v_cmp_eq_u16_e32 vcc, %[s0], %[v1]\n\t"))
+KERNEL(k_cmp_sdwa_vcc_ind4, REP4("v_cmp_eq_u32_sdwa vcc, %[s0], %[v1] src0_sel:WORD_1 src1_sel:WORD_0\n\t"))
+// compare into VCC, branch on it (never taken: v0 != s0 somewhere... all lanes differ), find the bit
+KERNEL(k_cmp_vccz_ff1_x4, REP4("v_cmp_ne_u32_e32 vcc, %[s3], %[v1]\n\ts_cbranch_vccz 3f\n\ts_ff1_i32_b64 %[s0], vcc\n\t") "3:\n\t")
+KERNEL(k_cmp_ff1_cmp_br_x4, REP4("v_cmp_ne_u32_e64 s[40:41], %[s3], %[v1]\n\ts_ff1_i32_b64 %[s0], s[40:41]\n\ts_cmp_lt_i32 %[s0], 0\n\ts_cbranch_scc1 3f\n\t") "3:\n\t")
+// untaken branches
+KERNEL(k_untaken_x8, REP8("s_cbranch_scc1 3f\n\t") "3:\n\t")
+KERNEL(k_readlane_sgprsel_ind8, REP4("v_readlane_b32 s42, %[v0], %[s1]\n\tv_readlane_b32 s43, %[v1], %[s2]\n\t"))
+KERNEL(k_readfirstlane_ind8, REP4("v_readfirstlane_b32 s42, %[v0]\n\tv_readfirstlane_b32 s43, %[v1]\n\t"))
+KERNEL(k_writelane_const_ind8, REP8("v_writelane_b32 %[v0], %[s2], 5\n\t"))
+KERNEL(k_writelane_m0_ind8, REP8("v_writelane_b32 %[v0], %[s2], m0\n\t"))
+KERNEL(k_smov_m0_8, REP8("s_mov_b32 m0, %[s1]\n\t"))
+
 struct Test { const char* name; void (*fn)(int*); int n; };
 
 int main(int argc, char** argv) {
@@ -74,6 +91,13 @@ int main(int argc, char** argv) {
         {"4 x (v_readlane, s_nop 3, v_readlane by it, s_nop 0, v_writelane)", k_rl_sel_rl_x2, 20},
         {"4 x (s_mov m0, v_writelane)", k_m0_wl_x4, 8}, {"4 x (s_cmp, taken s_cbranch over one s_nop)", k_branch_x4, 8},
         {"8 independent v_readlane", k_rl_ind8, 8}, {"4 independent v_cmp_sdwa to an SGPR pair", k_sdwa_cmp_ind4, 4},
+        {"4 v_cmp_eq_u32_e64 to an SGPR pair", k_cmp_e64_ind4, 4}, {"4 v_cmp_eq_u16_e64 to an SGPR pair", k_cmp_u16_e64_ind4, 4},
+        {"4 v_cmp_eq_u32_e32 to VCC", k_cmp_vcc_ind4, 4}, {"4 v_cmp_eq_u16_e32 to VCC", k_cmp_u16_vcc_ind4, 4}, {"4 v_cmp_eq_u32_sdwa to VCC", k_cmp_sdwa_vcc_ind4, 4},
+        {"4 x (v_cmp to VCC, s_cbranch_vccz untaken, s_ff1 vcc)", k_cmp_vccz_ff1_x4, 12},
+        {"4 x (v_cmp to SGPRs, s_ff1, s_cmp_lt, s_cbranch untaken)", k_cmp_ff1_cmp_br_x4, 16},
+        {"8 untaken s_cbranch_scc1", k_untaken_x8, 8}, {"8 v_readlane, lane select in an SGPR", k_readlane_sgprsel_ind8, 8},
+        {"8 v_readfirstlane", k_readfirstlane_ind8, 8}, {"8 v_writelane, constant lane", k_writelane_const_ind8, 8},
+        {"8 v_writelane, lane in M0", k_writelane_m0_ind8, 8}, {"8 s_mov m0", k_smov_m0_8, 8},
     };
     double base = 0;
     for (const Test& t : tests) {
