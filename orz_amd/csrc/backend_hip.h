@@ -698,8 +698,10 @@ class HipBackend {
     // flags[1], which the host reads with the block's output (a set flags[1] fails the encode: no stream is better than a
     // wrong one).  Twice in this round a finished stream carried one such rank (a WORD item coded as "the excluded
     // symbol") -- out of ~10^10 ranked items, never reproduced, cause not found.
+    // ORZ_SYMRANK_VERIFY=1 (diagnostics): every block is ranked twice from the same tables and the two runs' ranks are
+    // compared (flags[2] = differences; `keep` holds the first run's ranks) -- twice the chain, for soak runs only.
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags,
-                 uint16_t* backup) {
+                 uint16_t* backup, uint16_t* keep) {
         static_assert((512 * kSrWords * 2) % 8 == 0, "the tables are copied in 8-byte words");
         const uint32_t nw = 512 * kSrWords * 2 / 8;
         launch(nw, SymGuardBegin{reinterpret_cast<const uint64_t*>(srstate), reinterpret_cast<uint64_t*>(backup), nw, flags});
@@ -716,6 +718,14 @@ class HipBackend {
                            (const uint32_t*)flags);
         ORZ_HIP_CHECK(hipGetLastError());
         launch(SymCheck::kThreads, SymCheck{gsym, grank, nitems, flags + 1, flags});
+        static const bool verify = getenv("ORZ_SYMRANK_VERIFY") && atoi(getenv("ORZ_SYMRANK_VERIFY"));
+        if (verify && keep) {
+            launch(SymCompare::kThreads, SymKeep{grank, keep, nitems});
+            hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)backup,
+                               (const uint32_t*)nullptr);
+            ORZ_HIP_CHECK(hipGetLastError());
+            launch(SymCompare::kThreads, SymCompare{grank, keep, nitems, flags + 2});
+        }
     }
 
    private:

@@ -175,7 +175,28 @@ struct SymGuardBegin {  // the tables as they are before a block's ranking -> ba
     uint32_t* flags;
     ORZ_HD void operator()(size_t t) const {
         if (t < nwords) backup[t] = state[t];
-        if (t == 0) { flags[0] = 0; flags[1] = 0; }
+        if (t == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; }
+    }
+};
+struct SymCompare {  // (diagnostics, ORZ_SYMRANK_VERIFY) the ranks of two runs of a block's ranking side by side
+    const uint16_t* a;
+    const uint16_t* b;
+    uint32_t nitems;
+    uint32_t* flag;  // += differences
+    static constexpr uint32_t kThreads = 65536;
+    ORZ_HD void operator()(size_t t) const {
+        if (t >= kThreads) return;
+        uint32_t bad = 0;
+        for (size_t k = t; k < nitems; k += kThreads) bad += a[k] != b[k];
+        if (bad) ORZ_ATOMIC_ADD(flag, bad);
+    }
+};
+struct SymKeep {  // (diagnostics) the first run's ranks, put aside
+    const uint16_t* src;
+    uint16_t* dst;
+    uint32_t nitems;
+    ORZ_HD void operator()(size_t t) const {
+        for (size_t k = t; k < nitems; k += SymCompare::kThreads) dst[k] = src[k];
     }
 };
 struct SymInject {  // (tests) the failure the guard exists for: item k's rank reads "excluded symbol" although it is not

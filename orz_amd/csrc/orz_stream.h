@@ -394,7 +394,7 @@ class StreamEncoder {
                 t.hc = take<uint16_t>((size_t)kMaxChunks * kHwStride);
                 t.hdrbits = take<uint32_t>(kMaxChunks);
                 t.tot = take<uint32_t>(kMaxChunks);
-                t.srflags = take<uint32_t>(2);
+                t.srflags = take<uint32_t>(4);
                 t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords, false);
             }
             counts_ = take<uint32_t>(kSyms + 3);
@@ -926,7 +926,7 @@ class StreamEncoder {
         MainStreamGuard back_to_main{be_};
         be_.select(1);
         be_.wait(kEvItems + b);
-        be_.symrank(srstate_, t.gsym, t.grank, t.rstart, nitems, t.srflags, srbackup_);
+        be_.symrank(srstate_, t.gsym, t.grank, t.rstart, nitems, t.srflags, srbackup_, t.skey);  // (skey: free since SymRunStart)
         be_.record(kEvRank + b);
         // ---- static Huffman per chunk and bit packing on stream 2
         be_.select(2);
@@ -979,8 +979,9 @@ class StreamEncoder {
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
         {   // the guard of the block's symbol ranking (backend symrank): repeated? still impossible ranks?
-            uint32_t f[2] = {0, 0};
-            be_.d2h(f, t.srflags, 8);
+            uint32_t f[3] = {0, 0, 0};
+            be_.d2h(f, t.srflags, 12);
+            if (f[2]) fprintf(stderr, "orz: two runs of the symbol ranking of block %u from the same tables differ in %u ranks\n", t.block, f[2]);
             if (f[0]) {
                 stats.rank_redos++;
                 fprintf(stderr, "orz: the symbol ranking of block %u was repeated (%u impossible ranks in its first run; %u after the second)\n", t.block, f[0], f[1]);
@@ -1055,7 +1056,12 @@ class StreamEncoder {
     void slide_by(uint32_t sh, uint32_t extra, bool slide_window = true) {
         if (sh != kNewMax) hist_hint_ = ~0u;
         be_.launch(3, TailKeys{dwin(), kPre + sh, tailkey_});
-        if (slide_window) be_.d2d(dwin(), dwin() + sh, (size_t)kPre + extra);
+        // (two bytes more than the history: the context of the item start at window offset 1 -- hash1 of offset 0 -- looks at
+        // the byte before the window.  The reference files a position under the context it had when it was inserted; the
+        // tables here are rebuilt from the window's bytes, and with the front sentinel's zero in that place the position
+        // landed in the context without the letter-or-digit bit -- a source no decoder finds there.)
+        if (slide_window) be_.d2d(dwin() - 2, dwin() + sh - 2, (size_t)kPre + extra + 2);
+        else be_.d2d(dwin() - 2, dwin() + sh - 2, 2);  // (the caller uploads the window from offset 0 on: the two bytes before it are kept here)
         for (uint32_t off = 0; off < kPre; off += sh) {
             be_.launch(sh, SlideArray<uint8_t>{S_, off, sh, kPre});
             be_.launch(sh, SlideArray<uint8_t>{ML_, off, sh, kPre});

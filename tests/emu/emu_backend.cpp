@@ -134,8 +134,8 @@ struct EmuBackend {
         uint32_t run = 0;
         for (size_t i = 0; i < n; i++) { if (in[i] > run) run = in[i]; out[i] = run; }
     }
-    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags, uint16_t*) {
-        flags[0] = flags[1] = 0;  // (the reference loop below needs no second run; the check runs all the same)
+    void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags, uint16_t*, uint16_t*) {
+        flags[0] = flags[1] = flags[2] = 0;  // (the reference loop below needs no second run; the check runs all the same)
         for (uint32_t c = 0; c < 512; c++) {
             uint16_t value[orz::kSyms], index[orz::kSyms];
             orz::symrank_run(value, index, srstate + (size_t)c * orz::kSrWords, gsym, grank, rstart[c], rstart[c + 1]);
@@ -213,6 +213,46 @@ extern "C" int emu_encode_fast_reused(const uint8_t* first, size_t n_first, cons
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emu_encode_fast_reused: %s\n", e.what());
+        return -1;
+    }
+}
+// the fast parse's items (block, window offset, source, symbol, length, flags) next to its stream: parity forensics
+struct EmuItem { uint32_t block, pos, src; uint16_t sym, rank, ctx; uint8_t mlen, al, unl, enc; };
+extern "C" long emu_encode_fast_trace(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, uint8_t** dst, size_t* dst_len, EmuItem* items,
+                                      size_t cap) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        orz::ItemTrace tr;
+        enc.trace = &tr;
+        std::vector<uint8_t> out;
+        orz::encode_stream(enc, be, src, n, false, out);
+        *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        const size_t k = tr.pos.size() < cap ? tr.pos.size() : cap;
+        for (size_t i = 0; i < k; i++)
+            items[i] = EmuItem{tr.block[i], tr.pos[i], tr.src[i], tr.sym[i], tr.rank[i], tr.ctx[i], tr.mlen[i], tr.al[i], tr.unl[i], tr.enc[i]};
+        return (long)tr.pos.size();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_encode_fast_trace: %s\n", e.what());
+        return -1;
+    }
+}
+// the two bytes in front of the window after a stream was encoded (the context of the oldest history position looks there)
+extern "C" int emu_window_front(const uint8_t* src, size_t n, uint8_t* front2) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{15, 9, 6};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        std::vector<uint8_t> out;
+        orz::encode_stream(enc, be, src, n, false, out);
+        front2[0] = enc.dwin()[-2];
+        front2[1] = enc.dwin()[-1];
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_window_front: %s\n", e.what());
         return -1;
     }
 }

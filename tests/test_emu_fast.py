@@ -150,3 +150,20 @@ def test_a_reused_encoder_writes_what_a_fresh_one_writes(emu, oracle):
             again = emu.fast_reused(first, data, cfg=LEVELS[1])
             assert again == fresh
         assert oracle.decode(fresh)[0] == bytes(data)
+
+
+def test_the_byte_before_the_window_travels_with_the_slide(emu, oracle):
+    """The context of the history position at window offset 1 is hash1 of offset 0, which looks at the byte BEFORE the window
+    (src/lz.rs:482-486).  The reference keeps a position in the bucket it was inserted into; the tables here are rebuilt
+    from the window's bytes after every slide, so that byte has to travel with the slide -- with the front sentinel's zero
+    in its place the position lands in the context without the letter-or-digit bit, a later position of that (rare) context
+    takes it as a source, and no decoder finds it there (found by a soak of 64 MiB members: 5 of 640 invalid).  After a
+    two-block stream the two bytes in front of the window must be the stream's: offset 0 is stream offset 1."""
+    import ctypes
+
+    key = b"QWERTYUIOPASDFGHJKLZ"
+    head = b"a-" + key
+    data = head + b"x" * ((1 << 24) - len(head)) + b"x" * 500 + b" -" + key + b"x" * 500
+    front = (ctypes.c_uint8 * 2)()
+    assert emu.lib.emu_window_front(data, ctypes.c_size_t(len(data)), front) == 0
+    assert bytes(front) == b"\0a"  # (stream offset -1 is the sentinel, stream offset 0 the first byte)

@@ -330,3 +330,24 @@ def test_symbol_ranking_guard_repeats_a_block_with_an_impossible_rank(oracle, mo
     assert "was repeated" in capfd.readouterr().err
     assert out == clean
     assert oracle.decode(out)[0] == data
+
+
+def test_member_whose_oldest_history_position_changes_context(oracle):
+    """The input a soak of 64 MiB members found (tools/dev/soak_members.py, round 7, member 0): in its second block a match
+    of a rare context took the history position at window offset 1 as its source -- a position that had been filed under
+    the context WITHOUT the letter-or-digit bit because the byte before the window was not slid with it; the stream was
+    invalid for every decoder, deterministically, also from a fresh encoder (5 of 640 members of that soak).  The first two
+    blocks must decode with the oracle."""
+    import corpus
+    import orz_amd
+
+    base = corpus.enwik_like(100_000_000)
+    off = (7 * 7_919_113) % (len(base) - 1)
+    data = bytes((base[off:] + base[:off])[: 2 << 24])
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        out = enc.encode(data)
+    finally:
+        enc.close()
+    back, used = oracle.decode(out)
+    assert used == len(out) and back == data
