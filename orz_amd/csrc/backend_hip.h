@@ -696,8 +696,8 @@ class HipBackend {
     // that needs no table -- rank 388 exactly where the symbol is the excluded one (SymCheck) -- and when the check fails
     // the block is ranked again from the tables saved before the first run; what the second run left is checked again into
     // flags[1], which the host reads with the block's output (a set flags[1] fails the encode: no stream is better than a
-    // wrong one).  Twice in this round a finished stream carried one such rank (a WORD item coded as "the excluded
-    // symbol") -- out of ~10^10 ranked items, never reproduced, cause not found.
+    // wrong one).  An invariant check: it was written when invalid members were blamed on this kernel; their cause
+    // turned out to be elsewhere, and in soaks with every block ranked twice the two runs never differed.
     // ORZ_SYMRANK_VERIFY=1 (diagnostics): every block is ranked twice from the same tables and the two runs' ranks are
     // compared (flags[2] = differences; `keep` holds the first run's ranks) -- twice the chain, for soak runs only.
     void symrank(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank, const uint32_t* rstart, uint32_t nitems, uint32_t* flags,
