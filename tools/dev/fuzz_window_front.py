@@ -1,7 +1,9 @@
 """dev: two-block inputs on the HOST EMULATION whose second block refers to the oldest history positions (the first bytes of
 the stream, which sit at window offsets 0..7 after the slide) from rare contexts -- the neighbourhood of the defect fixed in
 round 3 (the context of window offset 1 needs the byte before the window).  Every stream is decoded by the
-oracle.  The filler is one repeated byte, so a 16 MiB block costs the emulation half a minute.
+oracle.  The filler is one repeated byte, so a 16 MiB block costs the emulation half a minute.  (Power: limited -- on the
+code WITHOUT the fix the same 16 cases also decode; the repairs cut the near cases this generator makes.  The reproducer of
+the defect is a real member: tests/test_gpu_fast.py, tools/dev/soak_members.py.)
     python tools/dev/fuzz_window_front.py [cases=12] [seed=1]"""
 import os
 import random
