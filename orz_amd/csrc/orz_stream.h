@@ -851,11 +851,15 @@ class StreamEncoder {
             be_.d2h(h, a.stats, sizeof h);
             fprintf(stderr, "flip: %llu item flips, %llu word flips, walk trips %llu / %llu\n", h[16], h[17], h[18], h[19]);
         }
-        if (const char* fv = getenv("ORZ_FAST_VERIFY")) {  // diagnostics: the frozen parse against first principles (FastVerify)
-            unsigned long long* e = (unsigned long long*)fgsum_ + 8192 + 32;  // (1 = read back per block; 2 = counters kept on the device until the stream ends: no extra synchronisation)
-            if (atoi(fv) != 2 || stream_start_) be_.memset(e, 0, 6 * 8);
+        // Every match of the frozen parse against first principles (FastVerify: the source is an item start of the same
+        // context, inside the ring, with the same bytes).  On by default since the round-3 incident: the
+        // counters stay on the device until the stream ends (no synchronisation) and a finding fails the encode -- no stream
+        // is better than one no decoder accepts.  ORZ_FAST_VERIFY=0 off, 1 = read back and reported per block.
+        if (const int vmode = verify_mode()) {
+            unsigned long long* e = (unsigned long long*)fgsum_ + 8192 + 32;
+            if (vmode != 2 || stream_start_) be_.memset(e, 0, 6 * 8);
             be_.launch(n, FastVerify{a, SRC_, S_, e});
-            if (atoi(fv) != 2) report_verify("block");
+            if (vmode != 2) report_verify("block");
         }
         // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
         be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
@@ -1036,14 +1040,22 @@ class StreamEncoder {
     template <class OutT>
     void finish(OutT& out) {
         collect(out, nullptr);
-        if (fast_ && getenv("ORZ_FAST_VERIFY") && atoi(getenv("ORZ_FAST_VERIFY")) == 2) report_verify("stream");
+        if (fast_ && stats.blocks && verify_mode() == 2) report_verify("stream");
+    }
+    static int verify_mode() {
+        static const int m = getenv("ORZ_FAST_VERIFY") ? atoi(getenv("ORZ_FAST_VERIFY")) : 2;
+        return m;
     }
     void report_verify(const char* what) {
         unsigned long long h6[6];
         be_.d2h(h6, (unsigned long long*)fgsum_ + 8192 + 32, sizeof h6);
-        if (h6[1] | h6[2] | h6[3] | h6[4])
-            fprintf(stderr, "ORZ_FAST_VERIFY: %s (%llu blocks so far): %llu matches, %llu sources not item starts, %llu in another context, %llu outside the ring, %llu with other bytes (e.g. at %llu)\n",
-                    what, (unsigned long long)stats.blocks, h6[0], h6[1], h6[2], h6[3], h6[4], h6[5]);
+        if (h6[1] | h6[2] | h6[3] | h6[4]) {
+            char msg[320];
+            snprintf(msg, sizeof msg, "fast parse verification, %s (%llu blocks so far): of %llu matches %llu have a source that is no item start, %llu one of another context, %llu one outside the ring, %llu one with other bytes (e.g. at window offset %llu)",
+                     what, (unsigned long long)stats.blocks, h6[0], h6[1], h6[2], h6[3], h6[4], h6[5]);
+            fprintf(stderr, "orz: %s\n", msg);
+            throw std::runtime_error(msg);
+        }
     }
 
     // window slide + LZEncoder::forward (src/lib.rs:83-84, src/lz.rs:82-87, src/matcher.rs:82-87):
