@@ -1538,16 +1538,37 @@ ORZ_D uint32_t fast_word_at(const FastArgs& a, const uint32_t* laste, uint32_t p
     if (le > klo) return a.kw[le - 1];
     return (uint32_t)a.wsnap[key2 * 2] | ((uint32_t)a.wsnap[key2 * 2 + 1] << 8);
 }
-struct FastWordCheck {  // a WORD item whose prediction the exact state does not make becomes two literals
+// A WORD item whose prediction the exact state does not make becomes two literals -- in TWO launches.  FastWordCheck only
+// NOTES the verdict (cutend[i] = kWordFix; the array is all zero between FastRecut and the next FastSource), FastWordApply
+// rewrites the item.  As one kernel this was the round-3 defect (1 of 10^2..10^3 members of 64 MiB
+// undecodable, on the GPU only): the rewrite makes i + 1 an item start, and the thread of i + 1 -- in another wavefront when
+// i is a wavefront's last lane, running at the same time -- could see that new bit in `sbits` but still the ROUND's decision
+// in ty[i + 1] (the plain store had not reached it).  Was that stale decision WORD with a wrong prediction, it "repaired" the
+// item that is not one: ty[i + 2] = literal -- which cut a match at i + 2 down to one byte with nothing re-parsing its span, a
+// hole in the path that no decoder follows.  The host emulation runs a launch's threads one after another and never saw it.
+// Rule for every kernel of the repair stage: a thread acts only on state that was written by an EARLIER launch.
+constexpr uint32_t kWordFix = ~0u;
+struct FastWordCheck {
     FastArgs a;
     const uint32_t* laste;
-    uint64_t* rdirty;
+    uint32_t* fix;  // [n] = cutend: kWordFix where a WORD item has to go
     const FastCtl* ctl;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
         const uint32_t p = kPre + (uint32_t)i;
         const uint32_t w = fast_word_at(a, laste, p);
         if (w == ((uint32_t)a.win[p] | ((uint32_t)a.win[p + 1] << 8))) return;
+        fix[i] = kWordFix;
+    }
+};
+struct FastWordApply {  // thread per position: acts on the flags of the launch before, writes nothing another thread of this launch reads
+    FastArgs a;
+    uint32_t* fix;
+    uint64_t* rdirty;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || fix[i] != kWordFix) return;
+        fix[i] = 0;
+        const uint32_t p = kPre + (uint32_t)i;
         atom_add32(a.nchg, 1);
         a.ty[i] = kTyLit; a.nl[i] = 1;
         a.ty[i + 1] = kTyLit; a.nl[i + 1] = 1;

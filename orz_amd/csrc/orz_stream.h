@@ -15,6 +15,7 @@
 //                     launch; histograms -> Huffman -> bit pack on stream 2 -- post_stage below)
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -662,6 +663,33 @@ class StreamEncoder {
         be_.launch(groups * 256, ColScanRows{in, fgsum_, rows, out});
     }
 
+    // Diagnostics (ORZ_DEBUG_DUMP=<dir>, ORZ_DEBUG_POS=<window offset>): the per-position state of the fast parse in a window of
+    // 512 positions around the offset, written after the rounds ("r") and after the repairs + commit ("f") of every block.
+    void debug_dump(const char* tag, uint32_t n, const FastCtl* h) {
+        static const char* dir = getenv("ORZ_DEBUG_DUMP");
+        if (!dir) return;
+        static const uint32_t at = getenv("ORZ_DEBUG_POS") ? (uint32_t)strtoul(getenv("ORZ_DEBUG_POS"), nullptr, 10) : kPre + 256;
+        const uint32_t lo = (std::max(at, kPre + 256) - 256) & ~63u, w = 512;
+        if (lo + w > kPre + n) return;
+        const uint32_t i0 = lo - kPre;  // (a multiple of 64 + 1 ... the bitmap words are fetched around it)
+        struct Rec { uint32_t lo, w, block, passes, total, nmem, lastflips, pad; } rec{lo, w, (uint32_t)stats.blocks, h ? h->passes : 0, h ? h->total : 0, h ? h->nmem : 0, h ? h->lastflips : 0, 0};
+        std::vector<uint8_t> b8(w);
+        std::vector<uint32_t> b32(w);
+        std::vector<uint64_t> b64(w / 64 + 2);
+        char name[512];
+        static std::atomic<unsigned> serial{0};
+        snprintf(name, sizeof name, "%s/dump_%05u_%p_b%u_%s.bin", dir, serial.fetch_add(1), (void*)this, (unsigned)stats.blocks, tag);
+        FILE* f = fopen(name, "wb");
+        if (!f) return;
+        fwrite(&rec, sizeof rec, 1, f);
+        be_.d2h(b64.data(), fsbits_ + i0 / 64, b64.size() * 8); fwrite(b64.data(), 8, b64.size(), f);
+        const uint8_t* a8[] = {fty_ + i0, fnl_ + i0, fpt_ + i0, fmf_ + i0, fef_ + i0, fdirty_ + i0, S_ + lo, TY_ + lo, ML_ + lo, W0_ + lo, LENMIN_ + lo, LMV_ + lo, dwin() + lo};
+        for (const uint8_t* q : a8) { be_.d2h(b8.data(), q, w); fwrite(b8.data(), 1, w, f); }
+        const uint32_t* a32[] = {SRC_ + lo, ORD_ + lo, fev_ + i0, ffarv_ + i0, idx_ + lo, fcut_ + i0};
+        for (const uint32_t* q : a32) { be_.d2h(b32.data(), q, (size_t)w * 4); fwrite(b32.data(), 4, w, f); }
+        fclose(f);
+    }
+
     // The GPU-native parse of one block (orz_fast.h): fills S_/TY_/ML_/SRC_/ORD_/W0_ for the new region and
     // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
     void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys) {
@@ -799,6 +827,7 @@ class StreamEncoder {
             }
             capture.on = false;
             if (use_graph && !replayed) be_.graph_capture_end(gkey);
+            debug_dump("r", n, nullptr);
             // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes.  The passes are launched in
             // groups without the host in between: a pass that finds nothing to repair sets `done` on the device and the
             // kernels of later passes return at once; the control block is read once per group.
@@ -830,12 +859,14 @@ class StreamEncoder {
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
                     be_.inclusive_max_scan_u32(f32_, flaste_, nk);
-                    be_.launch(n, FastWordCheck{a, flaste_, rd_out, fctl_});
+                    be_.launch(n, FastWordCheck{a, flaste_, fcut_, fctl_});
+                    be_.launch(n, FastWordApply{a, fcut_, rd_out});
                     be_.launch(1, FastPassEnd{fctl_});
                 }
                 be_.d2h(&h, fctl_, sizeof h);
             }
             if (!h.done) throw std::runtime_error("fast parse: repairs did not converge");
+            hfin_ = h;
             if (getenv("ORZ_FAST_SHOWFLIPS")) fprintf(stderr, "T=%u: %u item starts changed in their last round, %u repairs in %u passes, %u items\n", T, h.lastflips, h.total, h.passes, h.nmem);
             stats.seg_evals += h.total;  // (fast mode: repairs made)
             // unstable = more than 1 % of the items repaired AND more than one repair per 2000 input bytes (sparse item
@@ -866,6 +897,7 @@ class StreamEncoder {
         be_.launch(1, FastLtCarry{fpt_, n, fctl_});
         be_.launch(32768, FastWordsCarry{a, flaste_, krunend_, wsnap_});
         be_.launch(256, FastCtxCarry{fcp_, nsub, ctxcount_});
+        debug_dump("f", n, &hfin_);
     }
 
     // Second half of a block: items -> len_min -> symbols -> symrank -> Huffman -> bit pack (shared by both parse modes).
@@ -1147,6 +1179,7 @@ class StreamEncoder {
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr, *fcl_ = nullptr;
     uint32_t *fccnt_ = nullptr, *fcnew_ = nullptr;
     FastCtl* fctl_ = nullptr;
+    FastCtl hfin_{};  // the control block as read after the last repair pass of the block parsed last (diagnostics)
     uint8_t lt_carry_ = kTyLit;
     bool stream_start_ = true;
     // buffers of the item stage and the tail stage, two sets (block parity)

@@ -127,3 +127,34 @@ def encode_plan(data, plan_n):
     out = ctypes.string_at(dst, n.value)
     L.orc_free(dst)
     return out
+
+
+class Diag(ctypes.Structure):  # orc_diag (oracle/orz_diag.c)
+    _fields_ = [("kind", ctypes.c_int32), ("cause", ctypes.c_int32), ("stream_off", ctypes.c_uint64), ("item_index", ctypes.c_uint64)] + [
+        (k, ctypes.c_uint32) for k in ("block", "chunk", "item_in_chunk", "spos", "type", "symbol_rank", "symbol", "ctx", "after_literal",
+                                       "unlikely", "reduced_offset", "node", "node_pos", "node_len_min", "node_len_expected", "enc_len",
+                                       "match_len", "true_lcp", "src_ctx", "word0", "word1", "want0", "want1", "first_bad", "ring_count")] + [
+        (k, ctypes.c_uint32 * 33) for k in ("near_pos", "near_lcp", "near_exp", "near_min")] + [
+        (k, ctypes.c_uint32) for k in ("lit_rank", "word_rank", "unl_index", "tab_cnt", "tab_sum")] + [("tab_near", ctypes.c_uint32 * 9)] + [
+        (k, ctypes.c_uint32) for k in ("tab_raw_index", "best_ro", "best_pos", "best_lcp", "best_exp", "best_min")]
+
+
+_diag = None
+
+
+def diag(stream, expect):
+    """forensic decode (oracle/orz_diag.c): {} when `stream` decodes to `expect`, else the first item that does not --
+    everything the decoder knew about it"""
+    global _diag
+    if _diag is None:
+        so = os.path.join(ORACLE_DIR, "liborz_diag.so")
+        if not os.path.exists(so):
+            build()
+        _diag = ctypes.CDLL(so)
+        _diag.orc_diag_decode.restype = ctypes.c_int
+    d = Diag()
+    stream, expect = bytes(stream), bytes(expect)
+    kind = _diag.orc_diag_decode(stream, ctypes.c_size_t(len(stream)), expect, ctypes.c_size_t(len(expect)), ctypes.byref(d))
+    if kind == 0:
+        return {}
+    return {k: (list(getattr(d, k)) if k.startswith("near_") or k == "tab_near" else int(getattr(d, k))) for k, _ in Diag._fields_}

@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# GPU tier order: the per-row parity tests first, the full-size configurations and the soak last -- the tier runs with -x, and a
+# late failure in the heaviest, newest tests must not blank the per-row evidence ("what's weak" 2)
+_GPU_ORDER = ["test_gpu_parity.py", "test_gpu_fast.py", "test_device_decoder.py", "test_benchmark_tool.py", "test_enwik8.py",
+              "test_gpu_verify.py", "test_gpu_configs.py", "test_gpu_soak.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return _GPU_ORDER.index(name) if name in _GPU_ORDER else -1
+
+    items.sort(key=rank)  # (stable: the order inside a file, and of the CPU tests, stays as collected)
+
+
 def _have_gpu():
     try:
         from orz_amd import _native
