@@ -731,7 +731,7 @@ class HipBackend {
    private:
     int device_;
     hipStream_t stream_ = nullptr;
-    static constexpr int kStreams = 4, kEvents = 6;  // (stream 3 only copies finished output to the host: no temporary storage)
+    static constexpr int kStreams = 4, kEvents = 8;  // (stream 3 only copies finished output to the host: no temporary storage)
     hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
     void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};

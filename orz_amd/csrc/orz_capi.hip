@@ -59,6 +59,89 @@ bool mode_from_env() {
     return !(v && std::string(v) == "exact");
 }
 
+// ORZ_VERIFY=decode (bin/orz encode --verify): every finished stream goes through the library's OWN decoder
+// (orz_host_decode.h, src/lz.rs:366-478) before its bytes leave the library, and must reproduce the input bit for bit;
+// what the per-block validity gate (orz_verify.h) cannot see -- symbol ranking, Huffman tables, bit packing -- is covered by
+// this.  The check is incremental: input and output are fed as they arrive, a chunk is decoded as soon as it is complete, so
+// the streaming entry point (orz_encode) verifies a block's bytes BEFORE it hands them to the caller's sink.
+bool verify_decode_on() {
+    const char* v = std::getenv("ORZ_VERIFY");
+    return v && std::string(v) == "decode";
+}
+class DecodeCheck {
+   public:
+    DecodeCheck() : ws_(new orz::host::DecodeWorkspace) { ws_->begin_stream(); }
+    void feed_input(const uint8_t* p, size_t n) { in_.insert(in_.end(), p, p + n); }
+    // bytes of the stream in order; throws std::runtime_error on the first chunk that does not decode to the input
+    void feed_output(const uint8_t* p, size_t n) {
+        out_.insert(out_.end(), p, p + n);
+        for (;;) {
+            size_t t = 0, at = opos_;
+            unsigned sh = 0;
+            bool whole = false;
+            while (at < out_.size()) {  // read_len, src/ioutil.rs:60-77
+                const uint8_t b = out_[at++];
+                t |= (size_t)(b & 0x7f) << sh;
+                sh += 7;
+                if (!(b & 0x80)) { whole = true; break; }
+            }
+            if (!whole) break;
+            if (t == 0) { eof_ = true; opos_ = at; break; }
+            if (at + t > out_.size()) break;  // the chunk is not complete yet
+            if (t >= ws_->tbuf.size()) bad("a chunk longer than the decoder accepts");
+            std::memcpy(ws_->tbuf.data(), out_.data() + at, t);
+            uint8_t* sbuf = ws_->win.data() + orz::kSent;
+            size_t end;
+            try {
+                end = ws_->dec.decode(ws_->tbuf.data(), t, sbuf, spos_);
+            } catch (const std::exception&) {
+                bad("the decoder rejects a chunk");
+            }
+            if (end < spos_) bad("the decoder rejects a chunk");
+            const size_t got = end - spos_;
+            if (ipos_ + got > in_.size() || std::memcmp(sbuf + spos_, in_.data() + ipos_, got) != 0) bad("a chunk decodes to other bytes than were encoded");
+            ipos_ += got;
+            checked_ += got;
+            spos_ = end;
+            if (spos_ >= orz::kBlock) {  // src/lib.rs:120-125
+                std::memmove(sbuf, sbuf + (orz::kBlock - orz::kPre), orz::kPre);
+                ws_->dec.forward(orz::kBlock - orz::kPre);
+                spos_ = orz::kPre;
+            }
+            opos_ = at + t;
+            // drop what has been checked (the buffers stay small on long streams)
+            if (opos_ > (1u << 24)) { out_.erase(out_.begin(), out_.begin() + (ptrdiff_t)opos_); opos_ = 0; }
+            if (ipos_ > (1u << 24)) { in_.erase(in_.begin(), in_.begin() + (ptrdiff_t)ipos_); ipos_ = 0; }
+        }
+    }
+    void finish() {
+        if (!eof_ || ipos_ != in_.size() || opos_ != out_.size()) bad("the stream ends before its input does (or carries bytes behind its end)");
+    }
+    size_t checked() const { return checked_; }
+
+   private:
+    [[noreturn]] void bad(const char* what) {
+        throw std::runtime_error(std::string("ORZ_VERIFY=decode: ") + what + " (after " + std::to_string(checked_) + " verified bytes): no stream written");
+    }
+    std::unique_ptr<orz::host::DecodeWorkspace> ws_;
+    std::vector<uint8_t> in_, out_;
+    size_t ipos_ = 0, opos_ = 0, spos_ = orz::kPre, checked_ = 0;
+    bool eof_ = false;
+};
+// a whole stream in memory against its input (host or device resident)
+void verify_stream_decode(const uint8_t* src, size_t n, bool src_on_device, const uint8_t* out, size_t out_len) {
+    std::vector<uint8_t> host;
+    if (src_on_device && n) {
+        host.resize(n);
+        ORZ_HIP_CHECK(hipMemcpy(host.data(), src, n, hipMemcpyDeviceToHost));
+        src = host.data();
+    }
+    DecodeCheck chk;
+    chk.feed_input(src, n);
+    chk.feed_output(out, out_len);
+    chk.finish();
+}
+
 unsigned window_for(const orz::HipBackend& be, const orz_lzcfg& c, unsigned asked) {
     if (asked) return asked;
     const size_t dmax = std::max(c.match_depth, std::max(c.lazy_match_depth1, c.lazy_match_depth2));
@@ -114,6 +197,7 @@ struct orz_lz_encoder {
     size_t next_chunk = 0;
     size_t expect_spos = 0;
     bool first_block = true;
+    bool slid = false;  // forward() was called: the two bytes in front of the device window are history, not sentinel
 };
 
 extern "C" {
@@ -243,6 +327,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             (void)hipGetLastError();  // (registration refused: pageable copies, synchronised per block)
         }
         orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out, pinned);
+        if (verify_decode_on()) verify_stream_decode((const uint8_t*)src, n, src_on_device != 0, out.data(), out.size());
         ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
         be.sync();
         float total = 0;
@@ -330,6 +415,7 @@ int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_dev
         std::atomic<size_t> next{0};
         std::atomic<int> rc{ORZ_OK};
         std::string err;
+        const bool verify = verify_decode_on();
         auto work = [&](orz_stream* s) {
             try {
                 ORZ_HIP_CHECK(hipSetDevice(s->be->device()));  // every host thread talks to its worker's device
@@ -338,6 +424,7 @@ int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_dev
                     if (i >= nm || rc.load() != ORZ_OK) return;
                     const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
                     orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
+                    if (verify) verify_stream_decode((const uint8_t*)src + off, len, src_on_device != 0, outs[i].data(), outs[i].size());
                 }
             } catch (const std::exception& e) {
                 int expect = ORZ_OK;
@@ -500,8 +587,13 @@ int orz_lz_encoder_encode(orz_lz_encoder* e, const orz_lzcfg* cfg, const uint8_t
         const bool continuing = e->next_chunk < e->chunk_end_spos.size() && spos == e->expect_spos;
         if (!continuing) {
             if (spos != orz::kPre) return fail(ORZ_EINVAL, "a block must start at SBVEC_PREMATCH_LEN");
-            // upload the caller's window exactly as it is, sentinel pads included (src/lib.rs:67-69)
-            e->be->h2d(e->enc->dwinbuf(), sbuf - orz::kSent, (size_t)sbuf_len + 2 * orz::kSent);
+            // upload the caller's window exactly as it is, sentinel pads included (src/lib.rs:67-69) -- except, after a
+            // forward(), the pad in FRONT of the window: the caller's copy_within (src/lib.rs:83) leaves the sentinel's zeros
+            // there, but the context of the item start at window offset 1 (hash1 of offset 0, src/lz.rs:482-486) looks at the
+            // byte before the window, and this encoder rebuilds its tables from the window's bytes -- slide(false) kept the
+            // two real bytes on the device, and the upload must not wipe them (round 3's slide defect, at this seam)
+            if (e->slid) e->be->h2d(e->enc->dwin(), sbuf, (size_t)sbuf_len + orz::kSent);
+            else e->be->h2d(e->enc->dwinbuf(), sbuf - orz::kSent, (size_t)sbuf_len + 2 * orz::kSent);
             e->framed.clear();
             e->chunk_end_spos.clear();
             e->enc->encode_block((uint32_t)(sbuf_len - orz::kPre), e->framed, &e->chunk_end_spos);
@@ -533,6 +625,7 @@ int orz_lz_encoder_forward(orz_lz_encoder* e, size_t forward_len) {
     if (forward_len != orz::kNewMax) return fail(ORZ_EINVAL, "forward_len must be 2^24");
     try {
         e->enc->slide(false);  // the caller re-supplies the slid window on the next encode()
+        e->slid = true;
         e->chunk_end_spos.clear();
         e->next_chunk = 0;
         return ORZ_OK;
@@ -641,6 +734,7 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
         std::vector<uint8_t> out;
         size_t in_total = 0, out_total = 0;
         bool first = true;
+        std::unique_ptr<DecodeCheck> chk(verify_decode_on() ? new DecodeCheck : nullptr);  // (verifies a block's bytes before the sink sees them)
         for (;;) {
             // read_repeatedly, src/lib.rs:42-52: fill the block or hit EOF
             size_t got = 0;
@@ -654,8 +748,10 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
             if (!first) enc.slide();
             first = false;
             be.h2d_pinned(enc.dwin() + orz::kPre, in.data(), got);  // encode_block syncs before `in` is refilled
+            if (chk) chk->feed_input(in.data(), got);
             out.clear();
             enc.encode_block_units((uint32_t)got, in_total == 0 && got == in.size(), out);
+            if (chk && !out.empty()) chk->feed_output(out.data(), out.size());
             if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) { rc = fail(ORZ_EIO, "write failed"); break; }
             in_total += got;
             out_total += out.size();
@@ -665,6 +761,12 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
         if (rc == ORZ_OK) {  // the last block's tail stage is still in flight: take its bytes
             out.clear();
             enc.finish(out);
+            if (chk) {
+                const uint8_t z = 0;
+                if (!out.empty()) chk->feed_output(out.data(), out.size());
+                chk->feed_output(&z, 1);
+                chk->finish();
+            }
             if (!out.empty() && wr(wctx, out.data(), out.size()) != 0) rc = fail(ORZ_EIO, "write failed");
             out_total += out.size();
         }

@@ -6,6 +6,8 @@
 //   encode --member-size BYTES [--jobs J]: cut the input into independent members (complete orz streams,
 //   concatenated) and encode J of them concurrently on the GPU;  decode --members: decode every stream of
 //   such a concatenation (the reference, and the default here, stop after the first stream);
+//   encode --verify: every block's bytes go through the library's own decoder and must reproduce the input before they are
+//   written (ORZ_VERIFY=decode); a failed check fails the encode;
 //   decode --members --gpu [--device N]: decode the members on the GPU, one member per wavefront.
 // Progress lines mirror SimpleProgressLogger (src/progress.rs:48-98) on stderr.
 #include <cerrno>
@@ -49,7 +51,7 @@ int usage() {
     fprintf(stderr,
             "an optimized ROLZ data compressor (MI355X encoder)\n\nUsage: orz <COMMAND>\n\nCommands:\n"
             "  encode  Encode   [-s|--silent] [-l|--level <0..2>] [--mode fast|exact] [--backend hip] [--device N]\n"
-            "                   [--member-size BYTES [--jobs J] [--gpus N]] [source] [target]\n"
+            "                   [--member-size BYTES [--jobs J] [--gpus N]] [--verify] [source] [target]\n"
             "  decode  Decode   [-s|--silent] [source] [target]\n");
     return 2;
 }
@@ -84,6 +86,7 @@ int main(int argc, char** argv) {
             if (v != "fast" && v != "exact") return usage();
             setenv("ORZ_MODE", v.c_str(), 1);  // (read by the library when an encoder is created)
         }
+        else if (cmd == "encode" && a == "--verify") setenv("ORZ_VERIFY", "decode", 1);  // round trip through the library's own decoder
         else if (cmd == "decode" && a == "--members") all_members = true;
         else if (cmd == "decode" && a == "--gpu") gpu_decode = true;
         else if (cmd == "decode" && a == "--device") { if (++i >= argc) return usage(); device = strtol(argv[i], nullptr, 10); }

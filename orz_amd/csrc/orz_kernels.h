@@ -122,6 +122,11 @@ struct ItemSyms {
             uint32_t m = LMV[p] > kMinLen ? LMV[p] : kMinLen;
             uint32_t e = ML[q] > kMinLen ? ML[q] : kMinLen;
             uint32_t enc = L > e ? L - m : (L < e ? L - m + 1 : 0);
+            // (a ring distance beyond the ring or a length below len_min cannot be coded: only a defective parse gets here, the
+            // validity gate -- orz_verify.h -- reports it and fails the encode; the clamps keep the table indices of the later
+            // kernels inside their tables until then)
+            if (ro > kRing - 1) ro = kRing - 1;
+            if (enc > kLenSyms - 1) enc = kLenSyms - 1;
             uint32_t roid, bl, bits;
             roid_encode(ro, &roid, &bl, &bits);
             uint32_t lenid = enc < 5 ? enc : 5;

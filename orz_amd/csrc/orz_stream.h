@@ -20,11 +20,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "orz_fast.h"
 #include "orz_kernels.h"
 #include "orz_parse.h"
+#include "orz_verify.h"
 
 namespace orz {
 
@@ -286,6 +288,17 @@ class StreamEncoder {
             if (const char* u = getenv("ORZ_FAST_LEADUNIT")) lead_unit_ = (uint32_t)atoi(u);
             if (lead_unit_ && (lead_unit_ < (1u << 20) || lead_unit_ > kNewMax || lead_unit_ % kSub)) throw std::runtime_error("ORZ_FAST_LEADUNIT must be 0 or a multiple of 4096 in [1 MiB, 16 MiB]");
         }
+        if (const char* inj = getenv("ORZ_VERIFY_INJECT")) {  // (tests of the validity gate) "<class>:<n>"
+            static const char* names[] = {"", "hole", "context", "ring", "lenmin", "word", "bytes"};
+            const std::string v(inj);
+            const size_t colon = v.find(':');
+            const std::string cls = v.substr(0, colon);
+            for (uint32_t k = 1; k < 7; k++)
+                if (cls == names[k]) inject_kind_ = k;
+            if (!inject_kind_) throw std::runtime_error("ORZ_VERIFY_INJECT: unknown class");
+            inject_nth_ = colon == std::string::npos ? 0 : (uint32_t)strtoul(v.c_str() + colon + 1, nullptr, 10);
+        }
+        if (const char* oi = getenv("ORZ_OUTPUT_INJECT")) out_inject_ = (size_t)strtoull(oi, nullptr, 10);  // (tests) a flipped bit behind the gate
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
         try {
@@ -395,9 +408,15 @@ class StreamEncoder {
                 t.hc = take<uint16_t>((size_t)kMaxChunks * kHwStride);
                 t.hdrbits = take<uint32_t>(kMaxChunks);
                 t.tot = take<uint32_t>(kMaxChunks);
-                t.srflags = take<uint32_t>(4);
+                t.srflags = take<uint32_t>(4 + kVeCount);  // (+ the gate's findings of the block: read with the flags in one copy)
                 t.out = take<uint32_t>((size_t)kMaxChunks * kChunkCapWords, false);
             }
+            // the validity gate's own decoder state (orz_verify.h)
+            vrec_ = take<uint32_t>(kWLen);
+            vord_ = take<uint32_t>(kWLen, false);
+            vctx_ = take<uint32_t>(256);
+            vlast_ = take<uint32_t>(2);
+            vwords_ = take<uint8_t>(65536);
             counts_ = take<uint32_t>(kSyms + 3);
             order_ = take<uint16_t>(kSyms + 3);
             ncounted_ = take<uint32_t>(4);
@@ -428,6 +447,9 @@ class StreamEncoder {
         be_.memset(LENMIN_, 0, kWLen);
         be_.memset(ctxcount_, 0, 256 * 4);
         be_.memset(wsnap_, 0, 65536);
+        be_.memset(vrec_, 0, (size_t)kPre * 4);  // (no item starts in the history of a new stream)
+        be_.memset(vwords_, 0, 65536);
+        be_.launch(256, VerReset{vctx_, vlast_});
         be_.select(1); be_.sync(); be_.select(2); be_.sync(); be_.select(3); be_.sync(); be_.select(0);
         for (TailSet& t : ts_) t.pending = false;
         pend_order_.clear();
@@ -926,6 +948,7 @@ class StreamEncoder {
             nitems = two[0];
             hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by)
         }
+        if (inject_kind_) be_.launch(1, VerInjectK{inject_kind_, inject_nth_, t.ipos, nitems, TY_, ML_, SRC_, ORD_, win, S_});  // (tests of the gate)
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
         const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
@@ -980,6 +1003,29 @@ class StreamEncoder {
         be_.launch(nchunks, ChunkTotals{t.bscan, t.blen, t.hdrbits, nitems, nchunks, t.tot});
         be_.record(kEvTail + b);  // this block's bytes are ready
         be_.select(0);
+        // ---- the validity gate (orz_verify.h): the items as they will be coded against the decoder's rules, with state of its
+        // own; on the main stream BEHIND the hand-over to the ranking chain (it only reads the items), its findings are read
+        // with the block's output and fail the encode before a byte of the block is handed out
+        uint32_t* verr = t.srflags + 4;
+        if (gate_on()) {
+            VerArgs v;
+            v.win = win; v.ipos = t.ipos; v.isym = t.isym; v.ictx = t.ictx; v.irob = t.irob; v.iunl = t.iunl; v.ienc = t.ienc; v.ial = t.ial;
+            v.nitems = nitems; v.end = len; v.ML = ML_; v.LMV = LMV_; v.SRC = SRC_; v.ORD = ORD_; v.sperm = t.sperm; v.rstart = t.rstart;
+            v.vrec = vrec_; v.vord = vord_; v.vctx = vctx_; v.vlast = vlast_; v.vwords = vwords_; v.err = verr;
+            be_.launch(kVeCount, VerInit{verr});
+            be_.memset(vrec_ + kPre, 0, (size_t)n * 4);
+            be_.launch(nitems, VerItems{v});
+            be_.launch(nitems, VerOrdinals{v});
+            be_.launch(nitems, VerMatches{v});
+            be_.launch(nitems, VerWordEvents{v, entA_});
+            const uint64_t* evs = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits - 9);  // 15 key bits + 25 position bits + the sentinel's bit
+            be_.launch(nitems, VerWords{v, evs});
+            be_.launch(nitems, VerWordsCarry{v, evs});
+            be_.launch(256, VerCarry{v});
+        } else {
+            be_.launch(kVeCount, VerInit{verr});
+        }
+        be_.record(kEvGate + b);
         t.pending = true;
         t.nitems = nitems; t.nchunks = nchunks; t.len = len; t.block = (uint32_t)stats.blocks;
         pend_order_.push_back(b);
@@ -1012,11 +1058,13 @@ class StreamEncoder {
         const int set = (int)(&t - ts_);
         if (getenv("ORZ_COPY_STREAM") && atoi(getenv("ORZ_COPY_STREAM")) == 0) be_.select(2);  // (experiments)
         else { be_.select(3); be_.wait(kEvTail + set); }
+        be_.wait(kEvGate + set);
         std::vector<uint32_t> tot(nchunks);
         be_.d2h(tot.data(), t.tot, nchunks * 4);
         {   // the guard of the block's symbol ranking (backend symrank): repeated? still impossible ranks?
-            uint32_t f[3] = {0, 0, 0};
-            be_.d2h(f, t.srflags, 12);
+            uint32_t f[4 + kVeCount];
+            be_.d2h(f, t.srflags, sizeof f);
+            report_gate(f + 4, t.block);
             if (f[2]) fprintf(stderr, "orz: two runs of the symbol ranking of block %u from the same tables differ in %u ranks\n", t.block, f[2]);
             if (f[0]) {
                 stats.rank_redos++;
@@ -1033,6 +1081,7 @@ class StreamEncoder {
             size_t at = out.size();
             out.resize(at + tb);
             be_.d2h(out.data() + at, t.out + (uint64_t)i * kChunkCapWords, tb);
+            if (out_inject_ && t.block == 0 && i == 0 && out_inject_ < tb) out.data()[at + out_inject_] ^= 1;  // (tests of ORZ_VERIFY=decode)
             if (chunk_ends) {  // end_spos of the chunk, src/lz.rs:268
                 uint32_t i1 = (i + 1) << 20, e = len;
                 if (i1 < nitems) be_.d2h(&e, t.ipos + i1, 4);
@@ -1074,10 +1123,28 @@ class StreamEncoder {
         collect(out, nullptr);
         if (fast_ && stats.blocks && verify_mode() == 2) report_verify("stream");
     }
-    static int verify_mode() {
-        static const int m = getenv("ORZ_FAST_VERIFY") ? atoi(getenv("ORZ_FAST_VERIFY")) : 2;
+    static int verify_mode() {  // FastVerify (diagnostics of the fast parse; the gate below is what guards the output)
+        static const int m = getenv("ORZ_FAST_VERIFY") ? atoi(getenv("ORZ_FAST_VERIFY")) : 0;
         return m;
     }
+    // the validity gate: on unless ORZ_VERIFY=0 (measurements of its cost)
+    static bool gate_on() {
+        static const bool on = !(getenv("ORZ_VERIFY") && !strcmp(getenv("ORZ_VERIFY"), "0"));
+        return on;
+    }
+    void report_gate(const uint32_t* e, uint32_t block) {
+        uint32_t any = 0;
+        for (uint32_t c = 0; c < kVeFirst; c++) any |= e[c];
+        if (!any) return;
+        std::string msg = "validity gate, block " + std::to_string(block) + ": the items do not decode:";
+        for (uint32_t c = 0; c < kVeFirst; c++)
+            if (e[c]) msg += " " + std::to_string(e[c]) + " x " + ver_name(c) + ";";
+        msg += " first at window offset " + std::to_string(e[kVeFirst] - 1) + " -- no stream written";
+        fprintf(stderr, "orz: %s\n", msg.c_str());
+        throw std::runtime_error(msg);
+    }
+    // (tests) damage the n-th suitable item of every block after the parse: "hole", "context", "ring", "lenmin", "word", "bytes"
+    void set_inject(uint32_t kind, uint32_t nth) { inject_kind_ = kind; inject_nth_ = nth; }
     void report_verify(const char* what) {
         unsigned long long h6[6];
         be_.d2h(h6, (unsigned long long*)fgsum_ + 8192 + 32, sizeof h6);
@@ -1111,6 +1178,8 @@ class StreamEncoder {
             be_.launch(sh, SlideArray<uint8_t>{ML_, off, sh, kPre});
             be_.launch(sh, SlideArray<uint32_t>{ORD_, off, sh, kPre});
             be_.launch(sh, SlideArray<uint8_t>{LENMIN_, off, sh, kPre});
+            be_.launch(sh, SlideArray<uint32_t>{vrec_, off, sh, kPre});
+            be_.launch(sh, SlideArray<uint32_t>{vord_, off, sh, kPre});
         }
         // (no synchronisation: whatever fills the window next is queued on this stream behind the slide)
     }
@@ -1195,7 +1264,7 @@ class StreamEncoder {
         bool pending = false;
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
-    static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4;  // event numbers (+ set index)
+    static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4, kEvGate = 6;  // event numbers (+ set index)
     struct MainStreamGuard {  // whatever happens while a side stream is selected, the backend goes back to the main one
         BE& be;
         ~MainStreamGuard() { be.select(0); }
@@ -1230,6 +1299,10 @@ class StreamEncoder {
     uint16_t* order_;
     uint32_t* ncounted_;
     uint16_t* srstate_;
+    uint32_t *vrec_ = nullptr, *vord_ = nullptr, *vctx_ = nullptr, *vlast_ = nullptr;  // the gate's decoder state (orz_verify.h)
+    uint8_t* vwords_ = nullptr;
+    uint32_t inject_kind_ = 0, inject_nth_ = 0;
+    size_t out_inject_ = 0;  // byte of the stream's first chunk whose lowest bit is flipped on its way out (0 = none)
     uint16_t* srbackup_ = nullptr;  // the tables before the running block's ranking (the guard's second run starts from them)
     uint64_t* outoff_;
 };

@@ -158,3 +158,18 @@ def diag(stream, expect):
     if kind == 0:
         return {}
     return {k: (list(getattr(d, k)) if k.startswith("near_") or k == "tab_near" else int(getattr(d, k))) for k, _ in Diag._fields_}
+
+
+def assert_decodes_to(stream, expect, what="stream"):
+    """the oracle's decoder must turn `stream` into `expect`; on failure the assertion names the first item no decoder
+    follows (forensic decode, oracle/orz_diag.c)"""
+    stream, expect = bytes(stream), bytes(expect)
+    try:
+        back, used = decode(stream)
+        ok = back == expect and used == len(stream)
+    except ValueError:
+        ok = False
+    if not ok:
+        d = diag(stream, expect)
+        raise AssertionError("%s (%d bytes) does not decode to its input (%d bytes); first wrong item: %r" % (
+            what, len(stream), len(expect), {k: v for k, v in d.items() if not k.startswith("near_") and k != "tab_near"}))

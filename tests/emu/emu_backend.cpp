@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
 
 #include "../../orz_amd/csrc/orz_decode_device.h"
 #include "../../orz_amd/csrc/orz_stream.h"
@@ -168,6 +169,8 @@ extern "C" int emu_encode(const uint8_t* src, size_t n, int depth, int lazy1, in
         return -1;
     }
 }
+static std::string g_emu_err;
+extern "C" const char* emu_last_error() { return g_emu_err.c_str(); }  // message of the last emu_encode_fast that returned -1
 // the fast parse mode (orz_fast.h) on the emulation backend
 extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, unsigned tile, unsigned rounds,
                                uint8_t** dst, size_t* dst_len, unsigned long long* stats5) {
@@ -192,7 +195,8 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
                          orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2], orz::g_far_stats[3]);
         return 0;
     } catch (const std::exception& e) {
-        std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
+        g_emu_err = e.what();
+        if (!std::getenv("ORZ_VERIFY_INJECT")) std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
         return -1;
     }
 }
@@ -290,5 +294,41 @@ extern "C" int emu_decode_members(const uint8_t* src, size_t n, unsigned slots, 
     } catch (const std::exception& e) {
         if (err && cap) { std::strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
         return 1;
+    }
+}
+
+// The object-level seam (orz_lz_encoder_encode / _forward, orz_capi.hip) on the emulation: the caller keeps the window, slides
+// it with copy_within (src/lib.rs:83: the pad in front of the window keeps its zeros) and hands it over for every block;
+// `keep_front` = the upload after a forward() starts at window offset 0 (what the library does) instead of at the pad.
+extern "C" int emu_encode_fast_seam(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, int keep_front, uint8_t** dst, size_t* dst_len) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        std::vector<uint8_t> window((size_t)orz::kBlock + 2 * orz::kSent, 0), out;
+        uint8_t* sbuf = window.data() + orz::kSent;
+        bool slid = false;
+        for (size_t off = 0; off < n;) {
+            const size_t take = std::min<size_t>(orz::kNewMax, n - off);
+            std::memcpy(sbuf + orz::kPre, src + off, take);
+            const size_t sbuf_len = orz::kPre + take;
+            if (slid && keep_front) be.h2d(enc.dwin(), sbuf, sbuf_len + orz::kSent);
+            else be.h2d(enc.dwinbuf(), sbuf - orz::kSent, sbuf_len + 2 * orz::kSent);
+            std::vector<size_t> ends;
+            enc.encode_block((uint32_t)take, out, &ends);
+            off += take;
+            std::memmove(sbuf, sbuf + (orz::kBlock - orz::kPre), orz::kPre);
+            enc.slide(false);
+            slid = true;
+        }
+        out.push_back(0);
+        *dst = (uint8_t*)std::malloc(out.size());
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_emu_err = e.what();
+        std::fprintf(stderr, "emu_encode_fast_seam: %s\n", e.what());
+        return -1;
     }
 }

@@ -351,3 +351,43 @@ def test_member_whose_oldest_history_position_changes_context(oracle):
         enc.close()
     back, used = oracle.decode(out)
     assert used == len(out) and back == data
+
+
+def test_object_level_seam_keeps_the_bytes_before_the_window(oracle):
+    """The same two blocks through LZEncoder::encode / forward (src/lib.rs:72-84) in the fast mode: the caller's copy_within
+    leaves the front sentinel's zeros before the window, the device must keep the two real bytes all the same (the context of
+    window offset 1 reads the byte before the window; ADVICE round 3: the upload of the seam wiped them)."""
+    import ctypes
+
+    import corpus
+    import orz_amd
+
+    P, B, SENT = orz_amd.SBVEC_PREMATCH_LEN, orz_amd.LZ_BLOCK_SIZE, orz_amd.SBVEC_SENTINEL_LEN
+    base = corpus.enwik_like(100_000_000)
+    off0 = (7 * 7_919_113) % (len(base) - 1)
+    data = bytes((base[off0:] + base[:off0])[: 2 << 24])
+    cfg = orz_amd.cfg_for_level(1)
+    window = (ctypes.c_uint8 * (B + 2 * SENT))()
+    enc = orz_amd.LZEncoder(device=0)
+    stream = bytearray()
+    off = 0
+    try:
+        while off < len(data):
+            take = min(B - P, len(data) - off)
+            ctypes.memmove(ctypes.addressof(window) + SENT + P, data[off:off + take], take)
+            spos, sbuf_len = P, P + take
+            while spos < sbuf_len:
+                spos, chunk = enc.encode(cfg, window, sbuf_len, spos)
+                t = len(chunk)
+                while t >= 128:
+                    stream.append(128 + t % 128)
+                    t //= 128
+                stream.append(t)
+                stream += chunk
+            off += take
+            ctypes.memmove(ctypes.addressof(window) + SENT, ctypes.addressof(window) + SENT + (B - P), P)
+            enc.forward(B - P)
+    finally:
+        enc.close()
+    stream.append(0)
+    oracle.assert_decodes_to(stream, data, "the object-level encoder's stream")
