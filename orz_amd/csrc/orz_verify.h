@@ -245,15 +245,17 @@ struct VerInjectK {
                 while (q2 < p && !S[q2]) q2++;
                 if (q2 < p && hash1(win, q2 - 1) != hash1(win, p - 1) && seen++ == nth) { SRC[p] = q2; return; }
             } else if (kind == kViRing && ty == kTyMatch) {         // a source more than a ring's length of item starts back in the same context
+                if (ORD[SRC[p]] < 2 * kRing) continue;  // (a context with enough history: the walk below is bounded all the same)
                 const uint32_t c = hash1(win, p - 1);
-                uint32_t q2 = SRC[p], passed = 0;
-                while (q2 > 1 && passed < kRing + 4) { q2--; if (S[q2] && hash1(win, q2 - 1) == c) passed++; }
+                uint32_t q2 = SRC[p], passed = 0, steps = 0;
+                while (q2 > 1 && passed < kRing + 4 && steps++ < (1u << 22)) { q2--; if (S[q2] && hash1(win, q2 - 1) == c) passed++; }
                 if (passed == kRing + 4 && seen++ == nth) { SRC[p] = q2; return; }
-            } else if (kind == kViLenMin && ty == kTyMatch && ML[p] >= 6) {  // an earlier reference of the same source that is as long: find two
-                for (uint32_t k2 = k + 1; k2 + 1 < nitems && k2 < k + 200000; k2++) {
+            } else if (kind == kViLenMin && ty == kTyMatch && ML[p] >= 6) {  // the next match of the same ring that is no longer is given the same source:
+                const uint32_t c = hash1(win, p - 1);                       // the source's len_min (ML[p] + 1 by then) is above its length
+                for (uint32_t k2 = k + 1; k2 + 1 < nitems && k2 < k + 4000; k2++) {
                     const uint32_t p2 = ipos[k2];
-                    if ((TY[p2] & 3) == kTyMatch && SRC[p2] == SRC[p] && ML[p2] > ML[p]) {
-                        if (seen++ == nth) { ML[p2] = ML[p]; return; }  // now L2 == L1 < len_min = L1 + 1 (and the sequence has a hole, too)
+                    if ((TY[p2] & 3) == kTyMatch && ML[p2] <= ML[p] && hash1(win, p2 - 1) == c && SRC[p2] != SRC[p]) {
+                        if (seen++ == nth) { SRC[p2] = SRC[p]; return; }
                         break;
                     }
                 }
