@@ -299,7 +299,10 @@ def huffman_tables(weights, device=0):
     import numpy as np
 
     lib = _native.load()
-    w = np.ascontiguousarray(weights, dtype=np.uint32)
+    w0 = np.asarray(weights)
+    if w0.size and (not np.issubdtype(w0.dtype, np.integer) or (w0 < 0).any() or (w0 >= (1 << 23)).any()):
+        raise ValueError("weights must be integers in [0, 2^23)")  # (before the cast: a negative or huge weight must not wrap into range)
+    w = np.ascontiguousarray(w0, dtype=np.uint32)
     stride = lib.orz_huffman_stride()
     if w.ndim != 2 or w.shape[1] != stride:
         raise ValueError("weights must have shape [nchunks, %d]" % stride)

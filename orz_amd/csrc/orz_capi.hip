@@ -165,8 +165,20 @@ struct orz_stream {
     // that throws -- bad tile size, failed allocation -- leaves the handle as it was); callers that change settings go
     // through `reconfigure`, which also restores them.
     void rebuild() {
-        be->clear_graphs();
-        std::unique_ptr<Enc> fresh(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
+        std::unique_ptr<Enc> fresh;
+        try {
+            fresh.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
+        } catch (const std::exception&) {
+            // a stream's state is ~5 GB: two of them may not fit a loaded device where one does.  Was the failure a bad
+            // setting, the second attempt fails the same way and the handle has no encoder left (every call on it reports
+            // that); was it memory, dropping the old encoder first makes room.
+            if (!enc) throw;
+            (void)hipGetLastError();
+            enc.reset();
+            be->clear_graphs();
+            fresh.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
+        }
+        be->clear_graphs();  // (captured launches hold the old encoder's buffer addresses)
         enc = std::move(fresh);
         enc->trace = tracing ? &trace : nullptr;
     }
@@ -180,6 +192,9 @@ struct orz_stream {
             rebuild();
         } catch (...) {
             seg = seg0; win = win0; ftile = ftile0; frounds = frounds0; fast = fast0;
+            if (!enc) {  // (the old encoder was dropped to make room: bring it back with the old settings)
+                try { rebuild(); } catch (...) {}
+            }
             throw;
         }
     }
@@ -288,6 +303,7 @@ int orz_stream_get_kernel_times(orz_stream* s, double* ms4, uint64_t* launches4)
 }
 int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
     if (!s || !out) return fail(ORZ_EINVAL, "null argument");
+    if (!s->enc) return fail(ORZ_ENOMEM, "the stream has no encoder (a reconfiguration ran out of device memory)");
     out->mode = s->enc->fast() ? ORZ_MODE_FAST : ORZ_MODE_EXACT;
     out->segment_bytes = s->enc->seg_size();
     out->window_segments = s->enc->window_segs();
@@ -300,6 +316,7 @@ int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
 int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
                       orz_encode_stats* stats) {
     if (!s || !dst || !dst_len || (!src && n)) return fail(ORZ_EINVAL, "null argument");
+    if (!s->enc) return fail(ORZ_ENOMEM, "the stream has no encoder (a reconfiguration ran out of device memory)");
     try {
         orz::ByteBuf out;
         out.reserve(n / 3 + 4096);
@@ -352,7 +369,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
 }
 
 int orz_stream_set_item_trace(orz_stream* s, int on) {
-    if (!s) return fail(ORZ_EINVAL, "null stream");
+    if (!s || !s->enc) return fail(ORZ_EINVAL, "null stream");
     s->tracing = on != 0;
     s->enc->trace = s->tracing ? &s->trace : nullptr;
     if (!on) s->trace.clear();
@@ -422,6 +439,7 @@ int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_dev
                 for (;;) {
                     const size_t i = next.fetch_add(1);
                     if (i >= nm || rc.load() != ORZ_OK) return;
+                    if (!s->enc) throw std::runtime_error("a worker has no encoder (a reconfiguration ran out of device memory)");
                     const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
                     orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
                     if (verify) verify_stream_decode((const uint8_t*)src + off, len, src_on_device != 0, outs[i].data(), outs[i].size());
@@ -530,18 +548,19 @@ int orz_huffman_tables(int device, const uint32_t* weights, size_t nchunks, uint
         be.h2d(b.w, weights, n * 4);
         const orz::HuffBuild f{b.w, (uint32_t)nchunks, b.l, b.c};
         be.huffbuild(f);  // (warm: code object load)
-        hipEvent_t e0, e1;
-        ORZ_HIP_CHECK(hipEventCreate(&e0));
-        ORZ_HIP_CHECK(hipEventCreate(&e1));
-        ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
+        struct Events {  // destroyed on every path out
+            hipEvent_t a = nullptr, b = nullptr;
+            ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+        } ev;
+        ORZ_HIP_CHECK(hipEventCreate(&ev.a));
+        ORZ_HIP_CHECK(hipEventCreate(&ev.b));
+        ORZ_HIP_CHECK(hipEventRecord(ev.a, be.stream()));
         be.huffbuild(f);
-        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
+        ORZ_HIP_CHECK(hipEventRecord(ev.b, be.stream()));
         be.d2h(lens, b.l, n);
         be.d2h(codes, b.c, n * 2);
         float ms = 0;
-        ORZ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        ORZ_HIP_CHECK(hipEventElapsedTime(&ms, ev.a, ev.b));
         if (elapsed_us) *elapsed_us = (double)ms * 1000.0;
         return ORZ_OK;
     } catch (const std::exception& e) {

@@ -109,35 +109,47 @@ ORZ_D void atom_xor64(uint64_t* p, uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicXor((unsigned long long*)p, (unsigned long long)v);
 #else
-    *p ^= v;
+    __atomic_fetch_xor(p, v, __ATOMIC_RELAXED);
 #endif
 }
 ORZ_D uint64_t atom_fetch_xor64(uint64_t* p, uint64_t v) {  // returns the old word
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint64_t)atomicXor((unsigned long long*)p, (unsigned long long)v);
 #else
-    const uint64_t o = *p;
-    *p = o ^ v;
-    return o;
+    return __atomic_fetch_xor(p, v, __ATOMIC_RELAXED);
 #endif
 }
 ORZ_D uint32_t atom_fetch_add32(uint32_t* p, uint32_t v) {  // returns the old value
 #if defined(__HIP_DEVICE_COMPILE__)
     return atomicAdd(p, v);
 #else
-    const uint32_t o = *p;
-    *p = o + v;
-    return o;
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 #endif
 }
 ORZ_D void atom_sub32(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicSub(p, v);
 #else
-    *p -= v;
+    __atomic_fetch_sub(p, v, __ATOMIC_RELAXED);
 #endif
 }
 
+// Reads and writes that are MEANT to race with other threads of the same launch (the race check of tests/race reports every
+// other one): on the device plain accesses, on the host relaxed atomics.  Each use says why the race is harmless.
+ORZ_D uint64_t racy_load64(const uint64_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *p;
+#else
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+#endif
+}
+ORZ_D void racy_store8(uint8_t* p, uint8_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *p = v;
+#else
+    __atomic_store_n(p, v, __ATOMIC_RELAXED);
+#endif
+}
 ORZ_D int popc64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __popcll((unsigned long long)v);
@@ -581,7 +593,7 @@ struct FastEval {
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
         const uint32_t h4 = hz[0], h4was = hz[2];
         const bool need = p >= r2lo || dirty || scan;
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
         g_eval_stats[0]++;
         if (first) g_eval_stats[2]++; else if (dirty) g_eval_stats[3]++; else if (scan) g_eval_stats[4]++;
 #endif
@@ -596,7 +608,7 @@ struct FastEval {
             moved = o4.sure != d4.sure || o4.limit != d4.limit || d4.sure < fast_min(fast_min(kFastK, rl), d4.limit);
         }
         if (!need && !moved) return;
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
         g_eval_stats[1]++;
 #endif
         // ---- everything the evaluation reads, asked for up front: position-ordered statics, then the two bitmap windows
@@ -683,7 +695,7 @@ struct FastEval {
                             x0[b] = a.stext[2 * (size_t)s2];
                             x1[b] = a.stext[2 * (size_t)s2 + 1];
                         }
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
                         g_far_stats[3]++;
 #endif
 #pragma unroll
@@ -708,7 +720,7 @@ struct FastEval {
                     const uint64_t* top = a.cl + 2 * ((size_t)rs + avail);
                     const uint32_t room = a.depth + a.extra > s ? a.depth + a.extra - s : 0;
                     const uint32_t want = fast_min(room, avail);
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
                     g_far_stats[0]++;
 #endif
                     constexpr uint32_t kB = 8;  // records per trip, all loads of a trip in flight
@@ -726,7 +738,7 @@ struct FastEval {
                             const uint32_t q = rec_pos(x1[b]);
                             uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
                             if (l == kRecText) l += lcp_trips(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
                             g_far_stats[1]++;
                             if (l >= kRecText) g_far_stats[2]++;
 #endif
@@ -751,7 +763,7 @@ struct FastEval {
         if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
         if (km & 0x80) kmask &= ~(1ull << 63);
         const uint32_t lwm = kmask ? (uint32_t)((wm >> (63 - (uint32_t)clz64(kmask))) & 1) : (km >> 8) & 1;
-#if !defined(__HIPCC__)
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
         if ((a.dbg & 32) && p < r2lo && !a.dirty[i] && !moved && !scan) {  // verify mode: would a skipped position have changed?
             const uint32_t o = a.ev[i], nw = best | (m1 << 8) | (m2 << 16) | (lwm << 24) | (b510 << 25);
             if ((o ^ nw) & ~(1u << 25)) {
@@ -1166,7 +1178,9 @@ struct FastFlip {
             uint32_t q[kTrip];
 #pragma unroll
             for (uint32_t b = 0; b < kTrip; b++) q[b] = s + b < end ? pos[s + b] : 0;
-            const uint64_t w0 = bits[s >> 6], w1 = bits[(s + kTrip - 1) >> 6];
+            // (other threads of this launch flip bits of these words: whichever state a walk sees, the union of the marks covers
+            // every position whose answer can have changed -- see the kernel's comment)
+            const uint64_t w0 = racy_load64(&bits[s >> 6]), w1 = racy_load64(&bits[(s + kTrip - 1) >> 6]);
 #pragma unroll
             for (uint32_t b = 0; b < kTrip; b++) {
                 const uint32_t qq = q[b];
@@ -1186,7 +1200,7 @@ struct FastFlip {
             for (uint32_t b = 0; b < kTrip; b++) q[b] = k + b < n ? pos[slot + 1 + k + b] : 0;
 #pragma unroll
             for (uint32_t b = 0; b < kTrip; b++)
-                if (k + b < n && q[b] >= kPre) a.dirty[q[b] - kPre] = 1;
+                if (k + b < n && q[b] >= kPre) racy_store8(&a.dirty[q[b] - kPre], 1);  // (several walks may mark one position: the same value)
         }
     }
     ORZ_HD void operator()(size_t tid) const {
@@ -1577,6 +1591,28 @@ struct FastWordApply {  // thread per position: acts on the flags of the launch 
         a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
     }
 };
+#if defined(ORZ_RACE_SELFTEST)
+// (tests/race only) the one-kernel form of round 3, kept to show that the race check reports it: the thread of i + 1 reads
+// sbits / ty[i + 1] while the thread of i -- another wavefront when i is a wavefront's last lane -- rewrites them
+struct FastWordCheckRacy {
+    FastArgs a;
+    const uint32_t* laste;
+    uint64_t* rdirty;
+    const FastCtl* ctl;
+    ORZ_HD void operator()(size_t i) const {
+        if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
+        const uint32_t p = kPre + (uint32_t)i;
+        const uint32_t w = fast_word_at(a, laste, p);
+        if (w == ((uint32_t)a.win[p] | ((uint32_t)a.win[p + 1] << 8))) return;
+        atom_add32(a.nchg, 1);
+        a.ty[i] = kTyLit; a.nl[i] = 1;
+        a.ty[i + 1] = kTyLit; a.nl[i + 1] = 1;
+        atom_or64(&a.sbits[(i + 1) / 64], 1ull << ((i + 1) & 63));
+        mark_run(a.win, rdirty, p + 1);
+        a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
+    }
+};
+#endif
 // Diagnostics (ORZ_FAST_VERIFY): every match of the frozen parse against first principles -- the source is an item start of
 // the same context, lies inside the ring by the exact ordinals, and its bytes equal the item's -- independent of the
 // tables the source assignment used.  err[0..4] = matches checked, source not an item start, other context, outside the

@@ -20,11 +20,19 @@
 #define ORZ_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define ORZ_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define ORZ_ATOMIC_OR(p, v) atomicOr((p), (v))
-#else  // host emulation runs the threads of a kernel one after another
-template <class T, class U> inline T orz_fetch_add(T* p, U v) { T o = *p; *p = (T)(o + v); return o; }
-template <class T, class U> inline T orz_fetch_min(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class U> inline T orz_fetch_max(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <class T, class U> inline T orz_fetch_or(T* p, U v) { T o = *p; *p = (T)(o | v); return o; }
+#else  // host emulation: real (relaxed) atomics too -- the race check of tests/race runs a launch's threads on several host threads
+template <class T, class U> inline T orz_fetch_add(T* p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T orz_fetch_min(T* p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v < o && !__atomic_compare_exchange_n(p, &o, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+template <class T, class U> inline T orz_fetch_max(T* p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v > o && !__atomic_compare_exchange_n(p, &o, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+template <class T, class U> inline T orz_fetch_or(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
 #define ORZ_ATOMIC_ADD(p, v) orz_fetch_add((p), (v))
 #define ORZ_ATOMIC_MIN(p, v) orz_fetch_min((p), (v))
 #define ORZ_ATOMIC_MAX(p, v) orz_fetch_max((p), (v))

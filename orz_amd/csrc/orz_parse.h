@@ -156,15 +156,19 @@ ORZ_D SlotRec ld_rec(const SlotRec* p) {
 #else
 ORZ_D uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 ORZ_D uint64_t ldu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-ORZ_D void atom_or64(uint64_t* p, uint64_t v) { *p |= v; }
-ORZ_D void atom_and64(uint64_t* p, uint64_t v) { *p &= v; }
-ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
-ORZ_D uint64_t atom_load64(const uint64_t* p) { return *p; }
-ORZ_D void atom_store64(uint64_t* p, uint64_t v) { *p = v; }
+// (real relaxed atomics on the host as well: the race check of tests/race runs a launch's threads on several host threads)
+ORZ_D void atom_or64(uint64_t* p, uint64_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+ORZ_D void atom_and64(uint64_t* p, uint64_t v) { __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+ORZ_D uint64_t atom_load64(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+ORZ_D void atom_store64(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 ORZ_D void spin_pause() {}
-ORZ_D void atom_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
-ORZ_D void atom_add32(uint32_t* p, uint32_t v) { *p += v; }
-ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { *p += v; }
+ORZ_D void atom_min32(uint32_t* p, uint32_t v) {
+    uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+ORZ_D void atom_add32(uint32_t* p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 ORZ_D int clz64(uint64_t v) { return __builtin_clzll(v); }
 ORZ_D int ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ORZ_D SlotRec ld_rec(const SlotRec* p) { return *p; }

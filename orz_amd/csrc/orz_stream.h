@@ -360,7 +360,8 @@ class StreamEncoder {
                 fhz_ = take<uint32_t>((size_t)(kNSub + 2) * 256 * 4);
                 fhcm_ = take<uint32_t>((size_t)kHistSub * 256);
                 fhpre_ = take<uint32_t>((size_t)(kHistSub + 1) * 256);
-                fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256 + 2 * 8192 + 64);
+                fgsum_ = take<uint32_t>((size_t)(kNSub / 64 + 4) * 256);
+                fdiag_ = take<unsigned long long>(64);  // diagnostics counters (a.stats) and FastVerify's findings: an allocation of their own
                 fx0_ = take<uint8_t>(nn);
                 fx1_ = take<uint8_t>((size_t)(kNSub + 2) * kEntries);
                 fx2_ = take<uint8_t>((size_t)(kNewMax / kSub + 4) * kEntries);  // (sized for the finest tile)
@@ -751,7 +752,7 @@ class StreamEncoder {
         a.centry = fcentry_; a.tentry = ftentry_; a.cm = fcm_; a.cp = fcp_; a.nchg = &fctl_->chg; a.nentp = &fctl_->nent;
         be_.launch(1, FastSetNent{fctl_, nent});
         a.dbg = getenv("ORZ_FAST_DBG") ? (uint32_t)atoi(getenv("ORZ_FAST_DBG")) : 0;
-        a.stats = (unsigned long long*)fgsum_ + 8192;  // (diagnostics: the tail of a scratch table)
+        a.stats = fdiag_;
         if (a.dbg & 64) be_.memset(a.stats, 0, 32 * 8);
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
         // anyway), and a block whose parse turns out unstable -- many items lost their source -- is redone with tiles
@@ -881,8 +882,12 @@ class StreamEncoder {
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     be_.launch(nk, KbitVals{kbits_, nk, f32_});
                     be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+#if defined(ORZ_RACE_SELFTEST)
+                    be_.launch(n, FastWordCheckRacy{a, flaste_, rd_out, fctl_});
+#else
                     be_.launch(n, FastWordCheck{a, flaste_, fcut_, fctl_});
                     be_.launch(n, FastWordApply{a, fcut_, rd_out});
+#endif
                     be_.launch(1, FastPassEnd{fctl_});
                 }
                 be_.d2h(&h, fctl_, sizeof h);
@@ -909,7 +914,7 @@ class StreamEncoder {
         // counters stay on the device until the stream ends (no synchronisation) and a finding fails the encode -- no stream
         // is better than one no decoder accepts.  ORZ_FAST_VERIFY=0 off, 1 = read back and reported per block.
         if (const int vmode = verify_mode()) {
-            unsigned long long* e = (unsigned long long*)fgsum_ + 8192 + 32;
+            unsigned long long* e = fdiag_ + 32;
             if (vmode != 2 || stream_start_) be_.memset(e, 0, 6 * 8);
             be_.launch(n, FastVerify{a, SRC_, S_, e});
             if (vmode != 2) report_verify("block");
@@ -1147,7 +1152,7 @@ class StreamEncoder {
     void set_inject(uint32_t kind, uint32_t nth) { inject_kind_ = kind; inject_nth_ = nth; }
     void report_verify(const char* what) {
         unsigned long long h6[6];
-        be_.d2h(h6, (unsigned long long*)fgsum_ + 8192 + 32, sizeof h6);
+        be_.d2h(h6, fdiag_ + 32, sizeof h6);
         if (h6[1] | h6[2] | h6[3] | h6[4]) {
             char msg[320];
             snprintf(msg, sizeof msg, "fast parse verification, %s (%llu blocks so far): of %llu matches %llu have a source that is no item start, %llu one of another context, %llu one outside the ring, %llu one with other bytes (e.g. at window offset %llu)",
@@ -1243,6 +1248,7 @@ class StreamEncoder {
     uint16_t *fkw_ = nullptr, *fkmeta_ = nullptr;
     uint64_t *frdist_ = nullptr, *fwmask_ = nullptr;
     uint32_t *fhz_ = nullptr, *fhcm_ = nullptr, *fhpre_ = nullptr, *fgsum_ = nullptr;
+    unsigned long long* fdiag_ = nullptr;
     uint32_t *fev_ = nullptr, *fcentry_ = nullptr, *ftentry_ = nullptr, *fcm_ = nullptr, *fcp_ = nullptr, *fcut_ = nullptr,
              *flaste_ = nullptr, *fcok_ = nullptr, *ffarv_ = nullptr;
     uint64_t *fsbits_ = nullptr, *fstext_ = nullptr, *frdirty_ = nullptr, *fcl_ = nullptr;

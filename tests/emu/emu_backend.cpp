@@ -14,6 +14,12 @@
 #include "../../orz_amd/csrc/orz_decode_device.h"
 #include "../../orz_amd/csrc/orz_stream.h"
 #include "simt.h"
+#if defined(ORZ_EMU_THREADS)  // the race check (tests/race): a launch's threads / blocks on this many host threads
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#endif
 
 namespace {
 struct EmuBackend {
@@ -58,6 +64,77 @@ struct EmuBackend {
         return 0.0;
     }
     double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#if defined(ORZ_EMU_THREADS)
+    // Race check: wavefront w of a launch (threads 64 w .. 64 w + 63, one after another) runs on host thread w % T, so that any
+    // two threads of different wavefronts are unordered to ThreadSanitizer exactly as they are on the GPU.  A kernel whose
+    // threads read what other threads of the SAME launch write -- other than through the atomics -- is reported, whatever
+    // the timing of this run was.
+    // (a pool, not a thread per launch: a block has thousands of launches and the sanitizer's thread table is finite; the
+    // hand-over through the mutex orders the launches, as a HIP stream does)
+    struct Pool {
+        std::mutex m;
+        std::condition_variable cv, done_cv;
+        std::function<void(unsigned)> job;
+        uint64_t gen = 0;
+        unsigned pending = 0;
+        bool stop = false;
+        std::vector<std::thread> th;
+        Pool() {
+            for (unsigned t = 1; t < ORZ_EMU_THREADS; t++)
+                th.emplace_back([this, t] {
+                    uint64_t seen = 0;
+                    for (;;) {
+                        std::function<void(unsigned)> j;
+                        {
+                            std::unique_lock<std::mutex> lk(m);
+                            cv.wait(lk, [&] { return stop || gen != seen; });
+                            if (stop) return;
+                            seen = gen;
+                            j = job;
+                        }
+                        j(t);
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) done_cv.notify_all();
+                    }
+                });
+        }
+        ~Pool() {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            cv.notify_all();
+            for (auto& x : th) x.join();
+        }
+        void run(const std::function<void(unsigned)>& body) {
+            { std::lock_guard<std::mutex> lk(m); job = body; pending = ORZ_EMU_THREADS - 1; gen++; }
+            cv.notify_all();
+            body(0u);
+            std::unique_lock<std::mutex> lk(m);
+            done_cv.wait(lk, [&] { return pending == 0; });
+        }
+    };
+    template <class Body> static void on_threads(const Body& body) {
+        static Pool pool;
+        pool.run(body);
+    }
+    template <class F> void launch(size_t n, const F& f) {
+        const size_t nw = (n + 63) / 64;
+        if (nw < 2) { for (size_t i = 0; i < n; i++) f(i); return; }
+        on_threads([&](unsigned t) {
+            for (size_t w = t; w < nw; w += ORZ_EMU_THREADS)
+                for (size_t i = w * 64; i < n && i < (w + 1) * 64; i++) f(i);
+        });
+    }
+    template <class K> void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
+        const uint64_t sd = seed++;
+        if (nblocks < 2) { simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, sd); return; }
+        on_threads([&](unsigned t) { simt::launch_waves(nblocks, k, lds_bytes, (simt::Order)order, sd, t, ORZ_EMU_THREADS); });
+    }
+    template <class K> void launch_group(const K& k) {
+        const size_t lds = k.lds_bytes();
+        std::vector<uint8_t> mem(lds + 64);
+        for (uint32_t ph = 0; ph < K::kPhases; ph++)
+            on_threads([&](unsigned t) { for (uint32_t x = t; x < 1024; x += ORZ_EMU_THREADS) k.phase(ph, x, 1024, mem.data(), lds != 0); });
+    }
+#else
     template <class F> void launch(size_t n, const F& f) {
         for (size_t i = 0; i < n; i++) f(i);
     }
@@ -70,6 +147,7 @@ struct EmuBackend {
         for (uint32_t ph = 0; ph < K::kPhases; ph++)
             for (uint32_t t = 0; t < 1024; t++) k.phase(ph, t, 1024, mem.data(), lds != 0);
     }
+#endif
     void huffbuild(const orz::HuffBuild& f) { if (f.nchunks) launch_waves((size_t)f.nchunks * 3, orz::HuffWave{f}, orz::HuffWave::lds_bytes()); }
     void rank(const orz::RankArgs& a, uint32_t nchunks) {
         // one block per chunk, 256 threads around one barrier: run each block as two thread loops

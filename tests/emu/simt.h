@@ -16,6 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#if defined(__SANITIZE_THREAD__)  // the race check (tests/race): the lanes' coroutines are fibers to ThreadSanitizer
+#include <sanitizer/tsan_interface.h>
+#define ORZ_SIMT_TSAN 1
+#endif
 
 extern "C" void orz_simt_switch(void** save_sp, void* new_sp);
 asm(R"(
@@ -48,6 +52,7 @@ constexpr size_t kStack = 256 * 1024;
 
 struct Wave;
 struct Lane {
+    void* fiber = nullptr;
     void* sp = nullptr;
     bool done = true;
     uint32_t gen = 0;  // collectives this lane has entered
@@ -65,10 +70,14 @@ struct Wave {
     void* entry_arg = nullptr;
     std::vector<uint8_t> lds;
     uint32_t block = 0;
+    void* sched_fiber = nullptr;
 
     Wave() {
         stacks = (uint8_t*)std::malloc(kStack * kLanes);
         std::memset(tag, 0xff, sizeof tag);
+#if defined(ORZ_SIMT_TSAN)
+        for (int i = 0; i < kLanes; i++) lanes[i].fiber = __tsan_create_fiber(0);
+#endif
     }
     ~Wave() { std::free(stacks); }
 };
@@ -84,6 +93,9 @@ inline void lane_trampoline() {
     w->entry(w->entry_arg);
     w->lanes[me].done = true;
     void* dummy;
+#if defined(ORZ_SIMT_TSAN)
+    __tsan_switch_to_fiber(w->sched_fiber, 0);
+#endif
     orz_simt_switch(&dummy, w->sched_sp);  // never returns
     std::abort();
 }
@@ -96,7 +108,12 @@ struct WaveCtx {
     uint32_t block() const { return w->block; }
     uint8_t* lds() const { return w->lds.data(); }
 
-    void park() { orz_simt_switch(&w->lanes[lane_].sp, w->sched_sp); }
+    void park() {
+#if defined(ORZ_SIMT_TSAN)
+        __tsan_switch_to_fiber(w->sched_fiber, 0);
+#endif
+        orz_simt_switch(&w->lanes[lane_].sp, w->sched_sp);
+    }
     uint32_t deposit(uint64_t v) {
         Lane& l = w->lanes[lane_];
         uint32_t g = l.gen++;
@@ -129,12 +146,16 @@ struct WaveCtx {
 enum Order { kAscending = 0, kDescending = 1, kShuffled = 2 };
 
 // Run `nblocks` one-wave blocks of kernel body `k` (k(WaveCtx&) is the per-lane code).
+// (`first`, `stride`: the blocks first, first + stride, ... of the order -- the race check runs a launch's blocks on several host threads)
 template <class K>
-void launch_waves(size_t nblocks, const K& k, size_t lds_bytes, Order order = kAscending, uint64_t seed = 1) {
+void launch_waves(size_t nblocks, const K& k, size_t lds_bytes, Order order = kAscending, uint64_t seed = 1, size_t first = 0, size_t stride = 1) {
     static thread_local Wave* wave = nullptr;
     if (!wave) wave = new Wave();
     Wave* w = wave;
     current_wave() = w;
+#if defined(ORZ_SIMT_TSAN)
+    w->sched_fiber = __tsan_get_current_fiber();
+#endif
     if (w->lds.size() < lds_bytes) w->lds.resize(lds_bytes);
     struct Arg {
         const K* k;
@@ -158,7 +179,7 @@ void launch_waves(size_t nblocks, const K& k, size_t lds_bytes, Order order = kA
             uint32_t t = ord[i - 1]; ord[i - 1] = ord[j]; ord[j] = t;
         }
     }
-    for (size_t bi = 0; bi < nblocks; bi++) {
+    for (size_t bi = first; bi < nblocks; bi += stride) {
         w->block = ord[bi];
         std::memset(w->tag, 0xff, sizeof w->tag);
         for (int i = 0; i < kLanes; i++) {
@@ -181,6 +202,9 @@ void launch_waves(size_t nblocks, const K& k, size_t lds_bytes, Order order = kA
                 Lane& l = w->lanes[i];
                 if (l.done) continue;
                 w->cur = i;
+#if defined(ORZ_SIMT_TSAN)
+                __tsan_switch_to_fiber(l.fiber, 0);
+#endif
                 orz_simt_switch(&w->sched_sp, l.sp);
                 if (!l.done) live = true;
             }
