@@ -170,10 +170,11 @@ int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* 
 /* ---- members decoded on the device (decoder on GPU, one member per wavefront) --------
  * Replaces orz::decode (/root/reference/src/lib.rs:94-129) + LZDecoder::decode (src/lz.rs:366-478) for a
  * concatenation of members: decoding one stream is a serial chain, so each member is decoded by one lane of
- * its own wavefront and the parallelism is the number of members (up to 2048 in flight).  Members must fit
- * one block (<= 16,777,216 decoded bytes -- what orz_members_encode / `orz encode --member-size` produce);
- * a larger member fails with ORZ_EINVAL and a message naming the host decoder.  Same bytes out as
- * orz_decode_members_mem; ORZ_EINVAL for what the reference reports as InvalidData. */
+ * its own wavefront and the parallelism is the number of members (up to 2048 in flight).  Members of several
+ * blocks decode too (round 4): a member decodes straight into its place in the output, ring nodes hold offsets into
+ * the member, and the reference's window slide (src/lib.rs:119-124, src/matcher.rs:82-87) is a counter that retires
+ * the nodes that left the window.  Members of 4 GiB or more fail with ORZ_EINVAL and a message naming the host
+ * decoder.  Same bytes out as orz_decode_members_mem; ORZ_EINVAL for what the reference reports as InvalidData. */
 typedef struct {
     uint64_t members, in_bytes, out_bytes;
     uint64_t launches;     /* kernel launches (members / 2048, rounded up) */

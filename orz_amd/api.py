@@ -233,8 +233,8 @@ class MemberEncoder:
     def encode(self, data, member_bytes=1 << 26):
         """member_bytes: 64 MiB by default -- a member starts with empty rings and a flat symbol order, and that cold start
         costs about 1.5 % of the size at 16 MiB members, a quarter of that at 64 MiB.  Members larger than one
-        block (16 MiB) decode with the reference decoder and with `decode_members` (host); the DEVICE decoder
-        (`decode_members_device`) takes members of at most one block and refuses larger ones with a clear error."""
+        block (16 MiB) decode with the reference decoder, with `decode_members` (host) and with the device decoder
+        (`decode_members_device`: its window slides as a counter, round 4)."""
         data = bytes(data)  # (no copy when it is `bytes` already; the library reads the object's own buffer)
         ptr = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p) if data else ctypes.cast(ctypes.create_string_buffer(1), ctypes.c_void_p)
         return self._run(ptr, len(data), False, member_bytes)
@@ -271,9 +271,8 @@ def decode_members(container):
 
 
 def decode_members_device(container, device=0, stats=False):
-    """decode every member of a concatenation of orz streams ON THE GPU (one member per wavefront; members of at
-    most one block: 16,777,216 input bytes -- a MemberEncoder container written with the default 64 MiB members is refused
-    with "member larger than one block: use the host decoder") -> (bytes, n_members[, stats dict]).  Same bytes as
+    """decode every member of a concatenation of orz streams ON THE GPU (one member per wavefront; members of any number
+    of blocks below 4 GiB -- the window slides as a counter, round 4) -> (bytes, n_members[, stats dict]).  Same bytes as
     `decode_members`."""
     lib = _native.load()
     container = bytes(container)

@@ -9,9 +9,13 @@
 // HBM per member, the last eight decoded bytes in a register so the three context hashes need no loads,
 // canonical Huffman tables as 2^max_len-entry lookup tables in the blob.
 //
-// Scope: members that fit one block (<= 16,777,216 decoded bytes, what `orz_members_encode` / `orz encode
-// --member-size` produce): the window never slides, and the member decodes straight into its place in the
-// output buffer (positions before the member's first byte read as zero, as the reference's window does).
+// A member decodes straight into its place in the output buffer (positions before the member's first byte read as
+// zero, as the reference's window does), so the window never has to be MOVED: ring nodes hold offsets into the member,
+// and the reference's slide (src/lib.rs:119-124; Bucket::forward, src/matcher.rs:82-87) is a counter -- a node whose
+// position has left the window (window offset <= 0 after the slides so far) is dead, as `pos = 0` is in the reference.
+// Members of any number of blocks below 4 GiB decode here (round 4; before, one block: the default 64 MiB members of
+// `orz_members_encode` were refused).  One difference to the reference on MALFORMED streams only: a match that names a
+// dead node is rejected as invalid data here (the reference copies from window offset 0).
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -24,7 +28,7 @@ namespace orz {
 enum : uint32_t {
     kDecOk = 0,
     kDecBadData = 1,     // InvalidData of the reference (src/lz.rs:413-415, src/lib.rs:111-113)
-    kDecTooLarge = 2,    // the member does not fit one block: use the host decoder
+    kDecTooLarge = 2,    // (unused since round 4: members of several blocks decode here)
     kDecSizeMismatch = 3,// decoded size differs from what the chunk headers announced
     kDecDeepTable = 4    // a 16-bit Huffman table: the reference accepts it, no orz encoder writes it (src/huffman.rs:99-108
                          // caps at 15) and the lookup tables here hold 2^15 entries: use the host decoder
@@ -164,7 +168,8 @@ struct DecodeMember {
         const uint32_t out_len = a.out_len[m];
         uint64_t at = a.m_begin[m];
         const uint64_t end = a.m_end[m];
-        uint32_t spos = kPre;
+        uint32_t spos = kPre;                       // window offset, as the reference counts it
+        uint32_t slid = 0;                          // bytes the window has slid by so far: window offset x is member offset x - kPre + slid
         uint64_t tail = 0;                          // the last eight decoded bytes, newest in the low byte
         bool first = true, after_literal = true;
         for (;;) {
@@ -250,7 +255,7 @@ struct DecodeMember {
                 }
                 // the last item of a stream may run past the announced end (the chunk's end field cuts it back,
                 // src/lz.rs:478): such bytes are decoded but not stored -- the next member's bytes live there
-                const uint32_t opos = spos - kPre;
+                const uint32_t opos = spos - kPre + slid;
                 if (opos >= out_len) return kDecSizeMismatch;  // an item STARTING past the end: not a stream of this size
                 uint32_t ro = 0, len = 0;
                 bool match = false;
@@ -271,15 +276,18 @@ struct DecodeMember {
                     if (ro >= kRing) return kDecBadData;
                     const uint32_t node = (head[ctx] + kRing - ro) % kRing;
                     const uint32_t enc = lenid == 5 ? sym(br, lut + 2 * 32768, ml[2]) : lenid;
-                    const uint32_t src = ring_pos[(size_t)ctx * kRing + node];
+                    // ring nodes hold 1 + the member offset of their item (0 = never written: the reference's pos 0)
+                    const uint32_t srec = ring_pos[(size_t)ctx * kRing + node];
                     uint32_t mn = ring_min[(size_t)ctx * kRing + node], ex = ring_exp[(size_t)ctx * kRing + node];
                     if (mn < kMinLen) mn = kMinLen;
                     if (ex < kMinLen) ex = kMinLen;
                     len = enc + mn > ex ? enc + mn : (enc > 0 ? enc + mn - 1 : ex);  // src/lz.rs:459-467
-                    if (src >= spos || len > kMaxLen + 127) return kDecBadData;
-                    for (uint32_t k = 0; k < len; k++) {  // overlap-safe forward copy; positions before the member are zero
+                    // dead: never written, or slid out of the window (window offset = member offset + kPre - slid <= 0)
+                    if (srec == 0 || (uint64_t)(srec - 1) + kPre <= (uint64_t)slid || srec - 1 >= opos || len > kMaxLen + 127) return kDecBadData;
+                    const uint32_t src = srec - 1;
+                    for (uint32_t k = 0; k < len; k++) {  // overlap-safe forward copy
                         const uint32_t sp = src + k;
-                        const uint8_t b = (sp >= kPre && sp - kPre < out_len) ? out[sp - kPre] : 0;
+                        const uint8_t b = sp < out_len ? out[sp] : 0;
                         if (opos + k < out_len) out[opos + k] = b;
                         tail = (tail << 8) | b;
                     }
@@ -294,7 +302,7 @@ struct DecodeMember {
                         uint8_t& mm = ring_min[(size_t)ctx * kRing + ni];
                         if (mm <= len) mm = (uint8_t)(len + 1 < 127 ? len + 1 : 127);
                     }
-                    ring_pos[(size_t)ctx * kRing + nh] = spos;
+                    ring_pos[(size_t)ctx * kRing + nh] = opos + 1;
                     ring_min[(size_t)ctx * kRing + nh] = 0;
                     ring_exp[(size_t)ctx * kRing + nh] = (uint8_t)(match ? len : 0);
                     head[ctx] = nh;
@@ -309,9 +317,13 @@ struct DecodeMember {
             }
             if (end_field < spos) spos = end_field;  // src/lz.rs:478
             if (spos < kPre) return kDecBadData;
-            if (spos >= kBlock && at < end && a.src[at] != 0) return kDecTooLarge;  // the window would slide here
+            if (spos >= kBlock) {  // src/lib.rs:119-124: the window slides by 2^24, every ring position with it
+                if (slid > 0xffffffffu - 2 * kNewMax) return kDecBadData;  // (members below 4 GiB)
+                slid += kNewMax;
+                spos = kPre;
+            }
         }
-        return spos - kPre == out_len ? kDecOk : kDecSizeMismatch;
+        return spos - kPre + slid == out_len ? kDecOk : kDecSizeMismatch;
     }
 };
 
@@ -330,13 +342,15 @@ struct MemberIndex {  // the container cut into members, from the chunk framing 
 
 // Walks the chunk framing of every member (LEB128 lengths, src/ioutil.rs:60-77) and reads each chunk's end
 // field from its prologue (first chunk of a member: after the census, src/lz.rs:372-395): that is the
-// member's decoded size.  Throws std::runtime_error on malformed framing or a member beyond one block.
+// member's decoded size (a chunk that ends at the block's end slides the window, src/lib.rs:119-124: the next chunk's
+// field counts from SBVEC_PREMATCH_LEN again).  Throws std::runtime_error on malformed framing.
 inline MemberIndex index_members(const uint8_t* src, size_t n) {
     MemberIndex ix;
     size_t at = 0;
     while (at < n) {
         const size_t begin = at;
         uint32_t spos_end = kPre;
+        uint64_t slid = 0;
         bool first = true;
         for (;;) {
             uint64_t t = 0;
@@ -357,21 +371,26 @@ inline MemberIndex index_members(const uint8_t* src, size_t n) {
                 first = false;
             }
             const uint32_t end_field = br.varint(bad);
-            if (spos_end >= kBlock) throw std::runtime_error("member larger than one block: use the host decoder");
             if (bad || end_field < spos_end || end_field > kBlock) throw std::runtime_error("invalid orz data: end field");
             spos_end = end_field;
+            if (spos_end >= kBlock) {  // the decoder slides here (src/lib.rs:119-124)
+                slid += kNewMax;
+                spos_end = kPre;
+                if (slid > 0xffffffffull - 2 * kNewMax) throw std::runtime_error("member of 4 GiB or more: use the host decoder");
+            }
             at += t;
         }
         // A member cannot code more than 4096 bytes per byte of its own: an item is at least one bit behind a non-empty
         // Huffman table and at most 255 + 127 bytes long.  Streams that announce more (tables of zero-length codes,
         // which no encoder writes, or plain lies about the size) are not sized on the device on their own word.
-        if ((uint64_t)(spos_end - kPre) > (uint64_t)(at - begin) * 4096 + 4096)
+        const uint64_t mlen = (uint64_t)(spos_end - kPre) + slid;
+        if (mlen > (uint64_t)(at - begin) * 4096 + 4096)
             throw std::runtime_error("member announces more output than its bits can code: use the host decoder");
         ix.begin.push_back(begin);
         ix.end.push_back(at);
         ix.out_off.push_back(ix.out_total);
-        ix.out_len.push_back(spos_end - kPre);
-        ix.out_total += spos_end - kPre;
+        ix.out_len.push_back((uint32_t)mlen);
+        ix.out_total += mlen;
     }
     return ix;
 }

@@ -380,8 +380,8 @@ class StreamEncoder {
                 fccnt_ = take<uint32_t>(kNumKeys + 1);
                 fcnew_ = take<uint32_t>(kNumKeys + 1);
             }
-            f32_ = take<uint32_t>(kWLen, false);
-            sc32_ = take<uint32_t>(kWLen, false);
+            f32_ = take<uint32_t>((size_t)kNewMax + 8, false);   // flags / scan over at most 2^24 + 1 entries (the history's
+            sc32_ = take<uint32_t>((size_t)kNewMax + 8, false);  // positions, the new positions, the word-list slots)
             hpos_ = take<uint32_t>(kPre + 1);
             ctxcount_ = take<uint32_t>(256);
             tailkey_ = take<uint32_t>(8);
@@ -389,20 +389,8 @@ class StreamEncoder {
             wlast_ = take<uint32_t>(32768);
             // items and tail-stage buffers: two sets, taken by the blocks alternately (see post_stage)
             for (TailSet& t : ts_) {
-                t.ipos = take<uint32_t>((size_t)kNewMax + 1, false);
-                t.isym = take<uint16_t>(kNewMax);
-                t.ictx = take<uint16_t>(kNewMax);
-                t.irank = take<uint16_t>(kNewMax);
-                t.irob = take<uint16_t>(kNewMax);
-                t.grank = take<uint16_t>(kNewMax);
-                t.skey = take<uint16_t>(kNewMax);
-                t.iunl = take<uint8_t>(kNewMax);
-                t.ienc = take<uint8_t>(kNewMax);
-                t.ial = take<uint8_t>(kNewMax);
-                t.gsym = take<uint32_t>(kNewMax, false);
-                t.sperm = take<uint32_t>(kNewMax, false);
-                t.blen = take<uint32_t>(kNewMax, false);
-                t.bscan = take<uint32_t>(kNewMax, false);
+                t.cap = 0;
+                grow_tail_set(t, kTailItems0);
                 t.rstart = take<uint32_t>(520);
                 t.hw = take<uint32_t>((size_t)kMaxChunks * kHwStride);
                 t.hl = take<uint8_t>((size_t)kMaxChunks * kHwStride);
@@ -946,13 +934,14 @@ class StreamEncoder {
         be_.exclusive_scan_u32(f32_, sc32_, n);
         uint32_t nitems = 0;
         be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
-        be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
         {
             uint32_t two[2] = {0, 0};
             be_.d2h(two, tailkey_ + 3, 8);
             nitems = two[0];
             hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by)
         }
+        if (nitems > t.cap) grow_tail_set(t, nitems);  // (the set is idle: its last block was collected above)
+        be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
         if (inject_kind_) be_.launch(1, VerInjectK{inject_kind_, inject_nth_, t.ipos, nitems, TY_, ML_, SRC_, ORD_, win, S_});  // (tests of the gate)
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
@@ -1268,6 +1257,7 @@ class StreamEncoder {
         uint16_t* hc = nullptr;
         uint32_t *hdrbits = nullptr, *tot = nullptr, *out = nullptr, *srflags = nullptr;
         bool pending = false;
+        uint32_t cap = 0;  // items the per-item buffers hold (grow_tail_set)
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
     static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4, kEvGate = 6;  // event numbers (+ set index)
@@ -1276,6 +1266,30 @@ class StreamEncoder {
         ~MainStreamGuard() { be.select(0); }
     };
     TailSet ts_[2];
+    // The per-item buffers of a tail set hold `cap` items: 6 M to begin with (text has 0.3 items per byte: 5 M a block) and
+    // whatever a block needs from then on, up to one item per byte -- sized for the worst case from the start they were 1.2 GB
+    // of a stream's state.  Called only while the set is idle.
+    static constexpr uint32_t kTailItems0 = 6u << 20;
+    template <class T>
+    void retake(T*& p, size_t n, bool zero) {
+        if (p) {
+            be_.free(p);
+            owned_.erase(std::find(owned_.begin(), owned_.end(), (void*)p));
+            p = nullptr;
+        }
+        p = take<T>(n, zero);
+    }
+    void grow_tail_set(TailSet& t, uint32_t need) {
+        uint64_t cap = std::max<uint64_t>(need, (uint64_t)t.cap * 3 / 2);
+        cap = std::min<uint64_t>(kNewMax, (cap + 65535) & ~65535ull);
+        if (t.cap) be_.sync();
+        retake(t.ipos, (size_t)cap + 1, false);
+        retake(t.isym, cap, true); retake(t.ictx, cap, true); retake(t.irank, cap, true); retake(t.irob, cap, true);
+        retake(t.grank, cap, true); retake(t.skey, cap, true);
+        retake(t.iunl, cap, true); retake(t.ienc, cap, true); retake(t.ial, cap, true);
+        retake(t.gsym, cap, false); retake(t.sperm, cap, false); retake(t.blen, cap, false); retake(t.bscan, cap, false);
+        t.cap = (uint32_t)cap;
+    }
     int cur_set_ = 0;
     uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)
     uint32_t hist_hint_ = ~0u;   // history item starts of the next block as the host computes them (~0 = ask the device)

@@ -75,10 +75,16 @@ def test_emulated_kernel_rejects_bad_containers(emu_decode, oracle):
         pass
 
 
-def test_emulated_kernel_refuses_members_beyond_one_block(emu_decode, oracle):
-    big = oracle.encode(bytes(17_000_000), 0)
-    with pytest.raises(ValueError, match="larger than one block"):
-        emu_decode(big)
+def test_emulated_kernel_decodes_members_of_several_blocks(emu_decode, oracle):
+    """the window "slides" as a counter (src/lib.rs:119-124, src/matcher.rs:82-87): members beyond one block decode on the
+    device decoder's kernel body too -- zeros (every match refers across the slide), and text of two blocks and a tail
+    whose second block refers to sources in the first"""
+    import corpus
+
+    big = bytes(17_000_000)
+    assert emu_decode(oracle.encode(big, 0)) == (big, 1)
+    text = corpus.enwik_like(34_500_000)
+    assert emu_decode(oracle.encode(text, 1) + oracle.encode(text[:70_000], 2)) == (text + text[:70_000], 2)
 
 
 @pytest.mark.gpu
@@ -124,9 +130,22 @@ def test_gpu_decoder_reports_bad_data(oracle):
     good = oracle.encode(_data.mixed(50_000, seed=3), 1)
     with pytest.raises(Exception):
         orz_amd.decode_members_device(good[:-1])
-    with pytest.raises(Exception) as ei:
-        orz_amd.decode_members_device(oracle.encode(bytes(17_000_000), 0))
-    assert "larger than one block" in str(ei.value), str(ei.value)
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_the_default_64MiB_members():
+    """what MemberEncoder writes by default (64 MiB members: four blocks, three slides) decodes on the GPU decoder"""
+    import corpus
+    import orz_amd
+
+    data = corpus.enwik_like((1 << 26) + 3_000_000)  # (one lane decodes a member: ~2 MB/s each, so one full member and a short one)
+    enc = orz_amd.MemberEncoder(device=0, level=1, jobs=2)
+    try:
+        blob, n = enc.encode(data)
+    finally:
+        enc.close()
+    out, m = orz_amd.decode_members_device(blob)
+    assert m == n == 2 and out == data
 
 
 @pytest.mark.gpu

@@ -167,3 +167,11 @@ def test_the_byte_before_the_window_travels_with_the_slide(emu, oracle):
     front = (ctypes.c_uint8 * 2)()
     assert emu.lib.emu_window_front(data, ctypes.c_size_t(len(data)), front) == 0
     assert bytes(front) == b"\0a"  # (stream offset -1 is the sentinel, stream offset 0 the first byte)
+
+
+def test_more_items_than_the_tail_buffers_start_with(emu, oracle):
+    """incompressible input: an item per byte -- beyond the 6 M items the per-item buffers of a tail set hold to begin with
+    (StreamEncoder::grow_tail_set); the stream must still decode"""
+    data = _data.random_bytes(6_800_000)
+    out, _ = emu.fast(data)
+    assert oracle.decode(out)[0] == data

@@ -391,3 +391,20 @@ def test_object_level_seam_keeps_the_bytes_before_the_window(oracle):
         enc.close()
     stream.append(0)
     oracle.assert_decodes_to(stream, data, "the object-level encoder's stream")
+
+
+def test_more_items_than_the_tail_buffers_start_with(oracle):
+    """incompressible input, a full block and a part: one item per byte, 16.7 M in the first block -- the per-item buffers of
+    both tail sets grow from their initial 6 M items (StreamEncoder::grow_tail_set); text through the same encoder afterwards"""
+    import orz_amd
+
+    data = _data.random_bytes(20_000_000)
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        out = enc.encode(data)
+        text = _data.text(3_000_000, seed=12)
+        out2 = enc.encode(text)
+    finally:
+        enc.close()
+    oracle.assert_decodes_to(out, data, "random bytes")
+    oracle.assert_decodes_to(out2, text, "text after the buffers grew")
