@@ -519,7 +519,7 @@ class StreamEncoder {
         if (fast_) {
             double tf = be_.now();  // (no sync here: the prep kernels are queued, the parse follows on the same stream)
             stats.t_prep += tf - t0;
-            fast_parse(n, len, nent, keysB, kkeysB);
+            fast_parse(n, len, nent, keysB, kkeysB, out);
             double t2f = be_.now();
             stats.t_parse += t2f - tf;
             post_stage(n, len, out, chunk_ends, t2f);
@@ -703,7 +703,8 @@ class StreamEncoder {
 
     // The GPU-native parse of one block (orz_fast.h): fills S_/TY_/ML_/SRC_/ORD_/W0_ for the new region and
     // carries ctxcount_ / wsnap_ / lt_carry_, like the exact mode's sweeps + FinalizeBlock do.
-    void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys) {
+    template <class OutT>
+    void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys, OutT& out) {
         const uint8_t* win = dwin();
         const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
         be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
@@ -844,6 +845,11 @@ class StreamEncoder {
             // kernels of later passes return at once; the control block is read once per group.
             const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (tests, experiments: every pass walks for every match)
             static const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 256;  // (0 = no limit)
+            // The round loop is queued (≈ 25 ms of device work) and the host would only wait for it at the first read-back of the
+            // repairs: the output of the block that used the NEXT tail set two blocks ago is fetched now -- its copies run on
+            // the copy stream beside the rounds instead of between this block's parse and its item stage, where the main
+            // stream stood idle for them.
+            if (ts_[cur_set_].pending && !pend_order_.empty() && pend_order_.front() == cur_set_) collect_one(out, nullptr);
             FastCtl h{};
             be_.launch(1, FastCtlReset{fctl_});
             int pass = 0;

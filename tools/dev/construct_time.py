@@ -9,6 +9,17 @@ t1 = time.time()
 data = corpus.enwik_like(100_000_000)
 t2 = time.time()
 rows = []
+try:  # device memory one stream encoder holds (hipMemGetInfo through torch, when it is there)
+    import torch
+    free0 = torch.cuda.mem_get_info(0)[0]
+    e0 = orz_amd.StreamEncoder(device=0, level=1)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    e0.encode(data[:20_000_000])
+    held_after = free0 - torch.cuda.mem_get_info(0)[0]
+    e0.close()
+    print({"device_bytes_held_by_one_stream_encoder": held, "after_encoding_20MB_of_text": held_after})
+except Exception as ex:  # noqa: BLE001
+    print({"device_bytes_held_by_one_stream_encoder": "n/a (%r)" % (ex,)})
 for k in range(3):
     a = time.time(); enc = orz_amd.StreamEncoder(device=0, level=1); b = time.time()
     out = enc.encode(data[:20_000_000]); c = time.time()
