@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liborz_hip.so")
+LIB_PATH = os.environ.get("ORZ_LIB_PATH") or os.path.join(_HERE, "lib", "liborz_hip.so")  # (ORZ_LIB_PATH: dev builds side by side)
 
 
 class LZCfg(ctypes.Structure):

@@ -9,10 +9,13 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <rocprim/rocprim.hpp>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "orz_kernels.h"
@@ -32,6 +35,17 @@ __global__ __launch_bounds__(256) void orz_thread_kernel(F f, size_t n) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < n) f(tid);
 }
+
+// The same with an occupancy target (waves per SIMD) for the register allocator: FastEval runs at 82 registers = 5 waves
+// per SIMD when left alone, and one launch of it oversubscribes every wave slot of the GPU -- more slots are
+// more loads in flight.  ORZ_EVAL_WAVES at build time (tools/dev: 6 / 7 / 8 tried in round 4).
+#if defined(ORZ_EVAL_WAVES)
+template <class F>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORZ_EVAL_WAVES, ORZ_EVAL_WAVES))) void orz_thread_kernel_occ(F f, size_t n) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < n) f(tid);
+}
+#endif
 
 // wave-cooperative kernels: one 64-lane wavefront per block, dynamic LDS
 struct DevWave {
@@ -424,23 +438,96 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     }
 }
 
+struct FastEval;  // (orz_fast.h: the one kernel with an occupancy target, see orz_thread_kernel_occ)
+
+// How many encoders of a process may have a block's parse in flight on a device at a time (ORZ_PARSE_TOKENS; 0 = no limit).
+// The parse kernels of different encoders do not fill each other's gaps, they stretch each other: eight
+// encoders whose main streams happened to share hardware queues in pairs ran at 530 MB/s, the same eight on queues of their
+// own at 410.  The token makes that an explicit, deterministic policy instead of an accident of the runtime's queue
+// assignment: an encoder takes one before it queues a block's prep and gives it back when the block's items are handed to
+// the ranking chain; symbol ranking, Huffman, packing and copies of the other encoders run beside it as before.
+class ParseTokens {
+   public:
+    static ParseTokens& of(int device) {
+        static ParseTokens t[64];
+        return t[device & 63];
+    }
+    void acquire() {
+        if (!limit()) return;
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return busy_ < limit(); });
+        busy_++;
+    }
+    void release() {
+        if (!limit()) return;
+        { std::lock_guard<std::mutex> lk(m_); busy_--; }
+        cv_.notify_one();
+    }
+    static int limit() {
+        static const int n = getenv("ORZ_PARSE_TOKENS") ? atoi(getenv("ORZ_PARSE_TOKENS")) : 0;
+        return n;
+    }
+
+   private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int busy_ = 0;
+};
+
+// The HIP streams of the encoders of a process come from a pool and go back to it.  The runtime maps streams onto its
+// hardware queues (GPU_MAX_HW_QUEUES, 16 here) when they are CREATED, and how the encoders' streams share queues decides
+// how their kernels overlap: a process's first eight encoders (32 streams created in a row: main streams share queues in
+// pairs, ranking streams in pairs, ...) encode at 530 MB/s, every later set of eight -- created after others were destroyed, or
+// simply later -- at 410, with the same clocks, memory and code (round 4: tools/dev/members_sets.py; 24 queues: 470 / 455 /
+// 460, 32 queues: 413 for every set).  Reusing the streams keeps every set on the first set's mapping.
+class StreamPool {
+   public:
+    static constexpr int kStreams = 4;
+    struct Set { hipStream_t s[kStreams] = {nullptr, nullptr, nullptr, nullptr}; };
+    static StreamPool& get() {
+        static StreamPool* p = new StreamPool;  // (never destroyed: streams outlive every static of the runtime's clients)
+        return *p;
+    }
+    Set take(int device, bool rank_prio) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            auto& v = free_[{device, rank_prio}];
+            if (!v.empty()) { Set t = v.back(); v.pop_back(); return t; }
+        }
+        Set t;
+        int prio_low = 0, prio_high = 0;
+        ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        for (int i = 0; i < kStreams; i++) {
+            if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
+            else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking));
+        }
+        return t;
+    }
+    void give(int device, bool rank_prio, const Set& t) {
+        std::lock_guard<std::mutex> lk(m_);
+        free_[{device, rank_prio}].push_back(t);
+    }
+
+   private:
+    std::mutex m_;
+    std::map<std::pair<int, bool>, std::vector<Set>> free_;
+};
+
 class HipBackend {
    public:
     // `lone`: the encoder has the GPU to itself (a single stream: bench.py, orz_stream_new, bin/orz without --jobs); the
     // workers of a members job are not lone
-    explicit HipBackend(int device, bool lone = true) : device_(device) {
+    explicit HipBackend(int device, bool lone = true) : device_(device), lone_(lone) {
         ORZ_HIP_CHECK(hipSetDevice(device_));
         // Stream 1 carries nothing but the symbol-ranking launches -- the serial chain of an orz stream.  A lone encoder
         // gives it the device's highest priority so that a ranking launch does not queue behind the dispatch of the next
         // block's parse grids; the workers of a members job leave it at the default.  Neither choice moved a measurement
         // beyond the run-to-run spread (bench 298...303 MB/s, eight encoders 454...557).  ORZ_RANK_PRIO=0/1 overrides.
-        int prio_low = 0, prio_high = 0;
-        ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         const char* rp = getenv("ORZ_RANK_PRIO");
-        const bool rank_prio = rp ? atoi(rp) != 0 : lone;
-        for (int i = 0; i < kStreams; i++) {
-            if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio_high));
-            else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+        rank_prio_ = rp ? atoi(rp) != 0 : lone;
+        {
+            const StreamPool::Set t = StreamPool::get().take(device_, rank_prio_);
+            for (int i = 0; i < kStreams; i++) streams_[i] = t.s[i];
         }
         stream_ = streams_[0];
         for (int i = 0; i < kEvents; i++) ORZ_HIP_CHECK(hipEventCreateWithFlags(&sev_[i], hipEventDisableTiming));
@@ -464,10 +551,13 @@ class HipBackend {
         (void)hipSetDevice(device_);
         for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamSynchronize(streams_[i]);
         for (int i = 0; i < kStreams; i++) (void)hipFree(tmps_[i]);
+        if (arena_) (void)hipFree(arena_);
         for (int i = 0; i < kEvents; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         for (auto& kv : graph_exec_) (void)hipGraphExecDestroy(kv.second);
-        for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamDestroy(streams_[i]);
+        StreamPool::Set t;  // (synchronised above: the streams go back to the pool idle)
+        for (int i = 0; i < kStreams; i++) t.s[i] = streams_[i];
+        if (streams_[0]) StreamPool::get().give(device_, rank_prio_, t);
     }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;
@@ -501,15 +591,38 @@ class HipBackend {
         return (uint32_t)(per_cu * (size_t)(cus > 0 ? cus : 256));
     }
 
+    // ORZ_ARENA_MB=<n> (diagnostics, off by default): an encoder's ~60 buffers are carved out of ONE device allocation, 2 MiB-
+    // aligned when large, 256 B otherwise; nothing is returned before the last of them is freed, a buffer that does not fit
+    // falls back to hipMalloc.  Built in round 4 to test whether allocation placement explains why a process's later
+    // encoders are slower (it does not: the streams' hardware queues do, see StreamPool).  What it is good for: buffers that
+    // lie side by side turn an out-of-bounds access into a visible defect -- with it the exact mode's object-level test
+    // trips the validity gate (1,028 wrong excluded symbols in a 17 MB two-chunk block): some kernel of the exact parse
+    // reads or writes past a buffer's end, harmlessly with separate allocations.  Open.
     template <class T>
     T* alloc(size_t n, bool zero = true) {
-        void* p = nullptr;
-        ORZ_HIP_CHECK(hipSetDevice(device_));
-        ORZ_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
-        if (zero) ORZ_HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), stream_));
+        const size_t bytes = (n ? n : 1) * sizeof(T);
+        void* p = arena_take(bytes);
+        if (!p) {
+            ORZ_HIP_CHECK(hipSetDevice(device_));
+            ORZ_HIP_CHECK(hipMalloc(&p, bytes));
+        }
+        if (zero) ORZ_HIP_CHECK(hipMemsetAsync(p, 0, bytes, stream_));
         return (T*)p;
     }
-    void free(void* p) { (void)hipFree(p); }
+    void free(void* p) {
+        if (p && arena_ && (char*)p >= arena_ && (char*)p < arena_ + arena_bytes_) {
+            // (space comes back when the LAST buffer carved from the arena is gone: an encoder's buffers die together, and a
+            // rebuilt encoder may share the arena with its predecessor for a moment)
+            if (--arena_live_ == 0) {
+                for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamSynchronize(streams_[i]);
+                arena_used_ = 0;
+            }
+            return;
+        }
+        (void)hipFree(p);
+    }
+    void release_arena() {}
+    void enable_arena() { arena_on_ = true; }  // (stream encoders only: the decoder's and the Huffman entry point's backends allocate as before)
     void poison(void*, size_t) {}  // (the emulation backend fills state that must never be read before it is written)
     void memset(void* p, int v, size_t n) {
         if (n) ORZ_HIP_CHECK(hipMemsetAsync(p, v, n, stream_));
@@ -546,6 +659,8 @@ class HipBackend {
         }
     }
     void sync() { ORZ_HIP_CHECK(hipStreamSynchronize(stream_)); }
+    void parse_token_acquire() { if (!lone_) ParseTokens::of(device_).acquire(); }
+    void parse_token_release() { if (!lone_) ParseTokens::of(device_).release(); }
     // counts the host derives instead of reading them back are verified against the device only on request
     bool check_hints() const { static const bool on = getenv("ORZ_CHECK_HINTS") != nullptr; return on; }
     double now() {
@@ -555,6 +670,13 @@ class HipBackend {
     void launch(size_t n, const F& f) {
         if (!n) return;
         const unsigned grid = (unsigned)((n + 255) / 256);
+#if defined(ORZ_EVAL_WAVES)
+        if constexpr (std::is_same<F, FastEval>::value) {
+            hipLaunchKernelGGL(orz_thread_kernel_occ<F>, dim3(grid), dim3(256), 0, stream_, f, n);
+            ORZ_HIP_CHECK(hipGetLastError());
+            return;
+        }
+#endif
         hipLaunchKernelGGL(orz_thread_kernel<F>, dim3(grid), dim3(256), 0, stream_, f, n);
         ORZ_HIP_CHECK(hipGetLastError());
     }
@@ -729,9 +851,34 @@ class HipBackend {
     }
 
    private:
+    void* arena_take(size_t bytes) {
+        if (!arena_on_) return nullptr;
+        if (!arena_tried_) {
+            arena_tried_ = true;
+            const char* v = getenv("ORZ_ARENA_MB");
+            const size_t mb = v ? (size_t)strtoull(v, nullptr, 10) : 0;
+            if (mb) {
+                (void)hipSetDevice(device_);
+                void* p = nullptr;
+                if (hipMalloc(&p, mb << 20) == hipSuccess) { arena_ = (char*)p; arena_bytes_ = mb << 20; }
+                else (void)hipGetLastError();
+            }
+        }
+        if (!arena_) return nullptr;
+        const size_t align = bytes >= (1u << 20) ? (2u << 20) : 256;
+        const size_t at = (arena_used_ + align - 1) / align * align;
+        if (at + bytes > arena_bytes_) return nullptr;
+        arena_used_ = at + bytes;
+        arena_live_++;
+        return arena_ + at;
+    }
+    char* arena_ = nullptr;
+    size_t arena_bytes_ = 0, arena_used_ = 0, arena_live_ = 0;
+    bool arena_tried_ = false, arena_on_ = false;
     int device_;
+    bool lone_ = true, rank_prio_ = false;
     hipStream_t stream_ = nullptr;
-    static constexpr int kStreams = 4, kEvents = 8;  // (stream 3 only copies finished output to the host: no temporary storage)
+    static constexpr int kStreams = StreamPool::kStreams, kEvents = 8;  // (stream 3 only copies finished output to the host: no temporary storage)
     hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
     void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};

@@ -245,6 +245,7 @@ static orz_stream* stream_new(int device, const orz_lzcfg* cfg, bool lone) {
         if (device < 0 || device >= orz_device_count()) { fail(ORZ_ENODEV, "no such HIP device"); return nullptr; }
         std::unique_ptr<orz_stream> s(new orz_stream);
         s->be.reset(new orz::HipBackend(device, lone));
+        s->be->enable_arena();
         s->cfg = *cfg;
         s->seg = env_u("ORZ_SEG", kDefaultSeg);
         s->win = env_u("ORZ_WIN", 0);
@@ -574,6 +575,7 @@ orz_lz_encoder* orz_lz_encoder_new(int device) {
         if (device < 0 || device >= orz_device_count()) { fail(ORZ_ENODEV, "no such HIP device"); return nullptr; }
         std::unique_ptr<orz_lz_encoder> e(new orz_lz_encoder);
         e->be.reset(new orz::HipBackend(device));
+        e->be->enable_arena();
         e->seg = env_u("ORZ_SEG", kDefaultSeg);
         e->win = env_u("ORZ_WIN", 0);
         return e.release();

@@ -479,6 +479,11 @@ class StreamEncoder {
     template <class OutT>
     void encode_block(uint32_t n, OutT& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
+        struct TokenGuard {  // (members jobs: at most ORZ_PARSE_TOKENS encoders parse at a time, see the backend)
+            BE& be;
+            explicit TokenGuard(BE& b) : be(b) { be.parse_token_acquire(); }
+            ~TokenGuard() { be.parse_token_release(); }
+        } token{be_};
         last_n_ = n;
         double t0 = be_.now();
         const uint8_t* win = dwin();
@@ -1230,6 +1235,7 @@ class StreamEncoder {
     void release_all() {
         for (void* p : owned_) if (p) be_.free(p);
         owned_.clear();
+        be_.release_arena();
     }
     std::vector<void*> owned_;
     BE& be_;

@@ -34,6 +34,9 @@ struct EmuBackend {
         return p;
     }
     void free(void* p) { std::free(p); }
+    void release_arena() {}
+    void parse_token_acquire() {}
+    void parse_token_release() {}
     void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
     void poison(void* p, size_t n) { std::memset(p, 0xA5, n); }
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
