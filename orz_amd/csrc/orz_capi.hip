@@ -16,6 +16,7 @@
 #include "backend_hip.h"
 #include "orz_decode_device.h"
 #include "orz_host_decode.h"
+#include "orz_decode_check.h"
 #include "orz_stream.h"
 
 namespace {
@@ -68,66 +69,6 @@ bool verify_decode_on() {
     const char* v = std::getenv("ORZ_VERIFY");
     return v && std::string(v) == "decode";
 }
-class DecodeCheck {
-   public:
-    DecodeCheck() : ws_(new orz::host::DecodeWorkspace) { ws_->begin_stream(); }
-    void feed_input(const uint8_t* p, size_t n) { in_.insert(in_.end(), p, p + n); }
-    // bytes of the stream in order; throws std::runtime_error on the first chunk that does not decode to the input
-    void feed_output(const uint8_t* p, size_t n) {
-        out_.insert(out_.end(), p, p + n);
-        for (;;) {
-            size_t t = 0, at = opos_;
-            unsigned sh = 0;
-            bool whole = false;
-            while (at < out_.size()) {  // read_len, src/ioutil.rs:60-77
-                const uint8_t b = out_[at++];
-                t |= (size_t)(b & 0x7f) << sh;
-                sh += 7;
-                if (!(b & 0x80)) { whole = true; break; }
-            }
-            if (!whole) break;
-            if (t == 0) { eof_ = true; opos_ = at; break; }
-            if (at + t > out_.size()) break;  // the chunk is not complete yet
-            if (t >= ws_->tbuf.size()) bad("a chunk longer than the decoder accepts");
-            std::memcpy(ws_->tbuf.data(), out_.data() + at, t);
-            uint8_t* sbuf = ws_->win.data() + orz::kSent;
-            size_t end;
-            try {
-                end = ws_->dec.decode(ws_->tbuf.data(), t, sbuf, spos_);
-            } catch (const std::exception&) {
-                bad("the decoder rejects a chunk");
-            }
-            if (end < spos_) bad("the decoder rejects a chunk");
-            const size_t got = end - spos_;
-            if (ipos_ + got > in_.size() || std::memcmp(sbuf + spos_, in_.data() + ipos_, got) != 0) bad("a chunk decodes to other bytes than were encoded");
-            ipos_ += got;
-            checked_ += got;
-            spos_ = end;
-            if (spos_ >= orz::kBlock) {  // src/lib.rs:120-125
-                std::memmove(sbuf, sbuf + (orz::kBlock - orz::kPre), orz::kPre);
-                ws_->dec.forward(orz::kBlock - orz::kPre);
-                spos_ = orz::kPre;
-            }
-            opos_ = at + t;
-            // drop what has been checked (the buffers stay small on long streams)
-            if (opos_ > (1u << 24)) { out_.erase(out_.begin(), out_.begin() + (ptrdiff_t)opos_); opos_ = 0; }
-            if (ipos_ > (1u << 24)) { in_.erase(in_.begin(), in_.begin() + (ptrdiff_t)ipos_); ipos_ = 0; }
-        }
-    }
-    void finish() {
-        if (!eof_ || ipos_ != in_.size() || opos_ != out_.size()) bad("the stream ends before its input does (or carries bytes behind its end)");
-    }
-    size_t checked() const { return checked_; }
-
-   private:
-    [[noreturn]] void bad(const char* what) {
-        throw std::runtime_error(std::string("ORZ_VERIFY=decode: ") + what + " (after " + std::to_string(checked_) + " verified bytes): no stream written");
-    }
-    std::unique_ptr<orz::host::DecodeWorkspace> ws_;
-    std::vector<uint8_t> in_, out_;
-    size_t ipos_ = 0, opos_ = 0, spos_ = orz::kPre, checked_ = 0;
-    bool eof_ = false;
-};
 // a whole stream in memory against its input (host or device resident)
 void verify_stream_decode(const uint8_t* src, size_t n, bool src_on_device, const uint8_t* out, size_t out_len) {
     std::vector<uint8_t> host;
@@ -136,7 +77,7 @@ void verify_stream_decode(const uint8_t* src, size_t n, bool src_on_device, cons
         ORZ_HIP_CHECK(hipMemcpy(host.data(), src, n, hipMemcpyDeviceToHost));
         src = host.data();
     }
-    DecodeCheck chk;
+    orz::host::DecodeCheck chk;
     chk.feed_input(src, n);
     chk.feed_output(out, out_len);
     chk.finish();
@@ -755,7 +696,7 @@ int orz_encode(orz_read_fn rd, void* rctx, orz_write_fn wr, void* wctx, const or
         std::vector<uint8_t> out;
         size_t in_total = 0, out_total = 0;
         bool first = true;
-        std::unique_ptr<DecodeCheck> chk(verify_decode_on() ? new DecodeCheck : nullptr);  // (verifies a block's bytes before the sink sees them)
+        std::unique_ptr<orz::host::DecodeCheck> chk(verify_decode_on() ? new orz::host::DecodeCheck : nullptr);  // (verifies a block's bytes before the sink sees them)
         for (;;) {
             // read_repeatedly, src/lib.rs:42-52: fill the block or hit EOF
             size_t got = 0;

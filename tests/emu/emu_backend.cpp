@@ -11,6 +11,7 @@
 #include <numeric>
 #include <string>
 
+#include "../../orz_amd/csrc/orz_decode_check.h"
 #include "../../orz_amd/csrc/orz_decode_device.h"
 #include "../../orz_amd/csrc/orz_stream.h"
 #include "simt.h"
@@ -411,5 +412,30 @@ extern "C" int emu_encode_fast_seam(const uint8_t* src, size_t n, int depth, int
         g_emu_err = e.what();
         std::fprintf(stderr, "emu_encode_fast_seam: %s\n", e.what());
         return -1;
+    }
+}
+
+// the engine of ORZ_VERIFY=decode (orz_decode_check.h) alone: `stream` fed in pieces of `piece` bytes against `input`;
+// returns 0 when every chunk decodes to the input and the stream ends where the input does, else 1 with the message in err
+extern "C" int emu_decode_check(const uint8_t* stream, size_t n, const uint8_t* input, size_t m, size_t piece, char* err, size_t cap) {
+    try {
+        orz::host::DecodeCheck chk;
+        if (!piece) piece = n ? n : 1;
+        size_t fed = 0;
+        for (size_t at = 0; at < n; at += piece) {
+            // the input arrives block by block, ahead of the bytes that encode it (as in orz_encode)
+            while (fed < m && fed < (at / piece + 2) * (size_t)orz::kNewMax) {
+                const size_t k = std::min<size_t>(orz::kNewMax, m - fed);
+                chk.feed_input(input + fed, k);
+                fed += k;
+            }
+            chk.feed_output(stream + at, std::min(piece, n - at));
+        }
+        if (fed < m) chk.feed_input(input + fed, m - fed);
+        chk.finish();
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && cap) { std::strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
+        return 1;
     }
 }
