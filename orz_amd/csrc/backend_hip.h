@@ -488,12 +488,31 @@ class StreamPool {
         static StreamPool* p = new StreamPool;  // (never destroyed: streams outlive every static of the runtime's clients)
         return *p;
     }
+    // The first request for a (device, priority) kind creates kBlockSets sets in one go -- 32 streams in a row, however the
+    // process goes on to create its encoders one, two, four or eight at a time: every encoder of the first eight runs on
+    // the mapping a process's first eight encoders get (the good one, see above).  Later requests take what is free.
+    static constexpr int kBlockSets = 8;
     Set take(int device, bool rank_prio) {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            auto& v = free_[{device, rank_prio}];
-            if (!v.empty()) { Set t = v.back(); v.pop_back(); return t; }
+        std::lock_guard<std::mutex> lk(m_);
+        auto& v = free_[{device, rank_prio}];
+        if (v.empty()) {
+            const int n = made_[{device, rank_prio}] ? 1 : kBlockSets;
+            std::vector<Set> fresh;
+            for (int k = 0; k < n; k++) fresh.push_back(create(rank_prio));
+            made_[{device, rank_prio}] += n;
+            for (int k = n; k-- > 0;) v.push_back(fresh[k]);  // (handed out in the order they were created)
         }
+        Set t = v.back();
+        v.pop_back();
+        return t;
+    }
+    void give(int device, bool rank_prio, const Set& t) {
+        std::lock_guard<std::mutex> lk(m_);
+        free_[{device, rank_prio}].push_back(t);
+    }
+
+   private:
+    static Set create(bool rank_prio) {
         Set t;
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -503,14 +522,9 @@ class StreamPool {
         }
         return t;
     }
-    void give(int device, bool rank_prio, const Set& t) {
-        std::lock_guard<std::mutex> lk(m_);
-        free_[{device, rank_prio}].push_back(t);
-    }
-
-   private:
     std::mutex m_;
     std::map<std::pair<int, bool>, std::vector<Set>> free_;
+    std::map<std::pair<int, bool>, int> made_;
 };
 
 class HipBackend {
@@ -524,7 +538,9 @@ class HipBackend {
         // block's parse grids; the workers of a members job leave it at the default.  Neither choice moved a measurement
         // beyond the run-to-run spread (bench 298...303 MB/s, eight encoders 454...557).  ORZ_RANK_PRIO=0/1 overrides.
         const char* rp = getenv("ORZ_RANK_PRIO");
-        rank_prio_ = rp ? atoi(rp) != 0 : lone;
+        rank_prio_ = rp ? atoi(rp) != 0 : false;  // (round 4: no priority stream unless asked for -- it never moved a measurement, and
+                                                  // one kind of stream set keeps every encoder of a process on the pool's first block)
+        (void)lone;
         {
             const StreamPool::Set t = StreamPool::get().take(device_, rank_prio_);
             for (int i = 0; i < kStreams; i++) streams_[i] = t.s[i];
