@@ -492,11 +492,14 @@ class StreamPool {
     // process goes on to create its encoders one, two, four or eight at a time: every encoder of the first eight runs on
     // the mapping a process's first eight encoders get (the good one, see above).  Later requests take what is free.
     static constexpr int kBlockSets = 8;
-    Set take(int device, bool rank_prio) {
+    // (`block` false: a lone encoder -- bin/orz, bench.py -- takes one set and does not pay for 32 stream creations, ~300 ms
+    // of a process's start)
+    Set take(int device, bool rank_prio, bool block) {
         std::lock_guard<std::mutex> lk(m_);
         auto& v = free_[{device, rank_prio}];
         if (v.empty()) {
-            const int n = made_[{device, rank_prio}] ? 1 : kBlockSets;
+            const int n = (!block || blocks_[{device, rank_prio}]) ? 1 : kBlockSets;
+            if (n > 1) blocks_[{device, rank_prio}] = 1;
             std::vector<Set> fresh;
             for (int k = 0; k < n; k++) fresh.push_back(create(rank_prio));
             made_[{device, rank_prio}] += n;
@@ -524,7 +527,7 @@ class StreamPool {
     }
     std::mutex m_;
     std::map<std::pair<int, bool>, std::vector<Set>> free_;
-    std::map<std::pair<int, bool>, int> made_;
+    std::map<std::pair<int, bool>, int> made_, blocks_;
 };
 
 class HipBackend {
@@ -542,7 +545,7 @@ class HipBackend {
                                                   // one kind of stream set keeps every encoder of a process on the pool's first block)
         (void)lone;
         {
-            const StreamPool::Set t = StreamPool::get().take(device_, rank_prio_);
+            const StreamPool::Set t = StreamPool::get().take(device_, rank_prio_, !lone);
             for (int i = 0; i < kStreams; i++) streams_[i] = t.s[i];
         }
         stream_ = streams_[0];
