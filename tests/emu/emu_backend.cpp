@@ -28,13 +28,42 @@ struct EmuBackend {
     uint64_t seed = 1;
     // (allocations the encoder asks for without a zero fill come back POISONED: the device hands out recycled memory, and
     // whatever the kernels read before they have written it must not matter)
+    // ORZ_EMU_ARENA_MB=<n>: every buffer carved out of one block (2 MiB-aligned when large, 256 B otherwise, like the HIP
+    // backend's ORZ_ARENA_MB), the block filled with pseudo-random bytes first: neighbours instead of unmapped slack behind
+    // every buffer, plausible garbage instead of a constant in what was not asked to be zeroed -- out-of-bounds and
+    // uninitialised reads change the output instead of passing unnoticed.
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    void* arena_take(size_t bytes) {
+        if (!arena) {
+            const char* v = std::getenv("ORZ_EMU_ARENA_MB");
+            if (!v || !std::atoi(v)) return nullptr;
+            arena_bytes = (size_t)std::atoi(v) << 20;
+            arena = (char*)std::malloc(arena_bytes);
+            uint64_t x = 0x9E3779B97F4A7C15ull;
+            for (size_t i = 0; i + 8 <= arena_bytes; i += 8) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::memcpy(arena + i, &x, 8); }
+        }
+        const size_t align = bytes >= (1u << 20) ? (2u << 20) : 256;
+        const size_t at = (arena_used + align - 1) / align * align;
+        if (at + bytes > arena_bytes) return nullptr;
+        arena_used = at + bytes;
+        return arena + at;
+    }
+    ~EmuBackend() { std::free(arena); }
     template <class T> T* alloc(size_t n, bool zero = true) {
+        if (void* q = arena_take((n ? n : 1) * sizeof(T))) {
+            if (zero) std::memset(q, 0, (n ? n : 1) * sizeof(T));
+            return (T*)q;
+        }
         if (zero) return (T*)std::calloc(n ? n : 1, sizeof(T));
         T* p = (T*)std::malloc((n ? n : 1) * sizeof(T));
         if (p) std::memset(p, std::getenv("ORZ_EMU_POISON") ? std::atoi(std::getenv("ORZ_EMU_POISON")) : 0xA5, (n ? n : 1) * sizeof(T));
         return p;
     }
-    void free(void* p) { std::free(p); }
+    void free(void* p) {
+        if (arena && (char*)p >= arena && (char*)p < arena + arena_bytes) return;
+        std::free(p);
+    }
     void release_arena() {}
     void parse_token_acquire() {}
     void parse_token_release() {}
