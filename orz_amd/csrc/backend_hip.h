@@ -615,8 +615,9 @@ class HipBackend {
     // falls back to hipMalloc.  Built in round 4 to test whether allocation placement explains why a process's later
     // encoders are slower (it does not: the streams' hardware queues do, see StreamPool).  What it is good for: buffers that
     // lie side by side turn an out-of-bounds access into a visible defect -- with it the exact mode's object-level test
-    // trips the validity gate (1,028 wrong excluded symbols in a 17 MB two-chunk block): some kernel of the exact parse
-    // reads or writes past a buffer's end, harmlessly with separate allocations.  Open.
+    // tripped the validity gate: rebuild_summaries (orz_parse.h) wrote 62 words past the word list's level-1 summary on
+    // every full block, into allocator slack with separate allocations, into the level-2 summary with neighbours.  Fixed;
+    // the knob stays for the next defect of that kind (the emulation has the same: ORZ_EMU_ARENA_MB).
     template <class T>
     T* alloc(size_t n, bool zero = true) {
         const size_t bytes = (n ? n : 1) * sizeof(T);

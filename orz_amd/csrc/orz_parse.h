@@ -218,7 +218,11 @@ ORZ_D void rebuild_summaries(const uint64_t* L0, uint64_t* L1, uint64_t* L2, uin
     uint16_t* piece = (uint16_t*)sh;  // [256] sixteen level-1 bits per thread
     piece[t] = (uint16_t)bits;
     sync();
-    if (t < 64)
+    // (only the level-1 words that summarise existing level-0 words: the last block of a full 16 MiB block's word-list bitmap
+    // -- 262,146 words, 65 blocks -- used to write 62 words past the level-1 array, zeros, harmless behind a buffer of its own
+    // and fatal beside a neighbour: with the encoder's buffers side by side they wiped the level-2 summary and the exact
+    // parse missed word updates.  Found in round 4 with ORZ_ARENA_MB / ORZ_EMU_ARENA_MB.)
+    if (t < 64 && (size_t)(blk * 64 + t) * 64 < nwords0)
         L1[blk * 64 + t] = (uint64_t)piece[4 * t] | ((uint64_t)piece[4 * t + 1] << 16) | ((uint64_t)piece[4 * t + 2] << 32) |
                            ((uint64_t)piece[4 * t + 3] << 48);
     if (t == 64) {

@@ -40,8 +40,12 @@ struct EmuBackend {
             if (!v || !std::atoi(v)) return nullptr;
             arena_bytes = (size_t)std::atoi(v) << 20;
             arena = (char*)std::malloc(arena_bytes);
-            uint64_t x = 0x9E3779B97F4A7C15ull;
-            for (size_t i = 0; i + 8 <= arena_bytes; i += 8) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::memcpy(arena + i, &x, 8); }
+            if (const char* f = std::getenv("ORZ_EMU_ARENA_FILL")) {  // (a constant instead: which of the two effects is it?)
+                std::memset(arena, std::atoi(f), arena_bytes);
+            } else {
+                uint64_t x = 0x9E3779B97F4A7C15ull;
+                for (size_t i = 0; i + 8 <= arena_bytes; i += 8) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::memcpy(arena + i, &x, 8); }
+            }
         }
         const size_t align = bytes >= (1u << 20) ? (2u << 20) : 256;
         const size_t at = (arena_used + align - 1) / align * align;
