@@ -175,3 +175,17 @@ def test_more_items_than_the_tail_buffers_start_with(emu, oracle):
     data = _data.random_bytes(6_800_000)
     out, _ = emu.fast(data)
     assert oracle.decode(out)[0] == data
+
+
+def test_buffers_side_by_side_change_nothing(emu, oracle, monkeypatch):
+    """ORZ_EMU_ARENA_MB: every buffer of the encoder carved out of one block of pseudo-random bytes -- neighbours instead of
+    slack behind each buffer, plausible garbage in what was not asked to be zeroed.  An out-of-bounds or uninitialised read
+    changes the stream (round 4 found the exact parse's summary rebuild that way, at full block size); both modes must write
+    what they write with a buffer of their own each."""
+    data = _data.mixed(300_000, seed=17) + _data.text(300_000, seed=18)
+    plain_fast, _ = emu.fast(data)
+    monkeypatch.setenv("ORZ_EMU_ARENA_MB", "7000")
+    side_fast, _ = emu.fast(data)
+    side_exact, _ = emu(data[:120_000])
+    assert side_fast == plain_fast
+    assert side_exact == oracle.encode(data[:120_000], 1)  # (the full-block case of round 4: tools/dev, 57 minutes of CPU)
