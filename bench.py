@@ -69,6 +69,137 @@ def cpu_baseline(data, level):
     }
 
 
+def _meminfo_available_bytes():
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
+
+
+def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, device=0):
+    """Outside the timed region, rank 0 at N=1 only: the aggregate path of BASELINE configs[2]/[3] on ONE GPU and its CPU baseline
+    (the reference's harness, /root/reference/benchmark-tool/src/main.rs:57-114, times an encoder
+    process and verifies its output by decoding it).
+      members               `jobs` stream encoders on the GPU over `total` bytes of the workload cut into members of
+                            `member_bytes` (input resident in HBM) -> MB/s; every member's stream through the ORACLE's decoder
+                            (one `oracle/orz_oracle decode` process each); size against the oracle's encoder on the same split
+      cpu_baseline_members  one `oracle/orz_oracle encode` process per host core, each encoding one of the same members, all
+                            started together: bytes encoded / wall time (tmpfs file reads and writes included)
+    """
+    import torch
+
+    import orz_amd
+    from orz_amd import dist as odist
+
+    data = (base * (total // len(base) + 1))[:total]
+    members = [data[i:i + member_bytes] for i in range(0, len(data), member_bytes)]
+    # ---- GPU: `jobs` encoders, input in HBM
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(torch.device("cuda", device))
+    torch.cuda.synchronize()
+    enc = orz_amd.MemberEncoder(device=device, level=level, jobs=jobs)
+    enc.encode(data[: jobs * (1 << 20)], member_bytes=1 << 20)  # warm-up: allocations, first launches
+    t0 = time.time()
+    blob, n = enc.encode_device(src.data_ptr(), src.numel(), member_bytes=member_bytes)
+    t_gpu = time.time() - t0
+    enc.close()
+    del src
+    streams = odist.split_members(blob)
+    assert n == len(members) == len(streams)
+    res = members_check_and_cpu(members, streams, level)
+    gpu_mbs = len(data) / t_gpu / 1e6
+    res["members"].update({"value": round(gpu_mbs, 1), "unit": "MB/s", "encoders_on_one_gpu": jobs, "seconds": round(t_gpu, 3),
+                           "input": "resident in HBM",
+                           "pipeline_frac_of_hbm_peak": round(ALGO_BYTES_PER_INPUT_BYTE * gpu_mbs / 1e3 / HBM_PEAK_GBS, 8)})
+    res["gpu_over_cpu_members"] = round(gpu_mbs / res["cpu_baseline_members"]["value"], 4)
+    return res
+
+
+def members_check_and_cpu(members, streams, level, max_procs=None):
+    """the host half of members_leg: `streams[k]` must decode to `members[k]` with the oracle's decoder (a process each);
+    the oracle's encoder on the same members, one process per host core, timed"""
+    import shutil
+    import subprocess
+    import tempfile
+
+    import _oracle
+
+    _oracle.lib()  # (builds oracle/ when absent)
+    cli = _oracle.CLI
+    n = len(members)
+    total = sum(len(m) for m in members)
+    member_bytes = len(members[0]) if members else 0
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 12 * total // 10 + (8 << 30) else None
+    work = tempfile.mkdtemp(prefix="orz_bench_", dir=root)
+    try:
+        for k, m in enumerate(members):
+            with open(os.path.join(work, "m%d.in" % k), "wb") as f:
+                f.write(m)
+            with open(os.path.join(work, "g%d.orz" % k), "wb") as f:
+                f.write(streams[k])
+        # ---- every member's stream through the oracle's decoder
+        t0 = time.time()
+        procs = [subprocess.Popen([cli, "decode", os.path.join(work, "g%d.orz" % k), os.path.join(work, "g%d.out" % k)],
+                                  stderr=subprocess.DEVNULL) for k in range(n)]
+        rcs = [p.wait() for p in procs]
+        bad = []
+        for k in range(n):
+            ok = rcs[k] == 0
+            if ok:
+                with open(os.path.join(work, "g%d.out" % k), "rb") as f:
+                    ok = hashlib.sha256(f.read()).digest() == hashlib.sha256(members[k]).digest()
+            if not ok:
+                bad.append(k)
+            try:
+                os.remove(os.path.join(work, "g%d.out" % k))
+            except OSError:
+                pass
+        t_dec = time.time() - t0
+        # ---- CPU: one oracle process per host core (bounded by memory: a process holds ~0.25 GB at 64 MiB members)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        avail = _meminfo_available_bytes()
+        nproc = cores if avail is None else max(1, min(cores, int(avail * 0.6) // (256 << 20)))
+        if max_procs:
+            nproc = min(nproc, max_procs)
+        t0 = time.time()
+        procs = [subprocess.Popen([cli, "encode", "-l%d" % level, os.path.join(work, "m%d.in" % (k % n)), os.path.join(work, "c%d.orz" % k)],
+                                  stderr=subprocess.DEVNULL) for k in range(nproc)]
+        rcs = [p.wait() for p in procs]
+        t_cpu = time.time() - t0
+        assert all(rc == 0 for rc in rcs), "an oracle encoder process failed"
+        cpu_bytes = sum(len(members[k % n]) for k in range(nproc))
+        # sizes of the same split by the oracle's encoder (members the per-core pass did not reach are encoded now)
+        missing = [k for k in range(n) if k >= nproc]
+        for lo in range(0, len(missing), nproc):
+            ps = [subprocess.Popen([cli, "encode", "-l%d" % level, os.path.join(work, "m%d.in" % k), os.path.join(work, "c%d.orz" % k)])
+                  for k in missing[lo:lo + nproc]]
+            assert all(p.wait() == 0 for p in ps)
+        ref_sizes = [os.path.getsize(os.path.join(work, "c%d.orz" % k)) for k in range(n)]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    gpu_sizes = [len(s) for s in streams]
+    cpu_mbs = cpu_bytes / t_cpu / 1e6
+    return {
+        "members": {
+            "members": n, "member_bytes": member_bytes, "bytes": total, "level": level,
+            "compressed_bytes": sum(gpu_sizes), "oracle_compressed_bytes_same_split": sum(ref_sizes),
+            "size_delta_pct": round(100.0 * (sum(gpu_sizes) - sum(ref_sizes)) / max(1, sum(ref_sizes)), 4),
+            "roundtrip_ok": not bad, "members_not_decoding": bad,
+            "roundtrip_checker": "oracle decoder, one process per member, %.2f s" % t_dec,
+        },
+        "cpu_baseline_members": {
+            "value": round(cpu_mbs, 1), "unit": "MB/s", "cores": nproc, "kind": "port", "host_cores_available": cores,
+            "sample": "%d oracle processes started together, one per host core, each encoding one %d-byte member of the same split (-l%d); "
+                      "%d bytes in %.2f s wall, file reads and writes on %s included" % (nproc, member_bytes, level, cpu_bytes, t_cpu,
+                                                                                     "tmpfs" if root else "the temp dir"),
+            "per_core_MBps": round(cpu_mbs / nproc, 2),
+        },
+    }
+
+
 def oracle_check(data, stream):
     """outside the timed region: the stream the timed passes produced goes through the ORACLE's decoder"""
     import _oracle
@@ -107,6 +238,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=WORKLOAD_BYTES, help="workload size (default: BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-members", action="store_true", help="skip the members leg (8 encoders on one GPU + its many-core CPU baseline)")
+    ap.add_argument("--members-bytes", type=int, default=1_000_000_000)
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
                     help="fast: GPU-native parse (reference-decodable, size within +-0.5 %%); exact: the reference's parse item for item")
     args = ap.parse_args()
@@ -293,6 +426,12 @@ def main():
             res["size_delta_pct"] = round(100.0 * (len(out) - ref) / ref, 4)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
+        if world == 1 and not args.no_members:
+            enc.close()  # (the lone encoder's ~5 GB go back before eight more are built)
+            try:
+                res.update(members_leg(base, LEVEL, total=args.members_bytes, device=local_rank))
+            except Exception as e:  # the headline line must not be lost to its annex
+                res["members"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(res), flush=True)
     enc.close()
     if distributed:
