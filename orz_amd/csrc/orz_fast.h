@@ -80,6 +80,8 @@ struct FastArgs {
     // dynamic
     uint64_t *vbits, *kbits;    // item-start / word-update bitmaps in slot order
     uint64_t* v1;               // bit per non-zero word of vbits (V1Build once per parse, then kept in step by FastFlip)
+    uint64_t* k1;               // the same for kbits (zeroed with it; only ever set: a stale bit costs a search one wasted load)
+    uint64_t* tbits;            // [n/64+2] repair stage: positions whose item-start bit or end type was rewritten since the last flip
     uint32_t* ev;               // [n+8] best len | lz1 << 8 | lz2 << 16 | lwm << 24 | ro510 << 25
     uint8_t *ty, *nl, *pt;      // [n+264] decision type, advance, type of the item ending at the position
     uint64_t* sbits;            // [n/64+8] item starts of the current path, bit per new position
@@ -1206,6 +1208,10 @@ struct FastFlip {
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t y = lo + (uint32_t)tid;
         if (y > hi) return;
+        flip_one(y, nullptr);
+    }
+    // kdirty (repair stage): one bit per hash2 key whose word-update bits changed -- the WORD items of those keys are judged again
+    ORZ_D void flip_one(uint32_t y, uint64_t* kdirty) const {
         const uint32_t i = y - kPre;
         const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;  // where the path leaves the range / the block
         const uint32_t mf = a.mfb[i], ef = a.efb[i];
@@ -1231,8 +1237,10 @@ struct FastFlip {
         if (de) {
             if (a.dbg & 64) atom_add64(&a.stats[17], 1);
             atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+            if (ew) atom_or64(&a.k1[ku >> 12], 1ull << ((ku >> 6) & 63));
             a.efb[i] = (uint8_t)ew;
             mark(true, ku, nk);
+            if (kdirty) { const uint32_t key2 = hash2(a.win, y - 3); atom_or64(&kdirty[key2 >> 6], 1ull << (key2 & 63)); }
         }
     }
 };
@@ -1336,12 +1344,15 @@ struct FastCtl {
     uint32_t lastflips;  // item starts that still changed in their tile's LAST round (FastFlip): the rounds had not settled
     uint32_t nent;       // slots of the block's candidate lists -- read by the kernels of the round loop from HERE, not from their
                          // arguments: the loop is replayed as a graph whose arguments are those of the block it was captured on
+    uint32_t ncut, nfix;  // entries of the running pass's cut list (FastSource -> FastRecutL) / WORD-fix list (FastWordCheckL -> FastWordApplyL)
+    uint32_t nwx;         // ... and of the list of WORD items FastRecut made in this pass (the subtiles' lists were drawn up before it)
 };
 struct FastCtlReset {
     FastCtl* ctl;
     ORZ_HD void operator()(size_t tid) const {
         if (tid) return;
         ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;  // (lastflips: reset before the rounds)
+        ctl->ncut = 0; ctl->nfix = 0; ctl->nwx = 0;
     }
 };
 struct FastSetNent {
@@ -1361,6 +1372,83 @@ struct FastPassEnd {
         ctl->chg = 0;
         ctl->nmem = ctl->acc;
         ctl->acc = 0;
+        ctl->ncut = 0; ctl->nfix = 0; ctl->nwx = 0;  // (the lists of the pass were consumed by FastRecutL / FastWordApplyL)
+    }
+};
+// ---- the repair stage over lists (round 5) --------------------------------------------------------------------------------
+// A pass used to be a dozen grids over all 2^24 positions of which a few thousand had work.  Now: per 4096-position subtile the
+// items that a pass can touch are listed once per pass (RepairListWave: matches, WORD items -- u16 offsets, in position order,
+// no atomics), the kernels that judge them run over those lists, what they decide goes to short lists with a counter (cuts,
+// WORD fixes), and the positions whose bits the rewrite kernels change are noted in `tbits` so that the flips of the slot-order
+// bitmaps visit those only (FastFlipSparse).  Same decisions, same bytes; the rule of the stage stands: a thread acts only on
+// state written by an EARLIER launch.
+constexpr uint32_t kSubMatches = kSub / kMinLen;  // a subtile holds at most 1024 matches (4 bytes each at least)
+constexpr uint32_t kSubWords = kSub / 2;          // ... and 2048 WORD items
+constexpr uint32_t kListThreads = 256;            // threads per subtile in the kernels that run over the lists
+ORZ_D void touch(const FastArgs& a, uint32_t y) {  // y = window offset in [kPre, len]
+    const uint32_t i = y - kPre;
+    atom_or64(&a.tbits[i >> 6], 1ull << (i & 63));
+}
+struct FastFlipSparse {  // thread per word of tbits
+    FastFlip f;          // (lo / hi unused; mark_hi = last_hi = 0, next_entry = ~0u)
+    uint32_t nwords;     // words of tbits that can hold a bit: positions kPre .. len
+    uint64_t* kdirty;
+    ORZ_HD void operator()(size_t w) const {
+        if (w >= nwords) return;
+        uint64_t m = f.a.tbits[w];
+        if (!m) return;
+        f.a.tbits[w] = 0;
+        while (m) {
+            const uint32_t t = (uint32_t)ctz64(m);
+            m &= m - 1;
+            f.flip_one(kPre + (uint32_t)w * 64 + t, kdirty);
+        }
+    }
+};
+// One wavefront per subtile, lane = 64 positions: the subtile's item starts per ctx (what CountWave counts) and its matches
+// and WORD items as lists of offsets inside the subtile, in position order (a prefix sum over the lanes' counts).
+struct RepairListWave {
+    FastArgs a;
+    uint16_t *mlist, *wlist;  // [nsub][kSubMatches], [nsub][kSubWords]
+    uint32_t *mcnt, *wcnt;    // [nsub]
+    static size_t lds_bytes() { return 256 * 4; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        uint32_t* cnt = (uint32_t*)w.lds();
+        const uint32_t s = w.block(), lane = w.lane();
+        for (uint32_t c = lane; c < 256; c += 64) cnt[c] = 0;
+        w.sync();
+        const uint32_t i0 = s * kSub + lane * 64;
+        uint64_t mm = 0, wm = 0;  // the lane's matches / WORD items
+        if (i0 < a.n) {
+            uint64_t m = a.sbits[i0 / 64];
+            const uint8_t* b = a.win + kPre + i0;
+            while (m) {
+                const uint32_t t = (uint32_t)ctz64(m);
+                m &= m - 1;
+                if (i0 + t >= a.n) break;
+                atom_add32(&cnt[(uint32_t)(b[(int)t - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)t - 2]) << 7)], 1);
+                const uint32_t ty = a.ty[i0 + t];
+                if (ty == kTyMatch) mm |= 1ull << t;
+                else if (ty == kTyWord) wm |= 1ull << t;
+            }
+        }
+        // exclusive prefix of the two counts over the lanes (packed: matches in the low half)
+        const uint32_t mine = (uint32_t)popc64(mm) | ((uint32_t)popc64(wm) << 16);
+        uint32_t v = mine;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t t = w.shfl(v, lane >= d ? lane - d : lane);
+            if (lane >= d) v += t;
+        }
+        const uint32_t tot = w.bcast(v, 63);
+        uint32_t mo = (v - mine) & 0xffff, wo = (v - mine) >> 16;
+        uint16_t* ml = mlist + (size_t)s * kSubMatches;
+        uint16_t* wl = wlist + (size_t)s * kSubWords;
+        while (mm) { const uint32_t t = (uint32_t)ctz64(mm); mm &= mm - 1; ml[mo++] = (uint16_t)(lane * 64 + t); }
+        while (wm) { const uint32_t t = (uint32_t)ctz64(wm); wm &= wm - 1; wl[wo++] = (uint16_t)(lane * 64 + t); }
+        if (lane == 0) { mcnt[s] = tot & 0xffff; wcnt[s] = tot >> 16; }
+        w.sync();
+        for (uint32_t c = lane; c < 256; c += 64) a.cm[(size_t)s * 256 + c] = cnt[c];
     }
 };
 struct FastItemTotal {  // item starts of the block from the per-ctx ordinals (thread per ctx)
@@ -1436,6 +1524,8 @@ struct FastSource {
     const FastCtl* ctl;
     uint8_t* edge;         // [n] the match's source is near the end of the ring
     const uint32_t* cok;   // [256] the context has gained at most kEdgeMargin item starts since the first pass
+    uint32_t* cutlist = nullptr;  // the items cut in this pass (FastRecutL; nullptr: FastRecut looks at every position)
+    uint32_t* ncut = nullptr;
     static constexpr uint32_t kEdgeMargin = 1024;
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || ctl->done || !((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyMatch) return;
@@ -1490,6 +1580,7 @@ struct FastSource {
         if (found) { SRC[p] = found; edge[i] = op - 1 - a.ORD[found] > kRing - 1 - kEdgeMargin; return; }
         atom_add32(a.nchg, 1);
         cutend[i] = p + L;
+        if (cutlist) cutlist[atom_fetch_add32(ncut, 1)] = (uint32_t)i;
         if (best >= kMinLen) { a.nl[i] = (uint8_t)best; SRC[p] = bsrc; edge[i] = op - 1 - a.ORD[bsrc] > kRing - 1 - kEdgeMargin; }
         else { a.ty[i] = kTyLit; a.nl[i] = 1; }
     }
@@ -1512,12 +1603,15 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
     FastArgs a;
     uint32_t* cutend;
     uint64_t* rdirty;  // runs that gain an item start here (read by the next pass's FastSource)
+    uint32_t* wextra = nullptr;  // list form: the WORD items made here (this pass's FastWordCheckL judges them: the subtiles' lists
+    uint32_t* nwx = nullptr;     // were drawn up before); the positions rewritten are noted in a.tbits for FastFlipSparse
     ORZ_HD void operator()(size_t i) const {
         if (i >= a.n || !cutend[i]) return;  // (nothing is cut once the passes are done)
         const uint32_t end = cutend[i];
         cutend[i] = 0;
         uint32_t x = kPre + (uint32_t)i + a.nl[i];
         a.pt[x - kPre] = a.ty[i];
+        if (wextra) touch(a, x);
         while (x < end) {
             const uint32_t xi = x - kPre;
             uint32_t t = a.ty[xi], L = a.nl[xi];
@@ -1529,9 +1623,33 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
             a.ty[xi] = (uint8_t)t; a.nl[xi] = (uint8_t)L;
             atom_or64(&a.sbits[xi / 64], 1ull << (xi & 63));
             mark_run(a.win, rdirty, x);
+            if (wextra && t == kTyWord) wextra[atom_fetch_add32(nwx, 1)] = xi;
             x += L;
             a.pt[x - kPre] = (uint8_t)t;
+            if (wextra) touch(a, x);  // (the item start at x - L was touched as the end of the item before it)
         }
+    }
+};
+struct FastRecutL {  // the same over the pass's cut list
+    FastRecut f;
+    const uint32_t* cutlist;
+    const FastCtl* ctl;
+    uint32_t nthreads;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t n = ctl->ncut;
+        for (uint32_t k = (uint32_t)tid; k < n; k += nthreads) f(cutlist[k]);
+    }
+};
+struct FastSourceL {  // FastSource over the subtiles' match lists: kListThreads threads a subtile
+    FastSource f;
+    const uint16_t* mlist;
+    const uint32_t* mcnt;
+    uint32_t nsub;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t s = (uint32_t)(tid / kListThreads);
+        if (s >= nsub || f.ctl->done) return;
+        const uint32_t c = mcnt[s];
+        for (uint32_t k = (uint32_t)(tid % kListThreads); k < c; k += kListThreads) f((size_t)s * kSub + mlist[(size_t)s * kSubMatches + k]);
     }
 };
 struct KbitVals {  // v[s] = s + 1 where the word-update bit of slot s is set, else 0 (for the running maximum)
@@ -1589,6 +1707,94 @@ struct FastWordApply {  // thread per position: acts on the flags of the launch 
         atom_or64(&a.sbits[(i + 1) / 64], 1ull << ((i + 1) & 63));
         mark_run(a.win, rdirty, p + 1);
         a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
+    }
+};
+// The newest word update among the slots [klo, below) of the word list WITHOUT the running maximum: the highest set bit of
+// kbits there, through the summary level (returns slot + 1, 0 = none).  The later repair passes ask for a handful of WORD
+// items only (those of keys whose update bits changed); a scan over all 2^24 slots per pass was 0.1 ms of each.
+ORZ_D uint32_t kbits_prev(const FastArgs& a, uint32_t klo, uint32_t below) {
+    if (below <= klo) return 0;
+    const uint32_t wlo = klo >> 6;
+    uint32_t wi = (below - 1) >> 6;
+    uint64_t m = a.kbits[wi];
+    if (below & 63) m &= (1ull << (below & 63)) - 1;
+    for (;;) {
+        if (wi == wlo) m &= ~0ull << (klo & 63);
+        if (m) return wi * 64 + 63 - (uint32_t)clz64(m) + 1;
+        if (wi == wlo) return 0;
+        // the next non-empty word below wi, by the summary (bit per word; a stale set bit only costs the load of an empty word)
+        uint32_t nw = wi - 1;
+        uint64_t sm = a.k1[nw >> 6];
+        if ((nw & 63) != 63) sm &= (2ull << (nw & 63)) - 1;
+        while (!sm) {
+            if ((nw >> 6) == 0 || (nw >> 6) <= (wlo >> 6)) return 0;
+            nw = ((nw >> 6) << 6) - 1;
+            sm = a.k1[nw >> 6];
+        }
+        wi = (nw & ~63u) + 63 - (uint32_t)clz64(sm);
+        if (wi < wlo) return 0;
+        m = a.kbits[wi];
+    }
+}
+ORZ_D uint32_t fast_word_search(const FastArgs& a, uint32_t p) {  // = fast_word_at, from the bitmap itself
+    const uint32_t key2 = hash2(a.win, p - 1);
+    const uint32_t kj = a.kidx[p], klo = a.krun[key2];
+    uint32_t below = kj;
+    if (kj > klo && hash2(a.win, p - 2) == key2) below = kj - 1;
+    const uint32_t le = kbits_prev(a, klo, below);
+    if (le > klo) return a.kw[le - 1];
+    return (uint32_t)a.wsnap[key2 * 2] | ((uint32_t)a.wsnap[key2 * 2 + 1] << 8);
+}
+struct FastWordCheckL {  // FastWordCheck over the subtiles' WORD lists; the verdicts go to a list
+    FastArgs a;
+    const uint32_t* laste;   // the first pass: the running maximum, every WORD item; later passes (nullptr): only the items of
+    const uint64_t* kdirty;  // keys whose update bits changed since they were judged (FastFlipSparse), by search -- and the
+    const uint32_t* wextra;  // WORD items this pass's FastRecut made, whatever their keys
+    uint32_t* fixlist;
+    FastCtl* ctl;
+    const uint16_t* wlist;
+    const uint32_t* wcnt;
+    uint32_t nsub;
+    ORZ_D void check(uint32_t i, bool fresh) const {
+        if (!((a.sbits[i / 64] >> (i & 63)) & 1) || a.ty[i] != kTyWord) return;
+        const uint32_t p = kPre + i;
+        uint32_t w;
+        if (laste) w = fast_word_at(a, laste, p);
+        else {
+            const uint32_t key2 = hash2(a.win, p - 1);
+            if (!fresh && !((kdirty[key2 >> 6] >> (key2 & 63)) & 1)) return;
+            w = fast_word_search(a, p);
+        }
+        if (w == ((uint32_t)a.win[p] | ((uint32_t)a.win[p + 1] << 8))) return;
+        fixlist[atom_fetch_add32(&ctl->nfix, 1)] = i;
+    }
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t s = (uint32_t)(tid / kListThreads);
+        if (s >= nsub || ctl->done) return;
+        const uint32_t c = wcnt[s];
+        for (uint32_t k = (uint32_t)(tid % kListThreads); k < c; k += kListThreads) check(s * kSub + wlist[(size_t)s * kSubWords + k], false);
+        const uint32_t nx = ctl->nwx, nth = nsub * kListThreads;
+        for (uint32_t k = (uint32_t)tid; k < nx; k += nth) check(wextra[k], true);
+    }
+};
+struct FastWordApplyL {  // FastWordApply over the fix list (a launch of its own: see FastWordCheck)
+    FastArgs a;
+    const uint32_t* fixlist;
+    uint64_t* rdirty;
+    const FastCtl* ctl;
+    uint32_t nthreads;
+    ORZ_HD void operator()(size_t tid) const {
+        const uint32_t n = ctl->nfix;
+        for (uint32_t k = (uint32_t)tid; k < n; k += nthreads) {
+            const uint32_t i = fixlist[k], p = kPre + i;
+            atom_add32(a.nchg, 1);
+            a.ty[i] = kTyLit; a.nl[i] = 1;
+            a.ty[i + 1] = kTyLit; a.nl[i + 1] = 1;
+            atom_or64(&a.sbits[(i + 1) / 64], 1ull << ((i + 1) & 63));
+            mark_run(a.win, rdirty, p + 1);
+            a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
+            touch(a, p + 1); touch(a, p + 2);
+        }
     }
 };
 #if defined(ORZ_RACE_SELFTEST)

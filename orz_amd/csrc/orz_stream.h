@@ -270,6 +270,7 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
     static constexpr uint32_t kDirtyWords = kNumKeys / 64 + 1;  // one bit per (ctx, hash) run
+    static constexpr uint32_t kRepairGrid = 16384;              // threads of the kernels that run over the repair stage's short lists
 
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
     // per Gauss-Seidel tile (a multiple of 4096), `fast_rounds` rounds per tile
@@ -738,6 +739,24 @@ class StreamEncoder {
         a.ty = fty_; a.nl = fnl_; a.pt = fpt_; a.sbits = fsbits_; a.mfb = fmf_; a.efb = fef_; a.dirty = fdirty_; a.hz = fhz_;
         a.x0 = fx0_; a.x1 = fx1_; a.x2 = fx2_;
         a.cl = fcl_; a.ccnt = fccnt_; a.cnew = fcnew_; a.rounds = frounds_;
+        // Repair stage over lists (round 5, orz_fast.h): its lists live in the first sort buffer, which is idle between the prep's
+        // sorts and the post stage's.  ORZ_FAST_REPAIR=grid: every pass as grids over all positions (the form of rounds 2-4).
+        static const bool repair_lists = !(getenv("ORZ_FAST_REPAIR") && !strcmp(getenv("ORZ_FAST_REPAIR"), "grid"));
+        const uint32_t nsub_max = kNewMax / kSub + 2;
+        uint8_t* scratch = reinterpret_cast<uint8_t*>(entA_);
+        auto carve = [&](size_t bytes) { uint8_t* q = scratch; scratch += (bytes + 255) & ~(size_t)255; return q; };
+        uint16_t* mlist = reinterpret_cast<uint16_t*>(carve((size_t)nsub_max * kSubMatches * 2));
+        uint16_t* wlist = reinterpret_cast<uint16_t*>(carve((size_t)nsub_max * kSubWords * 2));
+        uint32_t* mcnt = reinterpret_cast<uint32_t*>(carve((size_t)nsub_max * 4));
+        uint32_t* wcnt = reinterpret_cast<uint32_t*>(carve((size_t)nsub_max * 4));
+        uint32_t* cutlist = reinterpret_cast<uint32_t*>(carve(((size_t)kNewMax / kMinLen + 64) * 4));
+        uint32_t* fixlist = reinterpret_cast<uint32_t*>(carve(((size_t)kNewMax / 2 + 64) * 4));
+        uint32_t* wextra = reinterpret_cast<uint32_t*>(carve(((size_t)kNewMax / 2 + 64) * 4));
+        const size_t tbits_bytes = ((size_t)kNewMax / 64 + 8) * 8, kdirty_bytes = 512 * 8;
+        uint64_t* tbits = reinterpret_cast<uint64_t*>(carve(tbits_bytes));
+        uint64_t* kdirty = reinterpret_cast<uint64_t*>(carve(kdirty_bytes));
+        if ((size_t)(scratch - reinterpret_cast<uint8_t*>(entA_)) > (size_t)kWLen * 8) throw std::runtime_error("repair lists do not fit the sort buffer");
+        a.k1 = k1_; a.tbits = tbits;
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 16;
         // (candidates beyond the reference's depth: half as many again -- a third at shallow depths -- keeps the sizes centred
         // on the reference's: text, full block, -l0 / -l1 / -l2: -0.20 / 0.00 / +0.17 %; 6 MB at -l0: -0.53 / -0.36 / -0.18 %
@@ -772,6 +791,7 @@ class StreamEncoder {
                 be_.launch(nent, FastListReset{win, epos_, nent, fccnt_});
             }
             be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
+            be_.memset(k1_, 0, ((size_t)kNewMax / 4096 + 2) * 8);
             be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             const size_t nn = (size_t)n + 264;
             // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
@@ -858,9 +878,46 @@ class StreamEncoder {
             FastCtl h{};
             be_.launch(1, FastCtlReset{fctl_});
             int pass = 0;
+            if (repair_lists) {
+                be_.memset(tbits, 0, tbits_bytes);
+                be_.memset(kdirty, 0, kdirty_bytes);
+            }
+            const FastFlip flip_all{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips};
+            const uint32_t tw = n / 64 + 1;  // words of tbits that can hold a bit (positions kPre .. len)
             for (int group = 0; group < 64 && !h.done; group++) {
                 const int todo = group == 0 ? 6 : 2;  // (text: five passes that repair something and one that finds nothing)
-                for (int k = 0; k < todo; k++, pass++) {
+                for (int k = 0; k < todo && repair_lists; k++, pass++) {
+                    // the bitmaps in slot order follow the path: everywhere before the first pass, from then on at the positions
+                    // the repair kernels rewrote
+                    if (pass == 0) be_.launch((size_t)n + 1, flip_all);
+                    else be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
+                    // exact ordinals of the item starts (per-(subtile, ctx) counts, their prefix, rank inside the subtile) and the
+                    // subtiles' lists of matches and WORD items
+                    be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt}, RepairListWave::lds_bytes());
+                    col_scan(fcm_, nsub, fcp_);
+                    be_.launch(256, FastItemTotal{fcp_, nsub, fctl_});
+                    be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
+                    uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
+                    uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
+                    be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
+                    be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
+                    FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
+                    fs.cutlist = cutlist; fs.ncut = &fctl_->ncut;
+                    be_.launch((size_t)nsub * kListThreads, FastSourceL{fs, mlist, mcnt, nsub});
+                    FastRecut rc{a, fcut_, rd_out};
+                    rc.wextra = wextra; rc.nwx = &fctl_->nwx;
+                    be_.launch(kRepairGrid, FastRecutL{rc, cutlist, fctl_, kRepairGrid});
+                    be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
+                    if (pass == 0) {  // every WORD item against the running maximum of the update bits; later passes search (FastWordCheckL)
+                        be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                        be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                    }
+                    be_.launch((size_t)nsub * kListThreads, FastWordCheckL{a, pass == 0 ? flaste_ : nullptr, kdirty, wextra, fixlist, fctl_, wlist, wcnt, nsub});
+                    be_.memset(kdirty, 0, kdirty_bytes);
+                    be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fctl_, kRepairGrid});
+                    be_.launch(1, FastPassEnd{fctl_});
+                }
+                for (int k = 0; k < todo && !repair_lists; k++, pass++) {
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
                     be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
@@ -873,9 +930,6 @@ class StreamEncoder {
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
                     // (the round loop's dirty flags are dead by now: their array holds the sources' ring-edge flags)
-                    // (a later pass as a sweep -- a thread per 64 positions that settles from the item-start word and the
-                    // type / edge bytes which matches need another look -- measured no faster: 330 vs 350 us, the threads
-                    // that do find work run it one match after the other)
                     be_.launch(n, FastSource{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256});
                     be_.launch(n, FastRecut{a, fcut_, rd_out});
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
@@ -890,6 +944,10 @@ class StreamEncoder {
                     be_.launch(1, FastPassEnd{fctl_});
                 }
                 be_.d2h(&h, fctl_, sizeof h);
+            }
+            if (repair_lists && h.done && h.passes > 1) {  // the running maximum of the FINAL update bits (FastCommit, FastWordsCarry)
+                be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                be_.inclusive_max_scan_u32(f32_, flaste_, nk);
             }
             if (!h.done) throw std::runtime_error("fast parse: repairs did not converge");
             hfin_ = h;

@@ -4,7 +4,7 @@ import sqlite3
 import sys
 
 
-def summarize(db_path, out_path=None, top=40):
+def summarize(db_path, out_path=None, top=80):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     rows = cur.execute(
