@@ -120,6 +120,16 @@ int orz_stream_get_kernel_times(orz_stream*, double* ms4, uint64_t* launches4);
  * runs as one hipGraph replay per block (its launch sequence is the same for every full block); brackets need
  * individual launches, so a profiled encode is slower than a normal one -- use it for the roofline leg only. */
 int orz_stream_set_profile(orz_stream*, int on);
+/* Profile mode, all of it: EVERY kernel (and library call: sorts, scans, fills) of the last profiled orz_stream_encode made with
+ * stats != NULL, by name, HIP-event time summed over its launches, largest first.  Returns the number of rows the encode
+ * produced (copy at most `cap` of them into `rows`; rows == NULL just counts).  bench.py's per-kernel table and DESIGN.md 6
+ * are generated from this (tools/kernel_table.py). */
+typedef struct {
+    char name[64];
+    double ms;
+    uint64_t launches;
+} orz_kernel_row;
+long orz_stream_get_kernel_table(orz_stream*, orz_kernel_row* rows, size_t cap);
 /* tuning: bytes per speculative segment and segments per sweep window (0 = keep) */
 int orz_stream_set_tuning(orz_stream*, unsigned seg_bytes, unsigned window_segs);
 /* Encode `n` bytes at `src` (host memory, or device memory when src_on_device != 0) into a

@@ -41,6 +41,10 @@ class EncodeStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class KernelRow(ctypes.Structure):  # orz_kernel_row
+    _fields_ = [("name", ctypes.c_char * 64), ("ms", ctypes.c_double), ("launches", ctypes.c_uint64)]
+
+
 class StreamConfig(ctypes.Structure):  # orz_stream_config
     _fields_ = [
         ("mode", ctypes.c_int), ("segment_bytes", ctypes.c_uint), ("window_segments", ctypes.c_uint),
@@ -118,6 +122,7 @@ SYMBOLS = [
     ("orz_stream_get_config", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StreamConfig)]),
     ("orz_stream_set_profile", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("orz_stream_get_kernel_times", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+    ("orz_stream_get_kernel_table", ctypes.c_long, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     (
         "orz_stream_encode",
         ctypes.c_int,

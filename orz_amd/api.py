@@ -99,6 +99,15 @@ class StreamEncoder:
         _check(self._lib.orz_stream_get_kernel_times(self._h, ms, n), "orz_stream_get_kernel_times")
         return [(ms[i], n[i]) for i in range(4)]
 
+    def kernel_table(self):
+        """[(name, ms, launches)] of EVERY kernel of the last encode(stats=True) made in profile mode, largest first"""
+        n = self._lib.orz_stream_get_kernel_table(self._h, None, 0)
+        if n <= 0:
+            return []
+        rows = (_native.KernelRow * n)()
+        self._lib.orz_stream_get_kernel_table(self._h, ctypes.cast(rows, ctypes.c_void_p), n)
+        return [(r.name.decode(), r.ms, int(r.launches)) for r in rows]
+
     def set_tuning(self, seg_bytes=0, window_segs=0):
         _check(self._lib.orz_stream_set_tuning(self._h, seg_bytes, window_segs), "orz_stream_set_tuning")
 

@@ -8,8 +8,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+
 #include <chrono>
 #include <condition_variable>
+#include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <rocprim/rocprim.hpp>
@@ -108,8 +113,12 @@ __global__ __launch_bounds__(256) void orz_rank_kernel(RankArgs a, uint32_t nchu
 // those ranks; index[] for the symbols that sit there).  Items are fetched 64 at a time into a register and
 // handed out with v_readlane; the ranks go back through v_writelane the same way.
 __device__ __forceinline__ int orz_writelane(int old, uint32_t sval, uint32_t slane) {  // old[slane] = sval (both uniform)
-    // (VOP3 reads one SGPR only: the lane select travels in M0)
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sval), "s"(slane) : "m0");
+    // (VOP3 reads one SGPR only: the lane select travels in M0 -- which the compiler does not let an asm statement clobber
+    // ("may not be preserved across the asm statement"), so the statement puts back what it found there)
+    uint32_t m0_was;
+    asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[ln]\n\tv_writelane_b32 %[o], %[val], m0\n\ts_mov_b32 m0, %[sv]"
+                 : [o] "+v"(old), [sv] "=&s"(m0_was)
+                 : [val] "s"(sval), [ln] "s"(slane));
     return old;
 }
 __device__ __forceinline__ uint32_t orz_ff1(uint64_t m) {  // index of the lowest set bit, 0xffffffff for 0 (s_ff1_i32_b64)
@@ -332,7 +341,9 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
     ORZ_LEAF(G, G2, NEXT, "v2", "v2", "v1")                                                                              \
     P "22:\n\t"                                                                                                          \
     ORZ_LEAF(G, G2, NEXT, "v2", "v1", "v1")
+                uint32_t m0_was;  // (the block moves lane selects through M0 and restores it at its one exit)
                 asm volatile(
+                    "s_mov_b32 %[m0s], m0\n\t"
                     "v_readlane_b32 %[g], %[items], %[kb]\n\t"
                     "s_nop 0\n\t"
                     ORZ_SR_ITEM("1", "g", "g2")
@@ -348,13 +359,14 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                     ORZ_SR_SIDE("2", "g2", "g", "3")
                     ORZ_SR_SIDE("3", "g", "g2", "4")
                     ORZ_SR_SIDE("4", "g2", "g", "1")
-                    "9:"
-                    : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
+                    "9:\n\t"
+                    "s_mov_b32 m0, %[m0s]"
+                    : [m0s] "=&s"(m0_was), [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [vi] "+v"(vi), [vu] "+v"(vu), [kb] "+s"(kb), [qa] "+s"(qa),
                       [qw] "+s"(qw), [g] "=&s"(g), [g2] "=&s"(g2), [i] "=&s"(i), [j] "=&s"(j),
                       [t] "=&s"(t), [x] "=&s"(x), [y] "=&s"(y), [pv] "=&s"(pv), [rv] "=&s"(rv), [ma] "=&s"(ma), [mb] "=&s"(mb)
                     : [items] "v"(items), [n1t0] "v"(n1t0), [nxt0] "v"(nxt0), [n1t1] "v"(n1t1), [nxt1] "v"(nxt1),
                       [n1t2] "v"(n1t2), [nxt2] "v"(nxt2), [qc] "s"(qc)
-                    : "scc", "m0");
+                    : "scc");
 #undef ORZ_SR_ITEM
 #undef ORZ_SR_SIDE
 #undef ORZ_LEAF
@@ -515,12 +527,33 @@ class StreamPool {
     }
 
    private:
+    // ORZ_CU_PART (experiments, round 5): the encoders of a process each on a share of the GPU's compute units instead of all
+    // of them on all -- "x<N>": share k = the CUs whose index is k modulo N (the driver deals a mask's bits out to the XCDs in
+    // turn, so with N = 8 a share is one XCD and its L2), "c<N>": N contiguous ranges of the mask; a trailing "m": only the
+    // main (parse) stream is masked, the ranking / tail / copy streams keep the whole device.
     static Set create(bool rank_prio) {
         Set t;
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        static const char* part = getenv("ORZ_CU_PART");
+        static std::atomic<unsigned> serial{0};
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool masked = false, main_only = false;
+        if (part && (part[0] == 'x' || part[0] == 'c') && atoi(part + 1) > 1) {
+            const unsigned n = (unsigned)atoi(part + 1), k = serial.fetch_add(1) % n;
+            int cus = 0;
+            ORZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+            if (cus > 256) cus = 256;
+            for (int b = 0; b < cus; b++) {
+                const bool mine = part[0] == 'x' ? (unsigned)b % n == k : (unsigned)b * n / (unsigned)cus == k;
+                if (mine) mask[b >> 5] |= 1u << (b & 31);
+            }
+            masked = true;
+            main_only = part[strlen(part) - 1] == 'm';
+        }
         for (int i = 0; i < kStreams; i++) {
-            if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
+            if (masked && (i == 0 || !main_only)) ORZ_HIP_CHECK(hipExtStreamCreateWithCUMask(&t.s[i], 8, mask));
+            else if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
             else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking));
         }
         return t;
@@ -528,6 +561,50 @@ class StreamPool {
     std::mutex m_;
     std::map<std::pair<int, bool>, std::vector<Set>> free_;
     std::map<std::pair<int, bool>, int> made_, blocks_;
+};
+
+// Names of the kernels a profiled encode brackets (profile mode, bench.py's roofline leg): one id per kernel type of the
+// process, by the functor's type name; the library calls (sorts, scans, fills, copies) get ids of their own.
+class KernelNames {
+   public:
+    static KernelNames& get() {
+        static KernelNames k;
+        return k;
+    }
+    int id_of(const std::string& name) {
+        std::lock_guard<std::mutex> lk(m_);
+        for (size_t i = 0; i < names_.size(); i++)
+            if (names_[i] == name) return (int)i;
+        names_.push_back(name);
+        return (int)names_.size() - 1;
+    }
+    std::string name(int id) {
+        std::lock_guard<std::mutex> lk(m_);
+        return id >= 0 && (size_t)id < names_.size() ? names_[id] : std::string("?");
+    }
+    template <class F>
+    static int of() {
+        static const int id = get().id_of(pretty(typeid(F).name()));
+        return id;
+    }
+    static int lib(const char* what) { return get().id_of(what); }
+
+   private:
+    static std::string pretty(const char* mangled) {
+        int st = 0;
+        char* d = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+        std::string r = st == 0 && d ? d : mangled;
+        std::free(d);
+        if (r.rfind("orz::", 0) == 0) r = r.substr(5);
+        return r;
+    }
+    std::mutex m_;
+    std::vector<std::string> names_;
+};
+struct KernelRow {
+    std::string name;
+    double ms = 0;
+    uint64_t launches = 0;
 };
 
 class HipBackend {
@@ -573,6 +650,7 @@ class HipBackend {
         if (arena_) (void)hipFree(arena_);
         for (int i = 0; i < kEvents; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+        for (hipEvent_t e : nev_) (void)hipEventDestroy(e);
         for (auto& kv : graph_exec_) (void)hipGraphExecDestroy(kv.second);
         StreamPool::Set t;  // (synchronised above: the streams go back to the pool idle)
         for (int i = 0; i < kStreams; i++) t.s[i] = streams_[i];
@@ -645,7 +723,9 @@ class HipBackend {
     void enable_arena() { arena_on_ = true; }  // (stream encoders only: the decoder's and the Huffman entry point's backends allocate as before)
     void poison(void*, size_t) {}  // (the emulation backend fills state that must never be read before it is written)
     void memset(void* p, int v, size_t n) {
-        if (n) ORZ_HIP_CHECK(hipMemsetAsync(p, v, n, stream_));
+        if (!n) return;
+        Bracket br(*this, profile_ ? KernelNames::lib("(fill)") : 0);
+        ORZ_HIP_CHECK(hipMemsetAsync(p, v, n, stream_));
     }
     void h2d(void* d, const void* s, size_t n) {
         if (!n) return;
@@ -686,9 +766,21 @@ class HipBackend {
     double now() {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
+    // profile mode: every launch between two events on its stream, summed per kernel name by collect_named()
+    struct Bracket {
+        HipBackend& be;
+        bool on;
+        Bracket(HipBackend& b, int id) : be(b), on(b.profile_ && !b.capturing_) {
+            if (on) be.named_begin(id);
+        }
+        ~Bracket() {
+            if (on) be.named_end();
+        }
+    };
     template <class F>
     void launch(size_t n, const F& f) {
         if (!n) return;
+        Bracket br(*this, profile_ ? KernelNames::of<F>() : 0);
         const unsigned grid = (unsigned)((n + 255) / 256);
 #if defined(ORZ_EVAL_WAVES)
         if constexpr (std::is_same<F, FastEval>::value) {
@@ -703,11 +795,13 @@ class HipBackend {
     template <class K>
     void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         if (!nblocks) return;
+        Bracket br(*this, profile_ ? KernelNames::of<K>() : 0);
         hipLaunchKernelGGL(orz_wave_kernel<K>, dim3((unsigned)nblocks), dim3(64), lds_bytes, stream_, k);
         ORZ_HIP_CHECK(hipGetLastError());
     }
     template <class K>
     void launch_group(const K& k) {
+        Bracket br(*this, profile_ ? KernelNames::of<K>() : 0);
         size_t lds = k.lds_bytes();
         // more than 64 KB of dynamic LDS (a CU of gfx950 has 160 KB) has to be asked for once per kernel
         static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&orz_group_kernel<K>),
@@ -726,28 +820,33 @@ class HipBackend {
     }
     void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits) {
         if (n == 0) return;
+        Bracket br(*this, profile_ ? KernelNames::lib("(radix sort, pairs)") : 0);
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(tmp_, sz, kin, kout, vin, vout, n, 0, (unsigned)bits, stream_));
     }
     // stable sort of the item indices 0..n-1 by their 9-bit symbol-ranking context
     void sort_by_ctx(const uint16_t* ctx, uint16_t* ctx_sorted, uint32_t* perm, size_t n) {
         if (n == 0) return;
+        Bracket br(*this, profile_ ? KernelNames::lib("(radix sort, items by context)") : 0);
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(tmp_, sz, ctx, ctx_sorted, rocprim::counting_iterator<uint32_t>(0), perm, n, 0, 9, stream_));
     }
     const uint64_t* sort_u64(uint64_t* a, uint64_t* b, size_t n, int bits) {
         if (n == 0) return a;
+        Bracket br(*this, profile_ ? KernelNames::lib("(radix sort, 64-bit keys)") : 0);
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::radix_sort_keys(tmp_, sz, a, b, n, 0, (unsigned)bits, stream_));
         return b;
     }
     void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
         if (n == 0) return;
+        Bracket br(*this, profile_ ? KernelNames::lib("(scan)") : 0);
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::exclusive_scan(tmp_, sz, in, out, 0u, n, rocprim::plus<uint32_t>(), stream_));
     }
     void inclusive_max_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
         if (n == 0) return;
+        Bracket br(*this, profile_ ? KernelNames::lib("(scan, running maximum)") : 0);
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::inclusive_scan(tmp_, sz, in, out, n, rocprim::maximum<uint32_t>(), stream_));
     }
@@ -774,6 +873,44 @@ class HipBackend {
         ev_used_ += 2;
     }
     void set_timing(bool on) { timing_ = on; }
+    void named_begin(int id) {
+        if (nev_used_ + 2 > nev_.size()) {
+            for (int i = 0; i < 1024; i++) {
+                hipEvent_t e;
+                ORZ_HIP_CHECK(hipEventCreate(&e));
+                nev_.push_back(e);
+            }
+            nev_id_.resize(nev_.size() / 2);
+        }
+        if (nest_++) return;  // (a library call inside a bracketed one counts once)
+        ORZ_HIP_CHECK(hipEventRecord(nev_[nev_used_], stream_));
+        nev_id_[nev_used_ / 2] = id;
+    }
+    void named_end() {
+        if (--nest_) return;
+        ORZ_HIP_CHECK(hipEventRecord(nev_[nev_used_ + 1], stream_));
+        nev_used_ += 2;
+    }
+    // per kernel name: summed event time and launch count since the last call (all streams synchronised first)
+    std::vector<KernelRow> collect_named() {
+        for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipStreamSynchronize(streams_[i]));
+        std::map<int, KernelRow> acc;
+        for (size_t i = 0; i + 1 < nev_used_; i += 2) {
+            float t = 0;
+            ORZ_HIP_CHECK(hipEventElapsedTime(&t, nev_[i], nev_[i + 1]));
+            KernelRow& r = acc[nev_id_[i / 2]];
+            r.ms += t;
+            r.launches++;
+        }
+        nev_used_ = 0;
+        std::vector<KernelRow> out;
+        for (auto& kv : acc) {
+            kv.second.name = KernelNames::get().name(kv.first);
+            out.push_back(kv.second);
+        }
+        std::sort(out.begin(), out.end(), [](const KernelRow& a, const KernelRow& b) { return a.ms > b.ms; });
+        return out;
+    }
     // sums of the bracketed intervals in ms per slot since the last call, and their counts; returns slot 0's sum
     double collect_timed(uint64_t* launches, double* ms_by_slot = nullptr, uint64_t* n_by_slot = nullptr) {
         for (int i = 0; i < kStreams; i++) ORZ_HIP_CHECK(hipStreamSynchronize(streams_[i]));
@@ -847,6 +984,7 @@ class HipBackend {
         static_assert((512 * kSrWords * 2) % 8 == 0, "the tables are copied in 8-byte words");
         const uint32_t nw = 512 * kSrWords * 2 / 8;
         launch(nw, SymGuardBegin{reinterpret_cast<const uint64_t*>(srstate), reinterpret_cast<uint64_t*>(backup), nw, flags});
+        Bracket br(*this, profile_ ? KernelNames::lib("orz_symrank_kernel (+ guard)") : 0);
         timed_begin(1);
         hipLaunchKernelGGL(orz_symrank_kernel, dim3(512), dim3(64), 0, stream_, srstate, gsym, grank, rstart, (const uint16_t*)nullptr,
                            (const uint32_t*)nullptr);
@@ -908,6 +1046,10 @@ class HipBackend {
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     std::vector<int> ev_slot_;
+    std::vector<hipEvent_t> nev_;  // profile mode: event pairs around every launch, with the kernel's name id
+    std::vector<int> nev_id_;
+    size_t nev_used_ = 0;
+    int nest_ = 0;
     std::map<uint64_t, hipGraphExec_t> graph_exec_;
     bool graphs_ = true, profile_ = false, capturing_ = false;
     size_t ev_used_ = 0;

@@ -102,6 +102,7 @@ struct orz_stream {
     unsigned ftile = orz::kFastTile, frounds = orz::kFastRounds;
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
+    std::vector<orz::KernelRow> ktable;  // profile mode: every kernel of the last encode by name (orz_stream_get_kernel_table)
     // Build the encoder for the current settings.  The new one is constructed BEFORE the old one is dropped (a constructor
     // that throws -- bad tile size, failed allocation -- leaves the handle as it was); callers that change settings go
     // through `reconfigure`, which also restores them.
@@ -243,6 +244,16 @@ int orz_stream_get_kernel_times(orz_stream* s, double* ms4, uint64_t* launches4)
     for (int i = 0; i < 4; i++) { ms4[i] = s->kernel_ms[i]; launches4[i] = s->kernel_n[i]; }
     return ORZ_OK;
 }
+long orz_stream_get_kernel_table(orz_stream* s, orz_kernel_row* rows, size_t cap) {
+    if (!s) return fail(ORZ_EINVAL, "null stream");
+    for (size_t i = 0; i < s->ktable.size() && i < cap && rows; i++) {
+        std::memset(&rows[i], 0, sizeof rows[i]);
+        std::strncpy(rows[i].name, s->ktable[i].name.c_str(), sizeof rows[i].name - 1);
+        rows[i].ms = s->ktable[i].ms;
+        rows[i].launches = s->ktable[i].launches;
+    }
+    return (long)s->ktable.size();
+}
 int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
     if (!s || !out) return fail(ORZ_EINVAL, "null argument");
     if (!s->enc) return fail(ORZ_ENOMEM, "the stream has no encoder (a reconfiguration ran out of device memory)");
@@ -299,6 +310,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
             stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
             stats->total_ms = total;
+            if (be.profile()) s->ktable = be.collect_named();
         }
         *dst_len = out.size();
         *dst = out.release();

@@ -70,6 +70,7 @@ struct FastArgs {
     const uint32_t* hpre;       // [kHistSub + 1][256] history item starts per ctx before each unified subtile; [kHistSub] = all of them
     uint32_t far;               // slots searched beyond the tabulated K through the bitmap (FastSource; FastEval for item starts not in the lists yet)
     uint32_t near;              // item starts a scan takes from there (0 = none)
+    uint32_t near1;             // ... in a tile's FIRST round
     uint32_t extra;             // candidates a scan may look at beyond the reference's depth (window + below the window + lists)
     // compact lists: per (ctx, hash) run the records of its FINAL item starts (history, then the tiles that had their last
     // round, appended by FastRetire) side by side from the run's first slot on, oldest first
@@ -555,7 +556,8 @@ ORZ_D uint32_t near_members(const FastArgs& a, uint32_t lo, uint32_t top, uint32
 // All parts together may look at more than `depth` candidates -- the depth is the reference's speed limit, not a rule of
 // the format -- which is why this parse can come out smaller than the reference's.
 #if !defined(__HIPCC__)
-inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
+inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline unsigned long long g_scan_hist[4][64] = {};  // (experiments) [0] first-round scans by window candidates seen, [1] last-round ones, [2] last-round ones whose answer differs from the remembered one, [3] ... by item starts in the window  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
 #endif
 struct FastEval {
     FastArgs a;
@@ -589,7 +591,16 @@ struct FastEval {
         const bool longrun = rl > kFastK;
         // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules)
         const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
-        const bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
+        bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
+        if (a.dbg & 12) {  // (experiments: 4 = no second scan, 8 = no scans at all, 16 below = the second scan only where the path looks)
+            if ((a.dbg & 8) || ((a.dbg & 4) && rnd > 1)) scan = false;
+        }
+        if ((a.dbg & 16) && scan && rnd > 1) {
+            // relevant to the current path: an item start, or one of the two positions behind an item start that found a match
+            const uint64_t sw = bits_at(a.sbits, (int64_t)i - 2);  // bits i-2, i-1, i at 0, 1, 2
+            const bool rel = ((sw >> 2) & 1) || (((sw >> 1) & 1) && i >= 1 && a.ty[i - 1] == kTyMatch) || ((sw & 1) && i >= 2 && a.ty[i - 2] == kTyMatch);
+            if (!rel) scan = false;
+        }
         const bool dirty = a.dirty[i] != 0 || (a.dbg & 1);
         const uint32_t c = hash1(win, p - 1);
         const uint32_t* hz = a.hz + ((size_t)(i / kSub) * 256 + c) * 4;
@@ -682,10 +693,11 @@ struct FastEval {
                 // bitmap, their records side by side, then in order -- until the lists take over (below `cline`), the budget
                 // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
                 // inside the tiles that are still in their rounds: the lists' records lie outside it and this walk is all.)
-                if (a.near && p > cline) {
+                const uint32_t nearn = rnd <= 1 ? a.near1 : a.near;
+                if (nearn && p > cline) {
                     uint32_t top = j - kFastK;
                     const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-                    uint32_t left = fast_min(a.near, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
+                    uint32_t left = fast_min(nearn, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
                     bool more = left != 0;
                     while (more && !fin) {
                         uint32_t sl[4];
@@ -749,6 +761,16 @@ struct FastEval {
                     }
                 }
                 fv = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
+                {
+                    const uint32_t sb = seen < 63 ? seen : 63;
+                    if (first) g_scan_hist[0][sb]++;
+                    else if (rnd == a.rounds) {
+                        g_scan_hist[1][sb]++;
+                        if (a.farv[i] != fv) { g_scan_hist[2][sb]++; g_scan_hist[3][popc64(wbits) < 63 ? popc64(wbits) : 63]++; }
+                    }
+                }
+#endif
                 a.farv[i] = fv;
             } else {
                 fv = first ? 0 : a.farv[i];
@@ -1504,6 +1526,58 @@ struct OrdWave {
             if (i0 + t >= n) break;
             const uint32_t c = (uint32_t)(b[(int)t - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)t - 2]) << 7);
             ORD[kPre + i0 + t] = cp[(size_t)s * 256 + c] + mine[c]++;
+        }
+    }
+};
+
+// The same ordinals with the wavefront's ballots instead of a 64 x 257 counter table (33 KB of LDS a wave: four waves a CU, and ~800
+// LDS operations a lane): the subtile's item starts are listed in position order (prefix sum over the lanes' counts), then taken 64
+// at a time -- a lane's rank among the batch's item starts of its own ctx comes from eight ballots (match-any on the ctx bits),
+// the ordinals before the batch from a running count per ctx in LDS that the first lane of each ctx group moves on.  9 KB of LDS.
+struct OrdWave2 {
+    const uint8_t* win;
+    const uint64_t* sbits;
+    const uint32_t* cp;
+    uint32_t n;
+    uint32_t* ORD;
+    const FastCtl* ctl;
+    static size_t lds_bytes() { return 256 * 4 + kSub * 2; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        if (ctl->done) return;
+        uint32_t* cnt = (uint32_t*)w.lds();
+        uint16_t* pos = (uint16_t*)(cnt + 256);
+        const uint32_t s = w.block(), lane = w.lane();
+        for (uint32_t c = lane; c < 256; c += 64) cnt[c] = cp[(size_t)s * 256 + c];
+        const uint32_t i0 = s * kSub + lane * 64;
+        uint64_t m = i0 < n ? sbits[i0 / 64] : 0;
+        if (i0 < n && n - i0 < 64) m &= (1ull << (n - i0)) - 1;
+        const uint32_t mine = (uint32_t)popc64(m);
+        uint32_t v = mine;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t t = w.shfl(v, lane >= d ? lane - d : lane);
+            if (lane >= d) v += t;
+        }
+        const uint32_t tot = w.bcast(v, 63);
+        uint32_t off = v - mine;
+        while (m) { const uint32_t t = (uint32_t)ctz64(m); m &= m - 1; pos[off++] = (uint16_t)(lane * 64 + t); }
+        w.sync();
+        for (uint32_t base = 0; base < tot; base += 64) {
+            const uint32_t k = base + lane;
+            const bool valid = k < tot;
+            const uint32_t x = kPre + s * kSub + (valid ? pos[k] : 0);
+            const uint32_t c = valid ? hash1(win, x - 1) : 0;
+            uint64_t peers = w.ballot(valid);
+            for (uint32_t b = 0; b < 8; b++) {
+                const uint64_t bb = w.ballot(valid && ((c >> b) & 1));
+                peers &= ((c >> b) & 1) ? bb : ~bb;
+            }
+            const uint32_t rank = (uint32_t)popc64(peers & ((1ull << lane) - 1));
+            uint32_t before = 0;
+            if (valid) { before = cnt[c]; ORD[x] = before + rank; }
+            w.sync();
+            if (valid && rank == 0) cnt[c] = before + (uint32_t)popc64(peers);
+            w.sync();
         }
     }
 };

@@ -758,6 +758,10 @@ class StreamEncoder {
         if ((size_t)(scratch - reinterpret_cast<uint8_t*>(entA_)) > (size_t)kWLen * 8) throw std::runtime_error("repair lists do not fit the sort buffer");
         a.k1 = k1_; a.tbits = tbits;
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 16;
+        // (in a tile's first round the walk reaches over the three tiles that are still in their rounds and its answers are
+        // redone in the last round anyway: one trip of four instead of up to four trips -- FastEval 121 -> 102 us a launch,
+        // +0.02 % of output on the text workload, nothing on zeros with noise; none at all: 95 us, +0.07 %)
+        a.near1 = getenv("ORZ_FAST_NEAR1") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR1")) : std::min<uint32_t>(a.near, 4);
         // (candidates beyond the reference's depth: half as many again -- a third at shallow depths -- keeps the sizes centred
         // on the reference's: text, full block, -l0 / -l1 / -l2: -0.20 / 0.00 / +0.17 %; 6 MB at -l0: -0.53 / -0.36 / -0.18 %
         // with 3 / 2 / 1 more than its 5; the full depth again gives -0.6 ... -0.1 %)
@@ -882,6 +886,7 @@ class StreamEncoder {
                 be_.memset(tbits, 0, tbits_bytes);
                 be_.memset(kdirty, 0, kdirty_bytes);
             }
+            static const bool ord_ballots = !(getenv("ORZ_FAST_ORD") && !strcmp(getenv("ORZ_FAST_ORD"), "table"));  // (experiments: the LDS-table form)
             const FastFlip flip_all{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips};
             const uint32_t tw = n / 64 + 1;  // words of tbits that can hold a bit (positions kPre .. len)
             for (int group = 0; group < 64 && !h.done; group++) {
@@ -896,7 +901,8 @@ class StreamEncoder {
                     be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt}, RepairListWave::lds_bytes());
                     col_scan(fcm_, nsub, fcp_);
                     be_.launch(256, FastItemTotal{fcp_, nsub, fctl_});
-                    be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
+                    if (ord_ballots) be_.launch_waves(nsub, OrdWave2{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave2::lds_bytes());
+                    else be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
                     uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
                     uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);

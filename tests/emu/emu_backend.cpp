@@ -305,6 +305,13 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
         if (std::getenv("ORZ_EVAL_STATS"))
             std::fprintf(stderr, "eval: %llu positions visited, %llu evaluated (first round %llu, dirty %llu, far due %llu), %llu settled the ring end with positions; verify: %llu skipped would differ (%llu in lwm)\n", orz::g_eval_stats[0],
                          orz::g_eval_stats[1], orz::g_eval_stats[2], orz::g_eval_stats[3], orz::g_eval_stats[4], orz::g_eval_stats[5], orz::g_eval_stats[6], orz::g_eval_stats[7]);
+        if (std::getenv("ORZ_SCAN_HIST")) {
+            for (int r = 0; r < 4; r++) {
+                std::fprintf(stderr, "scan hist %d:", r);
+                for (int k = 0; k < 64; k++) std::fprintf(stderr, " %llu", orz::g_scan_hist[r][k]);
+                std::fprintf(stderr, "\n");
+            }
+        }
         if (std::getenv("ORZ_FAR_STATS"))
             std::fprintf(stderr, "compact lists: %llu scans, %llu records read, %llu of them continued in the window; %llu trips below the window\n",
                          orz::g_far_stats[0], orz::g_far_stats[1], orz::g_far_stats[2], orz::g_far_stats[3]);
