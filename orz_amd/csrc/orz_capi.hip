@@ -297,8 +297,8 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             (void)hipGetLastError();  // (registration refused: pageable copies, synchronised per block)
         }
         orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out, pinned);
+        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));  // (before the host-side decode verification: its time is not GPU time)
         if (verify_decode_on()) verify_stream_decode((const uint8_t*)src, n, src_on_device != 0, out.data(), out.size());
-        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));
         be.sync();
         float total = 0;
         ORZ_HIP_CHECK(hipEventElapsedTime(&total, e0, e1));

@@ -136,7 +136,17 @@ int main(int argc, char** argv) {
         } else {
             rc = orz_encode(rd, &io, wr, &io, &cfg, silent ? nullptr : progress, &pg, (int)device);
         }
-        if (rc != ORZ_OK) { fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error()); return 1; }
+        if (rc != ORZ_OK) {
+            fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error());
+            // the streaming entry point hands blocks on as they are finished: what a failed encode left behind is a truncated
+            // stream, and it goes -- a named target only, never stdout
+            if (pos.size() >= 2) {
+                fclose(io.out);
+                io.out = nullptr;
+                if (remove(pos[1].c_str()) == 0) fprintf(stderr, "(the incomplete output %s was removed)\n", pos[1].c_str());
+            }
+            return 1;
+        }
     } else if (gpu_decode) {
         std::vector<uint8_t> in;
         uint8_t tmp[1 << 16];

@@ -67,7 +67,7 @@ class DecodeCheck {
 
    private:
     [[noreturn]] void bad(const char* what) {
-        throw std::runtime_error(std::string("ORZ_VERIFY=decode: ") + what + " (after " + std::to_string(checked_) + " verified bytes): no stream written");
+        throw std::runtime_error(std::string("ORZ_VERIFY=decode: ") + what + " (after " + std::to_string(checked_) + " verified bytes): the encode fails, nothing of this block is handed out (earlier blocks of a streaming call already were: the output is incomplete)");
     }
     std::unique_ptr<DecodeWorkspace> ws_;
     std::vector<uint8_t> in_, out_;

@@ -315,7 +315,16 @@ struct DecodeMember {
                     words[k2 * 2 + 1] = (uint8_t)tail;
                 }
             }
-            if (end_field < spos) spos = end_field;  // src/lz.rs:478
+            if (end_field < spos) {  // src/lz.rs:478: an item overran the chunk's end (never in a stream of this encoder; crafted ones)
+                spos = end_field;
+                // the contexts of the next item come from the bytes before the CUT position -- the reference computes them from
+                // the window (hash1(sbuf, spos - 1)), the register here still holds the overrun bytes
+                if (spos >= kPre) {
+                    const uint64_t mo = (uint64_t)spos - kPre + slid;
+                    tail = 0;
+                    for (uint32_t k = 8; k >= 1; k--) tail = (tail << 8) | (mo >= k ? (uint64_t)out[mo - k] : 0);
+                }
+            }
             if (spos < kPre) return kDecBadData;
             if (spos >= kBlock) {  // src/lib.rs:119-124: the window slides by 2^24, every ring position with it
                 if (slid > 0xffffffffu - 2 * kNewMax) return kDecBadData;  // (members below 4 GiB)

@@ -206,17 +206,24 @@ ORZ_D void mark_run(const uint8_t* win, uint64_t* rdirty, uint32_t x) {
 }
 
 // ---- static per block --------------------------------------------------------------------------------
-struct FastSlotInit {  // thread per slot: history slots are item starts for good; run depth of each new position
+// One wavefront per 64 slots = one word of the item-start bitmap: history slots are item starts for good (the word is written
+// whole from a ballot: no fill of the bitmap before, no atomics -- as a thread per slot this was 64 atomic ORs on one word per
+// wavefront); run depth of each new position.
+struct FastSlotInitWave {
     const uint32_t *epos, *keys, *runstart;
     uint32_t nent;
     uint64_t* vbits;
     uint8_t* rlen;
-    ORZ_HD void operator()(size_t j) const {
-        if (j >= nent) return;
-        const uint32_t p = epos[j];
-        if (p < kPre) { atom_or64(&vbits[j >> 6], 1ull << (j & 63)); return; }
-        if (!keys) return;  // (bitmap only: the run depths are already there)
-        const uint32_t d = (uint32_t)j - runstart[keys[j]];
+    static size_t lds_bytes() { return 0; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        const uint32_t j = w.block() * 64 + w.lane();
+        const bool valid = j < nent;
+        const uint32_t p = valid ? epos[j] : ~0u;
+        const uint64_t m = w.ballot(valid && p < kPre);
+        if (w.lane() == 0) vbits[w.block()] = m;
+        if (!valid || p < kPre || !keys) return;  // (keys == nullptr: bitmap only, the run depths are already there)
+        const uint32_t d = j - runstart[keys[j]];
         rlen[p - kPre] = (uint8_t)(d < 255 ? d : 255);
     }
 };
@@ -355,6 +362,7 @@ struct FastText {  // the slot records, in slot order (one scattered read per sl
     uint64_t* stext;
     uint64_t* cl;    // the history slots of a run are final item starts: the head of its compact list (FastRetire appends)
     uint32_t* ccnt;  // (zeroed) records per list
+    const uint32_t* runstart;
     ORZ_HD void operator()(size_t j) const {
         if (j >= nent) return;
         const uint32_t q = epos[j];
@@ -362,7 +370,8 @@ struct FastText {  // the slot records, in slot order (one scattered read per sl
         stext[2 * j] = lo; stext[2 * j + 1] = hi;
         if (q < kPre) {
             cl[2 * j] = lo; cl[2 * j + 1] = hi;
-            atom_add32(&ccnt[keys[j]], 1);
+            // the history slots lead their run (stable sort: history positions first): the last of them knows how many there are
+            if (j + 1 == nent || keys[j + 1] != keys[j] || epos[j + 1] >= kPre) ccnt[keys[j]] = (uint32_t)j + 1 - runstart[keys[j]];
         }
     }
 };
@@ -845,7 +854,7 @@ struct FastRetire {  // thread per position of the tile
         const uint32_t at = popc_range(a.vbits, j - good, good);
         uint64_t* dst = a.cl + 2 * ((size_t)rs + base + at);
         dst[0] = t0; dst[1] = t1;
-        atom_add32(&a.cnew[key], 1);
+        if (!(a.dbg & 1024)) atom_add32(&a.cnew[key], 1);  // (experiments: 1024 = the time of the kernel without this atomic)
         place[i] = at + 1;
     }
 };
@@ -866,14 +875,12 @@ struct FastRetireDone {  // the first member of each (run, tile) group moves the
     }
 };
 struct FastListReset {  // a block parsed again (finer tiles): the lists go back to their history heads (thread per slot)
-    const uint8_t* win;
-    const uint32_t* epos;
-    uint32_t nent;
+    const uint32_t *epos, *keys, *runstart;  // (the slots' sorted keys: the last three history positions were filed under the keys
+    uint32_t nent;                           // they had before the slide, BuildKeys)
     uint32_t* ccnt;  // (zeroed)
     ORZ_HD void operator()(size_t j) const {
         if (j >= nent) return;
-        const uint32_t q = epos[j];
-        if (q < kPre) atom_add32(&ccnt[bucket_key(win, q)], 1);
+        if (epos[j] < kPre && (j + 1 == nent || keys[j + 1] != keys[j] || epos[j + 1] >= kPre)) ccnt[keys[j]] = (uint32_t)j + 1 - runstart[keys[j]];
     }
 };
 
@@ -990,6 +997,11 @@ struct PathChunk {  // x1[c][e] = exit offset past chunk c when entering it at o
 // the position it jumps to), then the 240 chunk entries are walked through LDS.  Rows are padded to 68 bytes
 // so that the 64 lanes, which walk 64 different segments in lockstep, hit different banks.
 ORZ_D uint32_t pad68(uint32_t x) { return (x >> 6) * 68 + (x & 63); }
+// eight consecutive bytes (x a multiple of 8) into a padded table: two 32-bit LDS stores (a row of 64 starts at a multiple of 4)
+ORZ_D void st8_pad68(uint8_t* tab, uint32_t x, uint64_t v) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(tab + pad68(x));
+    d[0] = (uint32_t)v; d[1] = (uint32_t)(v >> 32);
+}
 struct PathUpWave {
     FastArgs a;
     uint32_t c0;
@@ -1001,26 +1013,41 @@ struct PathUpWave {
         const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
         for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
-            const uint32_t wi = k * 64 + lane, x = wi * 8;
-            uint64_t v = x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0;
-            for (uint32_t b = 0; b < 8; b++) nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
+            const uint32_t x = (k * 64 + lane) * 8;
+            st8_pad68(nlL, x, x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0);
         }
         w.sync();
+        // Exits of the lane's own segment by a backward sweep (a position either leaves the segment or inherits the exit of the
+        // position it jumps to).  The lane's 64 advances come out of LDS in sixteen independent reads first, so that a step of
+        // the sweep is ONE dependent LDS round trip (the inherited exit) instead of two.  (Tried and dropped: pointer jumping with
+        // lane = position, all segments a round -- 49 us against 21: every hop waits for the store before it.)
         {
-            const uint32_t s0 = lane * 64, s1 = fast_min(s0 + 64, clen);
-            for (uint32_t p = s1; p-- > s0 && s0 < clen;) {
-                const uint32_t d = nlL[pad68(p)], x = p + (d ? d : 1);
-                x0L[pad68(p)] = x >= s1 ? (uint8_t)(x - s1) : x0L[pad68(x)];
+            const uint32_t s0 = lane * 64;
+            if (s0 < clen) {
+                const uint32_t s1 = fast_min(s0 + 64, clen), sl = s1 - s0;
+                uint32_t adv[16];
+                const uint32_t* row = reinterpret_cast<const uint32_t*>(nlL + lane * 68);
+#pragma unroll
+                for (uint32_t q = 0; q < 16; q++) adv[q] = row[q];
+                uint8_t* xrow = x0L + lane * 68;
+#pragma unroll
+                for (uint32_t k = 0; k < 64; k++) {
+                    const uint32_t p = 63 - k;
+                    if (p < sl) {
+                        const uint32_t d = (adv[p >> 2] >> (8 * (p & 3))) & 0xff, x = p + (d ? d : 1);
+                        xrow[p] = x >= sl ? (uint8_t)(x - sl) : xrow[x];
+                    }
+                }
             }
         }
         w.sync();
         for (uint32_t k = part * 2; k < part * 2 + 2; k++) {  // every part writes a quarter of x0
-            const uint32_t wi = k * 64 + lane, x = wi * 8;
+            const uint32_t x = (k * 64 + lane) * 8;
             if (x >= clen) continue;
-            uint64_t v = 0;
-            for (uint32_t b = 0; b < 8; b++) v |= (uint64_t)x0L[pad68(x + b)] << (8 * b);
-            *reinterpret_cast<uint64_t*>(a.x0 + (cs - kPre) + x) = v;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(x0L + pad68(x));
+            *reinterpret_cast<uint64_t*>(a.x0 + (cs - kPre) + x) = (uint64_t)src[0] | ((uint64_t)src[1] << 32);
         }
+        w.sync();
         if (lane < 60) {
             const uint32_t e = part * 60 + lane;
             uint32_t x = e;
@@ -1035,30 +1062,30 @@ struct PathUpWave {
 struct PathMarkWave {  // one wavefront per chunk, lane = segment; also the chunk's item starts per ctx (what CountWave counts)
     FastArgs a;
     uint32_t c0;
-    static size_t lds_bytes() { return 3 * (64 * 68 + 32) + 256 * 4; }
+    static constexpr uint32_t kTab = 64 * 68 + 32;
+    static size_t lds_bytes() { return 3 * kTab + (65 * 68 + 12) + 256 * 4; }
     template <class W>
     ORZ_D void operator()(W& w) const {
         uint8_t* nlL = w.lds();
-        uint8_t* x0L = nlL + 64 * 68 + 32;
-        uint8_t* tyL = x0L + 64 * 68 + 32;
-        uint32_t* cnt = (uint32_t*)(tyL + 64 * 68 + 32);
+        uint8_t* x0L = nlL + kTab;
+        uint8_t* tyL = x0L + kTab;
+        uint8_t* wL = tyL + kTab;  // the window's bytes from two before the chunk on: the ctx of an item start without a load from memory inside the walk
+        uint32_t* cnt = (uint32_t*)(wL + 65 * 68 + 12);
         const uint32_t c = c0 + w.block(), lane = w.lane();
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
         for (uint32_t k = lane; k < 256; k += 64) cnt[k] = 0;
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t wi = k * 64 + lane, x = wi * 8;
+            const uint32_t x = (k * 64 + lane) * 8;
             uint64_t v = 0, u = 0, t = 0;
             if (x < clen) {
                 v = *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x);
                 u = *reinterpret_cast<const uint64_t*>(a.x0 + (cs - kPre) + x);
                 t = *reinterpret_cast<const uint64_t*>(a.ty + (cs - kPre) + x);
             }
-            for (uint32_t b = 0; b < 8; b++) {
-                nlL[pad68(x + b)] = (uint8_t)(v >> (8 * b));
-                x0L[pad68(x + b)] = (uint8_t)(u >> (8 * b));
-                tyL[pad68(x + b)] = (uint8_t)(t >> (8 * b));
-            }
+            st8_pad68(nlL, x, v); st8_pad68(x0L, x, u); st8_pad68(tyL, x, t);
+            st8_pad68(wL, x, ldu64(a.win + cs - 2 + x));  // wL[pad68(y)] = win[cs - 2 + y]
         }
+        if (lane == 0) st8_pad68(wL, kSub, ldu64(a.win + cs - 2 + kSub));
         w.sync();
         const uint32_t s0 = lane * 64;
         if (s0 < clen) {
@@ -1070,10 +1097,9 @@ struct PathMarkWave {  // one wavefront per chunk, lane = segment; also the chun
                 x = e1 + x0L[pad68(x)];
             }
             uint64_t m = 0;
-            const uint8_t* b = a.win + cs + s0;
             while (x < s1) {
                 m |= 1ull << (x - s0);
-                atom_add32(&cnt[(uint32_t)(b[(int)(x - s0) - 1] & 0x7f) | ((uint32_t)is_alnum(b[(int)(x - s0) - 2]) << 7)], 1);
+                atom_add32(&cnt[(uint32_t)(wL[pad68(x + 1)] & 0x7f) | ((uint32_t)is_alnum(wL[pad68(x)]) << 7)], 1);
                 const uint32_t d = nlL[pad68(x)];
                 const uint32_t e = x + (d ? d : 1);
                 a.pt[(cs - kPre) + e] = tyL[pad68(x)];
@@ -1245,14 +1271,15 @@ struct FastFlip {
         if (!dv && !de) return;
         // ---- loads
         const uint32_t j = dv ? a.idx[y] : 0, ku = de ? a.kidx[y - 2] : 0;
-        const uint32_t nv = dv && y < mark_hi ? walk(false, j, y) : 0;
-        const uint32_t nk = de && y - 2 < mark_hi ? walk(true, ku, y - 2) : 0;
+        const bool nowalk = (a.dbg & 512) != 0;  // (experiments: the time of the kernel without its walks)
+        const uint32_t nv = dv && y < mark_hi && !nowalk ? walk(false, j, y) : 0;
+        const uint32_t nk = de && y - 2 < mark_hi && !nowalk ? walk(true, ku, y - 2) : 0;
         // ---- stores
         if (dv) {
             if (y < last_hi) atom_add32(lastflips, 1);
             if (a.dbg & 64) atom_add64(&a.stats[16], 1);
             atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
-            if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
+            if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));  // (looking at the word first to save the atomic: 44 -> 54 us, a load among the stores)
             a.mfb[i] = (uint8_t)sw;
             mark(false, j, nv);
         }
@@ -1433,6 +1460,13 @@ struct RepairListWave {
     FastArgs a;
     uint16_t *mlist, *wlist;  // [nsub][kSubMatches], [nsub][kSubWords]
     uint32_t *mcnt, *wcnt;    // [nsub]
+    // later passes: only the matches FastSource has to look at again are listed -- those of a run that gained an item start in
+    // the pass before (rdirty), those whose source lies near the end of the ring (edge) and those of a context that has grown
+    // much since the first pass (cok): the tests FastSource makes itself, made here once per match while its bytes are at hand,
+    // instead of by a thread per listed match (later passes of FastSourceL: 165 us -> the few that remain)
+    const uint64_t* rdirty;   // nullptr: every match (the first pass)
+    const uint8_t* edge;
+    const uint32_t* cok;
     static size_t lds_bytes() { return 256 * 4; }
     template <class W>
     ORZ_D void operator()(W& w) const {
@@ -1453,6 +1487,14 @@ struct RepairListWave {
                 const uint32_t ty = a.ty[i0 + t];
                 if (ty == kTyMatch) mm |= 1ull << t;
                 else if (ty == kTyWord) wm |= 1ull << t;
+            }
+            if (rdirty) {
+                for (uint64_t q = mm; q;) {
+                    const uint32_t t = (uint32_t)ctz64(q);
+                    q &= q - 1;
+                    const uint32_t p = kPre + i0 + t, c = hash1(a.win, p - 1), key = c * kHash + hash_entry(a.win + p);
+                    if (!((rdirty[key >> 6] >> (key & 63)) & 1) && !edge[i0 + t] && cok[c]) mm &= ~(1ull << t);
+                }
             }
         }
         // exclusive prefix of the two counts over the lanes (packed: matches in the low half)
@@ -1677,6 +1719,7 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
     FastArgs a;
     uint32_t* cutend;
     uint64_t* rdirty;  // runs that gain an item start here (read by the next pass's FastSource)
+    uint32_t* cgrow = nullptr;   // list form: [256] item starts added per context since the first pass (FastCokGrow)
     uint32_t* wextra = nullptr;  // list form: the WORD items made here (this pass's FastWordCheckL judges them: the subtiles' lists
     uint32_t* nwx = nullptr;     // were drawn up before); the positions rewritten are noted in a.tbits for FastFlipSparse
     ORZ_HD void operator()(size_t i) const {
@@ -1698,6 +1741,7 @@ struct FastRecut {  // the rest of a shortened item's span, from the last round'
             atom_or64(&a.sbits[xi / 64], 1ull << (xi & 63));
             mark_run(a.win, rdirty, x);
             if (wextra && t == kTyWord) wextra[atom_fetch_add32(nwx, 1)] = xi;
+            if (cgrow) atom_add32(&cgrow[hash1(a.win, x - 1)], 1);
             x += L;
             a.pt[x - kPre] = (uint8_t)t;
             if (wextra) touch(a, x);  // (the item start at x - L was touched as the end of the item before it)
@@ -1851,10 +1895,18 @@ struct FastWordCheckL {  // FastWordCheck over the subtiles' WORD lists; the ver
         for (uint32_t k = (uint32_t)tid; k < nx; k += nth) check(wextra[k], true);
     }
 };
+struct FastCokGrow {  // thread per ctx: has the context gained at most kEdgeMargin item starts since the first pass? (= FastCtxOk, from
+    const uint32_t* cgrow;  // the counters FastRecut / FastWordApplyL keep instead of the pass's ordinals)
+    uint32_t* cok;
+    ORZ_HD void operator()(size_t c) const {
+        if (c < 256) cok[c] = cgrow[c] <= FastSource::kEdgeMargin;
+    }
+};
 struct FastWordApplyL {  // FastWordApply over the fix list (a launch of its own: see FastWordCheck)
     FastArgs a;
     const uint32_t* fixlist;
     uint64_t* rdirty;
+    uint32_t* cgrow;
     const FastCtl* ctl;
     uint32_t nthreads;
     ORZ_HD void operator()(size_t tid) const {
@@ -1868,6 +1920,7 @@ struct FastWordApplyL {  // FastWordApply over the fix list (a launch of its own
             mark_run(a.win, rdirty, p + 1);
             a.pt[i + 1] = kTyLit; a.pt[i + 2] = kTyLit;
             touch(a, p + 1); touch(a, p + 2);
+            atom_add32(&cgrow[hash1(a.win, p)], 1);  // (the new item start at p + 1)
         }
     }
 };

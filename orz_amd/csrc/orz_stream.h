@@ -290,16 +290,22 @@ class StreamEncoder {
             if (lead_unit_ && (lead_unit_ < (1u << 20) || lead_unit_ > kNewMax || lead_unit_ % kSub)) throw std::runtime_error("ORZ_FAST_LEADUNIT must be 0 or a multiple of 4096 in [1 MiB, 16 MiB]");
         }
         if (const char* inj = getenv("ORZ_VERIFY_INJECT")) {  // (tests of the validity gate) "<class>:<n>"
-            static const char* names[] = {"", "hole", "context", "ring", "lenmin", "word", "bytes"};
+            static const char* names[] = {"", "hole", "context", "ring", "lenmin", "word", "bytes", "lenmin2"};
             const std::string v(inj);
             const size_t colon = v.find(':');
             const std::string cls = v.substr(0, colon);
-            for (uint32_t k = 1; k < 7; k++)
+            for (uint32_t k = 1; k < 8; k++)
                 if (cls == names[k]) inject_kind_ = k;
             if (!inject_kind_) throw std::runtime_error("ORZ_VERIFY_INJECT: unknown class");
             inject_nth_ = colon == std::string::npos ? 0 : (uint32_t)strtoul(v.c_str() + colon + 1, nullptr, 10);
         }
         if (const char* oi = getenv("ORZ_OUTPUT_INJECT")) out_inject_ = (size_t)strtoull(oi, nullptr, 10);  // (tests) a flipped bit behind the gate
+        // The three fault-injection hooks of the tests live in the shipped path (the GPU tier drives the product library): an
+        // encoder that finds one of them set says so on stderr every time it is built -- a stray variable must not pass unnoticed.
+        for (const char* hook : {"ORZ_VERIFY_INJECT", "ORZ_OUTPUT_INJECT", "ORZ_SYMRANK_INJECT"})
+            if (getenv(hook))
+                fprintf(stderr, "orz: WARNING: the test hook %s is set in the environment: this encoder DELIBERATELY DAMAGES what it encodes "
+                                "(its streams are invalid unless a guard catches the damage); unset it for real use\n", hook);
         if (seg_ < 8 || seg_ > kSegMax) throw std::runtime_error("seg_size must be in [8, 62]");
         if (wsegs_ < 1) throw std::runtime_error("window must hold at least one segment");
         try {
@@ -391,7 +397,8 @@ class StreamEncoder {
             // items and tail-stage buffers: two sets, taken by the blocks alternately (see post_stage)
             for (TailSet& t : ts_) {
                 t.cap = 0;
-                grow_tail_set(t, kTailItems0);
+                // (ORZ_TAIL_ITEMS0: tests of the growth path start small)
+                grow_tail_set(t, getenv("ORZ_TAIL_ITEMS0") ? std::max<uint32_t>(65536u, (uint32_t)strtoul(getenv("ORZ_TAIL_ITEMS0"), nullptr, 10)) : kTailItems0);
                 t.rstart = take<uint32_t>(520);
                 t.hw = take<uint32_t>((size_t)kMaxChunks * kHwStride);
                 t.hl = take<uint8_t>((size_t)kMaxChunks * kHwStride);
@@ -480,11 +487,11 @@ class StreamEncoder {
     template <class OutT>
     void encode_block(uint32_t n, OutT& out, std::vector<size_t>* chunk_ends = nullptr) {
         if (n == 0 || n > kNewMax) throw std::runtime_error("bad block size");
-        struct TokenGuard {  // (members jobs: at most ORZ_PARSE_TOKENS encoders parse at a time, see the backend)
-            BE& be;
-            explicit TokenGuard(BE& b) : be(b) { be.parse_token_acquire(); }
-            ~TokenGuard() { be.parse_token_release(); }
-        } token{be_};
+        struct TokenGuard {  // (members jobs: at most ORZ_PARSE_TOKENS encoders parse at a time, see the backend: the token goes
+            StreamEncoder& e;  // back when the block's items are handed to the ranking chain -- post_stage -- or on the way out)
+            explicit TokenGuard(StreamEncoder& x) : e(x) { e.be_.parse_token_acquire(); e.token_held_ = true; }
+            ~TokenGuard() { e.release_token(); }
+        } token{*this};
         last_n_ = n;
         double t0 = be_.now();
         const uint8_t* win = dwin();
@@ -713,9 +720,9 @@ class StreamEncoder {
     void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys, OutT& out) {
         const uint8_t* win = dwin();
         const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
-        be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
+        be_.memset(vbits_ + nent / 64, 0, 16);  // (the words behind the last slot; FastSlotInitWave writes the others whole)
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
-        be_.launch(nent, FastSlotInit{epos_, slot_keys, runstart_, nent, vbits_, frlen_});
+        be_.launch_waves(((size_t)nent + 63) / 64, FastSlotInitWave{epos_, slot_keys, runstart_, nent, vbits_, frlen_}, 0);
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
         be_.launch_waves(((size_t)nk + 63) / 64, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_}, FastWordMasks::lds_bytes());
         // history item starts per (unified subtile, ctx) and their prefix: what the ring horizons reach back into
@@ -725,7 +732,7 @@ class StreamEncoder {
         col_scan(fhcm_, kHistSub, fhpre_);
         uint64_t* stext = fstext_;
         be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
-        be_.launch(nent, FastText{win, epos_, slot_keys, nent, stext, fcl_, fccnt_});
+        be_.launch(nent, FastText{win, epos_, slot_keys, nent, stext, fcl_, fccnt_, runstart_});
         be_.timed_begin(2);
         be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_, frdist_}, FastRowsWave::lds_bytes(K));
         be_.timed_end(2);
@@ -789,10 +796,10 @@ class StreamEncoder {
         for (int attempt = 0;; attempt++) {
             a.tile = T;
             if (attempt) {  // (the first attempt finds the bitmap and the list counters as the prep left them)
-                be_.memset(vbits_, 0, ((size_t)nent / 64 + 2) * 8);
-                be_.launch(nent, FastSlotInit{epos_, nullptr, runstart_, nent, vbits_, frlen_});
+                be_.memset(vbits_ + nent / 64, 0, 16);
+                be_.launch_waves(((size_t)nent + 63) / 64, FastSlotInitWave{epos_, nullptr, runstart_, nent, vbits_, frlen_}, 0);
                 be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
-                be_.launch(nent, FastListReset{win, epos_, nent, fccnt_});
+                be_.launch(nent, FastListReset{epos_, slot_keys, runstart_, nent, fccnt_});
             }
             be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
             be_.memset(k1_, 0, ((size_t)kNewMax / 4096 + 2) * 8);
@@ -873,11 +880,16 @@ class StreamEncoder {
             // groups without the host in between: a pass that finds nothing to repair sets `done` on the device and the
             // kernels of later passes return at once; the control block is read once per group.
             const bool incr_repairs = !getenv("ORZ_FAST_FULLPASS");  // (tests, experiments: every pass walks for every match)
-            static const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 256;  // (0 = no limit)
+            // (a walk is ONE thread's chain of dependent loads, and a launch lasts as long as its longest walk: 256 item starts ->
+            // 258 us a launch of FastSourceL on the text workload, 64 -> 160 us for +0.02 % of output, 32 -> 147 us, +0.07 %, 16: +0.4 %)
+            // The cap follows the level's depth (24 / 64 / 184 at -l0 / -l1 / -l2): with 64 at -l2 the text workload came out +0.28 %.
+            const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 4 * a.depth + 4;  // (0 = no limit)
             // The round loop is queued (≈ 25 ms of device work) and the host would only wait for it at the first read-back of the
             // repairs: the output of the block that used the NEXT tail set two blocks ago is fetched now -- its copies run on
             // the copy stream beside the rounds instead of between this block's parse and its item stage, where the main
             // stream stood idle for them.
+            // (chunk_ends = nullptr is right here: callers that ask for chunk ends -- the object-level API -- drain every block at
+            // once (post_stage's last line), so they never have a block pending at this point)
             if (ts_[cur_set_].pending && !pend_order_.empty() && pend_order_.front() == cur_set_) collect_one(out, nullptr);
             FastCtl h{};
             be_.launch(1, FastCtlReset{fctl_});
@@ -885,6 +897,7 @@ class StreamEncoder {
             if (repair_lists) {
                 be_.memset(tbits, 0, tbits_bytes);
                 be_.memset(kdirty, 0, kdirty_bytes);
+                be_.memset(fcok_, 0, 256 * 4);  // item starts the repairs added per context (FastCokGrow)
             }
             static const bool ord_ballots = !(getenv("ORZ_FAST_ORD") && !strcmp(getenv("ORZ_FAST_ORD"), "table"));  // (experiments: the LDS-table form)
             const FastFlip flip_all{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips};
@@ -898,20 +911,23 @@ class StreamEncoder {
                     else be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
                     // exact ordinals of the item starts (per-(subtile, ctx) counts, their prefix, rank inside the subtile) and the
                     // subtiles' lists of matches and WORD items
-                    be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt}, RepairListWave::lds_bytes());
+                    uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
+                    uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
+                    // (which contexts have grown by more than the edge margin since the first pass: from the counters the rewrite
+                    // kernels keep -- the lists below are drawn up before this pass's ordinals exist)
+                    be_.launch(256, FastCokGrow{fcok_, fcok_ + 256});
+                    be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt, pass && incr_repairs ? rd_in : nullptr, fdirty_, fcok_ + 256},
+                                     RepairListWave::lds_bytes());
                     col_scan(fcm_, nsub, fcp_);
                     be_.launch(256, FastItemTotal{fcp_, nsub, fctl_});
                     if (ord_ballots) be_.launch_waves(nsub, OrdWave2{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave2::lds_bytes());
                     else be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
-                    uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
-                    uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
-                    be_.launch(256, FastCtxOk{fcp_, nsub, fcok_, fcok_ + 256, pass == 0, fctl_});
                     FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
                     fs.cutlist = cutlist; fs.ncut = &fctl_->ncut;
                     be_.launch((size_t)nsub * kListThreads, FastSourceL{fs, mlist, mcnt, nsub});
                     FastRecut rc{a, fcut_, rd_out};
-                    rc.wextra = wextra; rc.nwx = &fctl_->nwx;
+                    rc.wextra = wextra; rc.nwx = &fctl_->nwx; rc.cgrow = fcok_;
                     be_.launch(kRepairGrid, FastRecutL{rc, cutlist, fctl_, kRepairGrid});
                     be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
                     if (pass == 0) {  // every WORD item against the running maximum of the update bits; later passes search (FastWordCheckL)
@@ -920,7 +936,7 @@ class StreamEncoder {
                     }
                     be_.launch((size_t)nsub * kListThreads, FastWordCheckL{a, pass == 0 ? flaste_ : nullptr, kdirty, wextra, fixlist, fctl_, wlist, wcnt, nsub});
                     be_.memset(kdirty, 0, kdirty_bytes);
-                    be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fctl_, kRepairGrid});
+                    be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fcok_, fctl_, kRepairGrid});
                     be_.launch(1, FastPassEnd{fctl_});
                 }
                 for (int k = 0; k < todo && !repair_lists; k++, pass++) {
@@ -1017,12 +1033,13 @@ class StreamEncoder {
         }
         if (nitems > t.cap) grow_tail_set(t, nitems);  // (the set is idle: its last block was collected above)
         be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
-        if (inject_kind_) be_.launch(1, VerInjectK{inject_kind_, inject_nth_, t.ipos, nitems, TY_, ML_, SRC_, ORD_, win, S_});  // (tests of the gate)
+        if (inject_kind_ && inject_kind_ != kViLenMin2) be_.launch(1, VerInjectK{inject_kind_, inject_nth_, t.ipos, nitems, TY_, ML_, SRC_, ORD_, win, S_});  // (tests of the gate)
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
         const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
         be_.launch(nitems, LenMinEval{lk, nitems, ML_, LENMIN_, LMV_});
         be_.launch(nitems, LenMinCommit{lk, nitems, ML_, LMV_, LENMIN_});
+        if (inject_kind_ == kViLenMin2) be_.launch(1, VerInjectLmv{inject_nth_, t.ipos, nitems, TY_, LMV_});  // (tests of the gate)
         be_.launch(nitems, ItemSyms{win, t.ipos, nitems, TY_, ML_, W0_, LMV_, SRC_, ORD_, t.isym, t.ictx, t.iunl, t.ienc, t.irob,
                                     t.ial});
         const uint32_t nchunks = (nitems + kChunkItems - 1) / kChunkItems;
@@ -1050,6 +1067,7 @@ class StreamEncoder {
         be_.launch(nitems, SymGather{t.sperm, t.isym, t.iunl, nitems, t.gsym});
         be_.launch(513, SymRunStart{t.skey, nitems, t.rstart});
         be_.record(kEvItems + b);  // items of this block are ready
+        release_token();           // (prep, parse and item stage are queued: the next encoder may start its block)
         // ---- symbol ranking: 512 independent serial chains, launch after launch on stream 1
         MainStreamGuard back_to_main{be_};
         be_.select(1);
@@ -1079,13 +1097,17 @@ class StreamEncoder {
         if (gate_on()) {
             VerArgs v;
             v.win = win; v.ipos = t.ipos; v.isym = t.isym; v.ictx = t.ictx; v.irob = t.irob; v.iunl = t.iunl; v.ienc = t.ienc; v.ial = t.ial;
-            v.nitems = nitems; v.end = len; v.ML = ML_; v.LMV = LMV_; v.SRC = SRC_; v.ORD = ORD_; v.sperm = t.sperm; v.rstart = t.rstart;
+            v.nitems = nitems; v.end = len; v.ML = ML_; v.SRC = SRC_; v.ORD = ORD_; v.sperm = t.sperm; v.rstart = t.rstart;
             v.vrec = vrec_; v.vord = vord_; v.vctx = vctx_; v.vlast = vlast_; v.vwords = vwords_; v.err = verr;
             be_.launch(kVeCount, VerInit{verr});
             be_.memset(vrec_ + kPre, 0, (size_t)n * 4);
             be_.launch(nitems, VerItems{v});
             be_.launch(nitems, VerOrdinals{v});
             be_.launch(nitems, VerMatches{v});
+            be_.launch(nitems, VerLmKeys{v, entA_});
+            const uint64_t* lmk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
+            be_.launch(nitems, VerLenMin{v, lmk});
+            be_.launch(nitems, VerLmCommit{v, lmk});
             be_.launch(nitems, VerWordEvents{v, entA_});
             const uint64_t* evs = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits - 9);  // 15 key bits + 25 position bits + the sentinel's bit
             be_.launch(nitems, VerWords{v, evs});
@@ -1139,7 +1161,7 @@ class StreamEncoder {
                 stats.rank_redos++;
                 fprintf(stderr, "orz: the symbol ranking of block %u was repeated (%u impossible ranks in its first run; %u after the second)\n", t.block, f[0], f[1]);
             }
-            if (f[1]) throw std::runtime_error("symbol ranking produced impossible ranks twice: no stream written");
+            if (f[1]) throw std::runtime_error("symbol ranking produced impossible ranks twice: the encode fails, nothing of this block is handed out");
         }
         for (uint32_t i = 0; i < nchunks; i++) {
             size_t tb = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
@@ -1208,7 +1230,7 @@ class StreamEncoder {
         std::string msg = "validity gate, block " + std::to_string(block) + ": the items do not decode:";
         for (uint32_t c = 0; c < kVeFirst; c++)
             if (e[c]) msg += " " + std::to_string(e[c]) + " x " + ver_name(c) + ";";
-        msg += " first at window offset " + std::to_string(e[kVeFirst] - 1) + " -- no stream written";
+        msg += " first at window offset " + std::to_string(e[kVeFirst] - 1) + " -- the encode fails, nothing of this block is handed out (a streaming call has written the blocks before it: its output is incomplete)";
         fprintf(stderr, "orz: %s\n", msg.c_str());
         throw std::runtime_error(msg);
     }
@@ -1301,6 +1323,10 @@ class StreamEncoder {
         owned_.clear();
         be_.release_arena();
     }
+    void release_token() {
+        if (token_held_) { token_held_ = false; be_.parse_token_release(); }
+    }
+    bool token_held_ = false;
     std::vector<void*> owned_;
     BE& be_;
     Cfg cfg_;
@@ -1346,25 +1372,48 @@ class StreamEncoder {
     // whatever a block needs from then on, up to one item per byte -- sized for the worst case from the start they were 1.2 GB
     // of a stream's state.  Called only while the set is idle.
     static constexpr uint32_t kTailItems0 = 6u << 20;
-    template <class T>
-    void retake(T*& p, size_t n, bool zero) {
-        if (p) {
-            be_.free(p);
-            owned_.erase(std::find(owned_.begin(), owned_.end(), (void*)p));
-            p = nullptr;
+    struct Fresh {  // buffers allocated for a growth that has not been committed yet: freed again unless `keep`
+        BE& be;
+        std::vector<void*> ptrs;
+        bool keep = false;
+        ~Fresh() {
+            if (!keep) for (void* q : ptrs) if (q) be.free(q);
         }
-        p = take<T>(n, zero);
-    }
+        template <class T>
+        T* get(size_t n, bool zero) {
+            ptrs.reserve(ptrs.size() + 1);
+            T* q = be.template alloc<T>(n, zero);
+            ptrs.push_back(q);
+            return q;
+        }
+    };
+    // All-or-nothing: every new buffer is allocated BEFORE an old one is freed, so an allocation that fails --
+    // eight encoders share a device -- leaves the set as it was (cap unchanged, every pointer valid) and the encode fails
+    // with the allocator's error instead of a later launch on a null pointer.
     void grow_tail_set(TailSet& t, uint32_t need) {
         uint64_t cap = std::max<uint64_t>(need, (uint64_t)t.cap * 3 / 2);
         cap = std::min<uint64_t>(kNewMax, (cap + 65535) & ~65535ull);
+        Fresh fresh{be_, {}};
+        TailSet nt = t;
+        nt.ipos = fresh.template get<uint32_t>((size_t)cap + 1, false);
+        nt.isym = fresh.template get<uint16_t>(cap, true); nt.ictx = fresh.template get<uint16_t>(cap, true);
+        nt.irank = fresh.template get<uint16_t>(cap, true); nt.irob = fresh.template get<uint16_t>(cap, true);
+        nt.grank = fresh.template get<uint16_t>(cap, true); nt.skey = fresh.template get<uint16_t>(cap, true);
+        nt.iunl = fresh.template get<uint8_t>(cap, true); nt.ienc = fresh.template get<uint8_t>(cap, true); nt.ial = fresh.template get<uint8_t>(cap, true);
+        nt.gsym = fresh.template get<uint32_t>(cap, false); nt.sperm = fresh.template get<uint32_t>(cap, false);
+        nt.blen = fresh.template get<uint32_t>(cap, false); nt.bscan = fresh.template get<uint32_t>(cap, false);
+        owned_.reserve(owned_.size() + fresh.ptrs.size());  // (nothing below this line throws)
+        fresh.keep = true;
         if (t.cap) be_.sync();
-        retake(t.ipos, (size_t)cap + 1, false);
-        retake(t.isym, cap, true); retake(t.ictx, cap, true); retake(t.irank, cap, true); retake(t.irob, cap, true);
-        retake(t.grank, cap, true); retake(t.skey, cap, true);
-        retake(t.iunl, cap, true); retake(t.ienc, cap, true); retake(t.ial, cap, true);
-        retake(t.gsym, cap, false); retake(t.sperm, cap, false); retake(t.blen, cap, false); retake(t.bscan, cap, false);
-        t.cap = (uint32_t)cap;
+        void* old[] = {t.ipos, t.isym, t.ictx, t.irank, t.irob, t.grank, t.skey, t.iunl, t.ienc, t.ial, t.gsym, t.sperm, t.blen, t.bscan};
+        for (void* q : old) {
+            if (!q) continue;
+            be_.free(q);
+            owned_.erase(std::find(owned_.begin(), owned_.end(), q));
+        }
+        for (void* q : fresh.ptrs) owned_.push_back(q);
+        nt.cap = (uint32_t)cap;
+        t = nt;
     }
     int cur_set_ = 0;
     uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)

@@ -3,14 +3,16 @@
 // handed out.  A finding fails the encode: no stream is better than one no decoder follows.
 //
 // The gate shares nothing with the parse it checks.  It reads the item arrays of the post stage (position, symbol,
-// context, excluded symbol, length code, offset bits: what ItemBits / Pack will write) plus SRC / ML / LMV per position,
+// context, excluded symbol, length code, offset bits: what ItemBits / Pack will write) plus SRC / ML per position,
 // and carries the decoder's state on its own, block to block:
-//   vrec[x]    per window offset: is an item start | its ring context | its match length      (slides with the window)
+//   vrec[x]    per window offset: is an item start | its ring context | its match length | the len_min its ring node has
+//              reached (src/matcher.rs:65-71), kept by the gate itself                         (slides with the window)
 //   vord[x]    ordinal of the item start x in its context's ring, counted by the gate itself   (slides with the window)
 //   vctx[256]  items each ring has taken so far            (src/matcher.rs:62-80: head arithmetic)
 //   vwords     the words[] table                           (src/lz.rs:132-133,203,233)
 //   vlast      was the last item a literal                 (after_literal, src/lz.rs:66)
-// Neither the parse's bitmaps, its ordinals (ORD), its word-update lists nor the contexts it derived are consulted: the
+// Neither the parse's bitmaps, its ordinals (ORD), its word-update lists, its len_min values (LMV / LENMIN: since round 5 --
+// until then the gate read the very value ItemSyms codes from) nor the contexts it derived are consulted: the
 // context of a source is the one RECORDED when the source was an item (round 3's slide defect lived in re-deriving it
 // from the window's bytes, and FastVerify, which re-derived it the same way, could not see it); ordinals come from the
 // stable order of the item list (the two after_literal runs of a context merged by position); words[] answers come from
@@ -54,9 +56,10 @@ ORZ_HD const char* ver_name(uint32_t e) {
 }
 
 constexpr uint32_t kVrValid = 1u << 31;
-ORZ_HD uint32_t vrec_make(uint32_t ctx8, uint32_t mlen) { return kVrValid | (ctx8 << 16) | (mlen << 8); }
+ORZ_HD uint32_t vrec_make(uint32_t ctx8, uint32_t mlen) { return kVrValid | (ctx8 << 16) | (mlen << 8); }  // (len_min 0: a new node)
 ORZ_HD uint32_t vrec_ctx(uint32_t r) { return (r >> 16) & 0xff; }
 ORZ_HD uint32_t vrec_mlen(uint32_t r) { return (r >> 8) & 0xff; }
+ORZ_HD uint32_t vrec_lenmin(uint32_t r) { return r & 0x7f; }
 
 struct VerArgs {
     const uint8_t* win;
@@ -65,7 +68,7 @@ struct VerArgs {
     const uint8_t *iunl, *ienc, *ial;
     uint32_t nitems;
     uint32_t end;  // window offset where the block's last item must end
-    const uint8_t *ML, *LMV;
+    const uint8_t* ML;
     const uint32_t *SRC, *ORD;
     const uint32_t *sperm, *rstart;  // items in (context | after_literal << 8) order, stable; run starts [513]
     uint32_t *vrec, *vord, *vctx, *vlast;
@@ -149,13 +152,73 @@ struct VerMatches {
         roid_encode(ro, &roid, &bl, &bits);
         const uint32_t enc = a.ienc[k];
         if (s != 256 + roid * 6 + (enc < 5 ? enc : 5) || a.irob[k] != (bits | (bl << 12))) ver_fail(a, kVeOffsetCode, p);
-        // src/lz.rs:459-467 with the node the decoder will find: len_min as the references before this one left it,
-        // len_expected = the match length the source item was coded with
-        const uint32_t m = a.LMV[p] > kMinLen ? a.LMV[p] : kMinLen;
-        const uint32_t e = vrec_mlen(rec) > kMinLen ? vrec_mlen(rec) : kMinLen;
+        // (len_min and the length code: VerLenMin below, with the gate's own len_min)
+    }
+};
+// len_min (src/matcher.rs:65-71): a ring node starts at 0 and every reference raises it to min(len + 1, 127); a reference must
+// be at least max(len_min, 4) long and its length code is read against it (src/lz.rs:459-467).  The gate's own bookkeeping: the
+// references of the block sorted by (source, item index) -- keys and sort of its own --, the value a reference meets = the
+// node's value from earlier blocks (in vrec) and the references before it in its source's run.  A walk back stops at 127 (the
+// cap) -- and after 256 references below 126, which cannot all have been longer than the one before: a finding by itself.
+struct VerLmKeys {  // thread per item: source << 25 | item index for matches, ~0 for the others
+    VerArgs a;
+    uint64_t* keys;
+    ORZ_HD void operator()(size_t k) const {
+        if (k >= a.nitems) return;
+        keys[k] = ((a.ial[k] >> 1) & 1) ? (((uint64_t)a.SRC[a.ipos[k]] << kPosBits) | (uint64_t)k) : ~0ull;
+    }
+};
+ORZ_HD uint32_t ver_lm_before(const VerArgs& a, const uint64_t* keys, size_t j, uint32_t q, bool* runaway) {
+    uint32_t v = vrec_lenmin(a.vrec[q]);
+    uint32_t steps = 0;
+    for (size_t i = j; i > 0 && v < 127;) {
+        i--;
+        const uint64_t ki = keys[i];
+        if ((uint32_t)(ki >> kPosBits) != q) break;
+        if (++steps > 256) { *runaway = true; break; }
+        const uint32_t l = a.ML[a.ipos[(uint32_t)(ki & kPosMask)]];
+        const uint32_t w = l + 1 < 127 ? l + 1 : 127;
+        if (w > v) v = w;
+    }
+    return v;
+}
+struct VerLenMin {  // thread per sorted reference
+    VerArgs a;
+    const uint64_t* keys;
+    ORZ_HD void operator()(size_t j) const {
+        if (j >= a.nitems) return;
+        const uint64_t key = keys[j];
+        if (key == ~0ull) return;
+        const uint32_t q = (uint32_t)(key >> kPosBits), k = (uint32_t)(key & kPosMask), p = a.ipos[k], L = a.ML[p];
+        if (q < 1 || q >= p || !(a.vrec[q] & kVrValid)) return;  // (reported by VerMatches)
+        bool runaway = false;
+        const uint32_t lm = ver_lm_before(a, keys, j, q, &runaway);
+        if (runaway) { ver_fail(a, kVeLenMin, p); return; }
+        const uint32_t m = lm > kMinLen ? lm : kMinLen;
+        const uint32_t rec = a.vrec[q], e = vrec_mlen(rec) > kMinLen ? vrec_mlen(rec) : kMinLen;
         if (L < m) ver_fail(a, kVeLenMin, p);
-        const uint32_t dec = enc + m > e ? enc + m : (enc > 0 ? enc + m - 1 : e);
+        const uint32_t enc = a.ienc[k];
+        const uint32_t dec = enc + m > e ? enc + m : (enc > 0 ? enc + m - 1 : e);  // src/lz.rs:459-467
         if (dec != L || enc > kLenSyms - 1) ver_fail(a, kVeLenCode, p);
+    }
+};
+struct VerLmCommit {  // the last reference of each source's run leaves the node's new len_min in the gate's record (a launch of its own:
+    VerArgs a;        // the references of the run read the old one)
+    const uint64_t* keys;
+    ORZ_HD void operator()(size_t j) const {
+        if (j >= a.nitems) return;
+        const uint64_t key = keys[j];
+        if (key == ~0ull) return;
+        const uint32_t q = (uint32_t)(key >> kPosBits);
+        if (j + 1 < a.nitems && keys[j + 1] != ~0ull && (uint32_t)(keys[j + 1] >> kPosBits) == q) return;
+        const uint32_t k = (uint32_t)(key & kPosMask), p = a.ipos[k];
+        if (q < 1 || q >= p || !(a.vrec[q] & kVrValid)) return;
+        bool runaway = false;
+        uint32_t v = ver_lm_before(a, keys, j, q, &runaway);
+        const uint32_t l = a.ML[p], w = l + 1 < 127 ? l + 1 : 127;
+        if (w > v) v = w;
+        if (runaway) v = 127;
+        a.vrec[q] = (a.vrec[q] & ~0x7fu) | v;
     }
 };
 // words[] (src/lz.rs:132-133,203,233): an item that is not a WORD, ending at y, writes words[hash2(y - 3)] = the two bytes
@@ -223,7 +286,22 @@ struct VerReset {  // LZContext::new (src/lz.rs:57-66): empty rings, zero words[
 
 // Fault injection for the gate's tests (ORZ_VERIFY_INJECT=<class>:<n>): the n-th suitable item of every block is damaged
 // AFTER the parse and BEFORE the items are built, the way a parse defect would.  Thread 0 only.
-enum VerInject : uint32_t { kViNone = 0, kViHole, kViContext, kViRing, kViLenMin, kViWord, kViBytes };
+enum VerInject : uint32_t { kViNone = 0, kViHole, kViContext, kViRing, kViLenMin, kViWord, kViBytes, kViLenMin2 };
+struct VerInjectLmv {  // "lenmin2": the len_min the parse hands to ItemSyms damaged AFTER LenMinEval / LenMinCommit -- what the gate could not
+    uint32_t nth;      // see while it read that very value: the n-th match coded against a len_min above 4
+    const uint32_t* ipos;
+    uint32_t nitems;
+    const uint8_t* TY;
+    uint8_t* LMV;
+    ORZ_HD void operator()(size_t t) const {
+        if (t) return;
+        uint32_t seen = 0;
+        for (uint32_t k = 1; k + 1 < nitems; k++) {
+            const uint32_t p = ipos[k];
+            if ((TY[p] & 3) == kTyMatch && LMV[p] > kMinLen + 1 && seen++ == nth) { LMV[p]--; return; }
+        }
+    }
+};
 struct VerInjectK {
     uint32_t kind, nth;
     const uint32_t* ipos;

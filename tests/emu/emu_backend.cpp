@@ -54,7 +54,10 @@ struct EmuBackend {
         return arena + at;
     }
     ~EmuBackend() { std::free(arena); }
+    long fail_alloc_in = -1;  // (tests) the allocation that many calls from now throws std::bad_alloc; -1 = never
     template <class T> T* alloc(size_t n, bool zero = true) {
+        if (fail_alloc_in == 0) { fail_alloc_in = -1; throw std::bad_alloc(); }
+        if (fail_alloc_in > 0) fail_alloc_in--;
         if (void* q = arena_take((n ? n : 1) * sizeof(T))) {
             if (zero) std::memset(q, 0, (n ? n : 1) * sizeof(T));
             return (T*)q;
@@ -319,6 +322,32 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
     } catch (const std::exception& e) {
         g_emu_err = e.what();
         if (!std::getenv("ORZ_VERIFY_INJECT")) std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
+        return -1;
+    }
+}
+// An allocation fails in the middle of a tail set's growth (the `fail_in`-th allocation after the encoder was built), the encode
+// fails -- and the SAME encoder then encodes `src` again: it must write what a fresh encoder writes (a half-grown
+// set left null pointers behind an unchanged capacity).  Returns 0 and the second stream; -2 if the first encode did not fail.
+extern "C" int emu_encode_fast_after_failed_growth(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, long fail_in,
+                                                   uint8_t** dst, size_t* dst_len) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        std::vector<uint8_t> out;
+        be.fail_alloc_in = fail_in;
+        bool failed = false;
+        try { orz::encode_stream(enc, be, src, n, false, out); } catch (const std::bad_alloc&) { failed = true; }
+        be.fail_alloc_in = -1;
+        if (!failed) return -2;
+        out.clear();
+        orz::encode_stream(enc, be, src, n, false, out);
+        *dst = (uint8_t*)std::malloc(out.size() ? out.size() : 1);
+        std::memcpy(*dst, out.data(), out.size());
+        *dst_len = out.size();
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emu_encode_fast_after_failed_growth: %s\n", e.what());
         return -1;
     }
 }

@@ -189,3 +189,24 @@ def test_buffers_side_by_side_change_nothing(emu, oracle, monkeypatch):
     side_exact, _ = emu(data[:120_000])
     assert side_fast == plain_fast
     assert side_exact == oracle.encode(data[:120_000], 1)  # (the full-block case of round 4: tools/dev, 57 minutes of CPU)
+
+
+def test_failed_growth_of_the_tail_buffers_leaves_the_encoder_usable(emu, oracle, monkeypatch):
+    """an allocation that fails half-way through grow_tail_set must leave the set as it was -- the encode fails,
+    the same encoder then encodes the input like a fresh one (every new buffer is allocated before an old one is freed)."""
+    import ctypes
+
+    monkeypatch.setenv("ORZ_TAIL_ITEMS0", "65536")
+    data = _data.random_bytes(200_000)  # one item per byte: more items than the buffers start with
+    fresh, _ = emu.fast(data)
+    for fail_in in (0, 5, 13):  # the first, a middle and the last allocation of the growth
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        rc = emu.lib.emu_encode_fast_after_failed_growth(data, ctypes.c_size_t(len(data)), 15, 9, 6, ctypes.c_long(fail_in), ctypes.byref(dst),
+                                                         ctypes.byref(n))
+        assert rc == 0, "fail_in=%d: rc %d" % (fail_in, rc)
+        out = ctypes.string_at(dst, n.value)
+        emu.lib.emu_free(dst)
+        assert out == fresh
+    back, used = oracle.decode(fresh)
+    assert back == data and used == len(fresh)
