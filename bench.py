@@ -351,7 +351,7 @@ def main():
     barrier()
     gather_s[0] = 0.0
     t0 = time.time()
-    agg = {"sweeps": 0, "seg_evals": 0, "items": 0, "t_prep_s": 0.0, "t_parse_s": 0.0, "t_post_s": 0.0}
+    agg = {"sweeps": 0, "seg_evals": 0, "items": 0, "t_prep_s": 0.0, "t_parse_s": 0.0, "t_post_s": 0.0, "host_syncs": 0, "blocks": 0}
     kt = [[0.0, 0] for _ in range(4)]
     out = b""
     for _ in range(args.steps):
@@ -442,6 +442,9 @@ def main():
             "items_per_byte": round(agg["items"] / args.steps / len(data), 4),
             "rounds_or_sweeps_per_step": agg["sweeps"] // args.steps,
             "repairs_per_step": agg["seg_evals"] // args.steps if cfg["mode"] == 1 else None,
+            # times the host waited for a stream, per 16 MiB block (orz_encode_stats.host_syncs: one for the block's control block +
+            # item count, two when its output is collected two blocks later -- sizes, then bytes --, the closing waits of the call)
+            "host_syncs_per_block": round(agg["host_syncs"] / max(1, agg["blocks"]), 2),
             "roofline": roofs[0] if roofs else None,
             "roofline_others": roofs[1:],
             # every kernel of one profiled pass over the workload (HIP events around each launch, on the stream it runs on; no graph

@@ -91,6 +91,8 @@ typedef struct {
     double parse_kernel_ms;               /* HIP-event time of the parse kernel launches (sum) */
     uint64_t parse_launches;
     double total_ms;                      /* HIP-event time of the whole encode on the stream */
+    uint64_t host_syncs;                  /* times the host waited for a stream during the call (every hipStreamSynchronize of the
+                                             encoder: reads of counts and sizes, copies of finished output, the closing wait) */
 } orz_encode_stats;
 
 typedef struct orz_stream orz_stream;

@@ -35,6 +35,7 @@ class EncodeStats(ctypes.Structure):
         ("parse_kernel_ms", ctypes.c_double),
         ("parse_launches", ctypes.c_uint64),
         ("total_ms", ctypes.c_double),
+        ("host_syncs", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -551,7 +551,19 @@ class StreamPool {
             masked = true;
             main_only = part[strlen(part) - 1] == 'm';
         }
+        // ORZ_SHARE_MAIN=<k> (experiments, round 5): k encoders in a row take the SAME main stream -- their parse kernels follow
+        // each other in submission order instead of running side by side (what the runtime's queue mapping did by accident
+        // for a process's first eight encoders: main streams in pairs on one hardware queue)
+        static const int share = getenv("ORZ_SHARE_MAIN") ? atoi(getenv("ORZ_SHARE_MAIN")) : 0;
+        static hipStream_t shared_main = nullptr;
+        static unsigned shared_left = 0;
         for (int i = 0; i < kStreams; i++) {
+            if (i == 0 && share > 1 && !masked) {
+                if (!shared_left) { ORZ_HIP_CHECK(hipStreamCreateWithFlags(&shared_main, hipStreamNonBlocking)); shared_left = (unsigned)share; }
+                shared_left--;
+                t.s[0] = shared_main;
+                continue;
+            }
             if (masked && (i == 0 || !main_only)) ORZ_HIP_CHECK(hipExtStreamCreateWithCUMask(&t.s[i], 8, mask));
             else if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
             else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking));
@@ -639,14 +651,22 @@ class HipBackend {
         size_t s4 = 0;
         ORZ_HIP_CHECK(rocprim::inclusive_scan(nullptr, s4, u, u, (size_t)kWLen, rocprim::maximum<uint32_t>(), stream_));
         if (s4 > s2) s2 = s4;
-        tmp_bytes_ = (s1 > s2 ? s1 : s2) + 256;
-        for (int i = 0; i < 3; i++) ORZ_HIP_CHECK(hipMalloc(&tmps_[i], tmp_bytes_));
+        // The sorts run on the main stream only: its work area is the large one (a second copy of the keys and values of the
+        // biggest sort).  Streams 1 and 2 carry the ranking launches and the tail stage, whose only library call is a scan over
+        // the items: their work areas hold a scan's few hundred kilobytes -- before round 5 each stream had the large one
+        // (~0.5 GB of an encoder's 6 GB for nothing).
+        tmp_bytes_main_ = (s1 > s2 ? s1 : s2) + 256;
+        tmp_bytes_side_ = s2 + 256;
+        ORZ_HIP_CHECK(hipMalloc(&tmps_[0], tmp_bytes_main_));
+        for (int i = 1; i < 3; i++) ORZ_HIP_CHECK(hipMalloc(&tmps_[i], tmp_bytes_side_));
         tmp_ = tmps_[0];
+        tmp_bytes_ = tmp_bytes_main_;
     }
     ~HipBackend() {
         (void)hipSetDevice(device_);
         for (int i = 0; i < kStreams; i++) if (streams_[i]) (void)hipStreamSynchronize(streams_[i]);
         for (int i = 0; i < kStreams; i++) (void)hipFree(tmps_[i]);
+        if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
         if (arena_) (void)hipFree(arena_);
         for (int i = 0; i < kEvents; i++) (void)hipEventDestroy(sev_[i]);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
@@ -670,7 +690,7 @@ class HipBackend {
     uint32_t far_deadline() const { return 0; }
     uint32_t skip_after() const { return 0; }
     // streams 1 and 2: the tail stage of a block (symbol ranking; Huffman + packing) overlaps the next block's parse (orz_stream.h)
-    void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; cur_ = s; }
+    void select(int s) { stream_ = streams_[s]; tmp_ = tmps_[s]; tmp_bytes_ = s == 0 ? tmp_bytes_main_ : (s < 3 ? tmp_bytes_side_ : 0); cur_ = s; }
     void record(int ev) { ORZ_HIP_CHECK(hipEventRecord(sev_[ev], stream_)); }
     void wait(int ev) { ORZ_HIP_CHECK(hipStreamWaitEvent(stream_, sev_[ev], 0)); }
     int device() const { return device_; }
@@ -731,6 +751,7 @@ class HipBackend {
         if (!n) return;
         ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream_));
         ORZ_HIP_CHECK(hipStreamSynchronize(stream_));  // pageable source may be reused by the caller
+        nsync_++;
     }
     // host -> device from PINNED host memory (hipHostMalloc / hipHostRegister): asynchronous on the encoder's stream, no
     // synchronisation here -- the caller must not reuse the source before the stream's next sync (encode_block ends in one)
@@ -742,7 +763,15 @@ class HipBackend {
         if (!n) return;
         ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream_));
         ORZ_HIP_CHECK(hipStreamSynchronize(stream_));
+        nsync_++;
     }
+    // device -> host without waiting: the caller reads `d` after the stream's next sync()
+    void d2h_async(void* d, const void* s, size_t n) {
+        if (n) ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream_));
+    }
+    // times the host waited for a stream since the last call (orz_encode_stats.host_syncs): every hipStreamSynchronize
+    // the encoder's own code makes -- reads of counts and sizes, the copies of finished output
+    uint64_t take_host_syncs() { const uint64_t v = nsync_; nsync_ = 0; return v; }
     void d2d(void* d, const void* s, size_t n) {
         if (!n) return;
         const char* a = (const char*)s;
@@ -758,7 +787,7 @@ class HipBackend {
             ORZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream_));
         }
     }
-    void sync() { ORZ_HIP_CHECK(hipStreamSynchronize(stream_)); }
+    void sync() { ORZ_HIP_CHECK(hipStreamSynchronize(stream_)); nsync_++; }
     void parse_token_acquire() { if (!lone_) ParseTokens::of(device_).acquire(); }
     void parse_token_release() { if (!lone_) ParseTokens::of(device_).release(); }
     // counts the host derives instead of reading them back are verified against the device only on request
@@ -940,11 +969,21 @@ class HipBackend {
         ORZ_HIP_CHECK(hipGraphLaunch(it->second, stream_));
         return true;
     }
-    void graph_capture_begin() { ORZ_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal)); capturing_ = true; }
+    // (captured on a stream of the backend's own: the main stream may be shared with another encoder's thread -- ORZ_SHARE_MAIN --
+    // whose launches must not end up in this graph; nothing executes during a capture, the graph is launched on the main stream)
+    void graph_capture_begin() {
+        if (!cap_stream_) ORZ_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+        run_stream_ = stream_;
+        stream_ = cap_stream_;
+        ORZ_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        capturing_ = true;
+    }
     void graph_capture_end(uint64_t key) {
         hipGraph_t g = nullptr;
         capturing_ = false;
-        ORZ_HIP_CHECK(hipStreamEndCapture(stream_, &g));
+        const hipError_t ce = hipStreamEndCapture(stream_, &g);
+        stream_ = run_stream_;
+        ORZ_HIP_CHECK(ce);
         hipGraphExec_t ex = nullptr;
         hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
@@ -958,6 +997,7 @@ class HipBackend {
         capturing_ = false;
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(stream_, &g);
+        stream_ = run_stream_;
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
     }
@@ -1036,13 +1076,15 @@ class HipBackend {
     int device_;
     bool lone_ = true, rank_prio_ = false;
     hipStream_t stream_ = nullptr;
+    hipStream_t cap_stream_ = nullptr, run_stream_ = nullptr;  // graph capture (see graph_capture_begin)
     static constexpr int kStreams = StreamPool::kStreams, kEvents = 8;  // (stream 3 only copies finished output to the host: no temporary storage)
     hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
     void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     int cur_ = 0;
     void* tmp_ = nullptr;
-    size_t tmp_bytes_ = 0;
+    size_t tmp_bytes_ = 0, tmp_bytes_main_ = 0, tmp_bytes_side_ = 0;
+    uint64_t nsync_ = 0;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     std::vector<int> ev_slot_;

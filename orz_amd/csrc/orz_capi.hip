@@ -310,6 +310,7 @@ int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_devic
             stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
             stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
             stats->total_ms = total;
+            stats->host_syncs = st.host_syncs + be.take_host_syncs();
             if (be.profile()) s->ktable = be.collect_named();
         }
         *dst_len = out.size();

@@ -135,8 +135,14 @@ struct ParseArgs {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-ORZ_D uint32_t ldu32(const uint8_t* p) { return *reinterpret_cast<const __attribute__((aligned(1))) uint32_t*>(p); }
-ORZ_D uint64_t ldu64(const uint8_t* p) { return *reinterpret_cast<const __attribute__((aligned(1))) uint64_t*>(p); }
+// Unaligned loads.  The alignment has to sit on a TYPEDEF: `reinterpret_cast<const __attribute__((aligned(1))) uint64_t*>` is accepted and the
+// attribute silently dropped -- the compiler then takes the address for 8-aligned, which the vector memory path forgives but the
+// SCALAR path does not: with a wave-uniform address the load becomes an s_load and returns other bytes.  (Found in round 5: every
+// use until then had a per-lane address; PathMarkWave's one uniform load wrote the bytes of 48 positions earlier.)
+typedef uint32_t orz_u32_unaligned __attribute__((aligned(1)));
+typedef uint64_t orz_u64_unaligned __attribute__((aligned(1)));
+ORZ_D uint32_t ldu32(const uint8_t* p) { return *reinterpret_cast<const orz_u32_unaligned*>(p); }
+ORZ_D uint64_t ldu64(const uint8_t* p) { return *reinterpret_cast<const orz_u64_unaligned*>(p); }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }

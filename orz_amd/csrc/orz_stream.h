@@ -41,6 +41,7 @@ struct ItemTrace {
 struct EncodeStats {
     uint64_t blocks = 0, sweeps = 0, seg_evals = 0, items = 0, chunks = 0, in_bytes = 0, out_bytes = 0;
     uint64_t rank_redos = 0;  // blocks whose symbol ranking was repeated by the guard (backend symrank)
+    uint64_t host_syncs = 0;  // times the host waited for a stream (HIP backend: every hipStreamSynchronize of the encoder's own code)
     double t_prep = 0, t_parse = 0, t_post = 0;  // seconds (host clock around device syncs)
 };
 
@@ -270,6 +271,7 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
     static constexpr uint32_t kDirtyWords = kNumKeys / 64 + 1;  // one bit per (ctx, hash) run
+    static constexpr int kFirstPasses = 8;                      // repair passes queued before the first read-back (lists form)
     static constexpr uint32_t kRepairGrid = 16384;              // threads of the kernels that run over the repair stage's short lists
 
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
@@ -902,8 +904,12 @@ class StreamEncoder {
             static const bool ord_ballots = !(getenv("ORZ_FAST_ORD") && !strcmp(getenv("ORZ_FAST_ORD"), "table"));  // (experiments: the LDS-table form)
             const FastFlip flip_all{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips};
             const uint32_t tw = n / 64 + 1;  // words of tbits that can hold a bit (positions kPre .. len)
+            // Lists form: the first group is queued WITHOUT a read-back -- the commit and the item count follow it on the stream
+            // and the control block is read together with the count, ONE wait for both (round 5; before: one after the sixth
+            // pass, one for the count).  A block that is not done after kFirstPasses passes (rare) goes on in groups of two
+            // with a read-back each, and its commit and count are redone.
             for (int group = 0; group < 64 && !h.done; group++) {
-                const int todo = group == 0 ? 6 : 2;  // (text: five passes that repair something and one that finds nothing)
+                const int todo = group == 0 ? (repair_lists ? kFirstPasses : 6) : 2;  // (text: five passes that repair something and one that finds nothing)
                 for (int k = 0; k < todo && repair_lists; k++, pass++) {
                     // the bitmaps in slot order follow the path: everywhere before the first pass, from then on at the positions
                     // the repair kernels rewrote
@@ -965,11 +971,22 @@ class StreamEncoder {
 #endif
                     be_.launch(1, FastPassEnd{fctl_});
                 }
-                be_.d2h(&h, fctl_, sizeof h);
-            }
-            if (repair_lists && h.done && h.passes > 1) {  // the running maximum of the FINAL update bits (FastCommit, FastWordsCarry)
-                be_.launch(nk, KbitVals{kbits_, nk, f32_});
-                be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                if (repair_lists) {
+                    // the running maximum of the FINAL update bits (FastCommit, FastWordsCarry), the per-position arrays of the
+                    // post stage (idempotent: a block that turns out not to be done commits again) and the item count
+                    be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                    be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                    be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
+                    be_.launch(n, Flags32{S_, n, f32_});
+                    be_.exclusive_scan_u32(f32_, sc32_, n);
+                    be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
+                    be_.d2h_async(&h, fctl_, sizeof h);
+                    be_.d2h_async(pre_two_, tailkey_ + 3, 8);
+                    be_.sync();
+                    pre_items_valid_ = h.done != 0;
+                } else {
+                    be_.d2h(&h, fctl_, sizeof h);
+                }
             }
             if (!h.done) throw std::runtime_error("fast parse: repairs did not converge");
             hfin_ = h;
@@ -999,7 +1016,7 @@ class StreamEncoder {
             if (vmode != 2) report_verify("block");
         }
         // ---- hand over to the post stage; carry the model state (the last pass changed nothing: its counts are final)
-        be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
+        if (!repair_lists) be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});  // (lists form: committed and counted with the last read-back)
         be_.launch(1, FastLtCarry{fpt_, n, fctl_});
         be_.launch(32768, FastWordsCarry{a, flaste_, krunend_, wsnap_});
         be_.launch(256, FastCtxCarry{fcp_, nsub, ctxcount_});
@@ -1021,13 +1038,18 @@ class StreamEncoder {
         // ---- the block that used this set two blocks ago has long finished: take its output (in block order)
         if (t.pending) collect_one(out, nullptr);
         // ---- items
-        be_.launch(n, Flags32{S_, n, f32_});
-        be_.exclusive_scan_u32(f32_, sc32_, n);
         uint32_t nitems = 0;
-        be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
         {
             uint32_t two[2] = {0, 0};
-            be_.d2h(two, tailkey_ + 3, 8);
+            if (pre_items_valid_) {  // (fast parse, lists form: flags, scan and count came with the repairs' read-back)
+                two[0] = pre_two_[0]; two[1] = pre_two_[1];
+                pre_items_valid_ = false;
+            } else {
+                be_.launch(n, Flags32{S_, n, f32_});
+                be_.exclusive_scan_u32(f32_, sc32_, n);
+                be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
+                be_.d2h(two, tailkey_ + 3, 8);
+            }
             nitems = two[0];
             hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by)
         }
@@ -1150,11 +1172,15 @@ class StreamEncoder {
         if (getenv("ORZ_COPY_STREAM") && atoi(getenv("ORZ_COPY_STREAM")) == 0) be_.select(2);  // (experiments)
         else { be_.select(3); be_.wait(kEvTail + set); }
         be_.wait(kEvGate + set);
+        // Two waits per collected block (round 5; before: one per size read, per flag read and per chunk): sizes and guard
+        // flags together, then every chunk's bytes together -- the output buffer is grown ONCE before the copies are queued (a
+        // copy in flight must not lose its target to a reallocation).
         std::vector<uint32_t> tot(nchunks);
-        be_.d2h(tot.data(), t.tot, nchunks * 4);
+        uint32_t f[4 + kVeCount];
+        be_.d2h_async(tot.data(), t.tot, nchunks * 4);
+        be_.d2h_async(f, t.srflags, sizeof f);
+        be_.sync();
         {   // the guard of the block's symbol ranking (backend symrank): repeated? still impossible ranks?
-            uint32_t f[4 + kVeCount];
-            be_.d2h(f, t.srflags, sizeof f);
             report_gate(f + 4, t.block);
             if (f[2]) fprintf(stderr, "orz: two runs of the symbol ranking of block %u from the same tables differ in %u ranks\n", t.block, f[2]);
             if (f[0]) {
@@ -1163,22 +1189,39 @@ class StreamEncoder {
             }
             if (f[1]) throw std::runtime_error("symbol ranking produced impossible ranks twice: the encode fails, nothing of this block is handed out");
         }
+        std::vector<size_t> at_of(nchunks), tb_of(nchunks);
+        size_t need = out.size();
         for (uint32_t i = 0; i < nchunks; i++) {
-            size_t tb = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
+            const size_t tb = ((size_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
             if (tb / 4 > kChunkCapWords) throw std::runtime_error("chunk payload overflow");
+            tb_of[i] = tb;
+            size_t v = tb, lenb = 1;
+            while (v >= 128) { lenb++; v /= 128; }
+            need += lenb + tb;
+        }
+        {
+            const size_t keep = out.size();
+            out.resize(need);   // (one growth)
+            out.resize(keep);
+        }
+        std::vector<uint32_t> ends(chunk_ends ? nchunks : 0, len);
+        for (uint32_t i = 0; i < nchunks; i++) {
+            const size_t tb = tb_of[i];
             size_t v = tb;  // write_len, src/ioutil.rs:79-88
             while (v >= 128) { out.push_back((uint8_t)(128 + v % 128)); v /= 128; }
             out.push_back((uint8_t)v);
-            size_t at = out.size();
-            out.resize(at + tb);
-            be_.d2h(out.data() + at, t.out + (uint64_t)i * kChunkCapWords, tb);
-            if (out_inject_ && t.block == 0 && i == 0 && out_inject_ < tb) out.data()[at + out_inject_] ^= 1;  // (tests of ORZ_VERIFY=decode)
+            at_of[i] = out.size();
+            out.resize(at_of[i] + tb);
+            be_.d2h_async(out.data() + at_of[i], t.out + (uint64_t)i * kChunkCapWords, tb);
             if (chunk_ends) {  // end_spos of the chunk, src/lz.rs:268
-                uint32_t i1 = (i + 1) << 20, e = len;
-                if (i1 < nitems) be_.d2h(&e, t.ipos + i1, 4);
-                chunk_ends->push_back(e);
+                const uint32_t i1 = (i + 1) << 20;
+                if (i1 < nitems) be_.d2h_async(&ends[i], t.ipos + i1, 4);
             }
         }
+        be_.sync();
+        if (out_inject_ && t.block == 0 && nchunks && out_inject_ < tb_of[0]) out.data()[at_of[0] + out_inject_] ^= 1;  // (tests of ORZ_VERIFY=decode)
+        if (chunk_ends)
+            for (uint32_t i = 0; i < nchunks; i++) chunk_ends->push_back(ends[i]);
         if (trace) {
             const size_t at = trace->pos.size();
             trace->block.resize(at + nitems, t.block);
@@ -1212,6 +1255,7 @@ class StreamEncoder {
     template <class OutT>
     void finish(OutT& out) {
         collect(out, nullptr);
+        stats.host_syncs += be_.take_host_syncs();
         if (fast_ && stats.blocks && verify_mode() == 2) report_verify("stream");
     }
     static int verify_mode() {  // FastVerify (diagnostics of the fast parse; the gate below is what guards the output)
@@ -1327,6 +1371,8 @@ class StreamEncoder {
         if (token_held_) { token_held_ = false; be_.parse_token_release(); }
     }
     bool token_held_ = false;
+    bool pre_items_valid_ = false;   // pre_two_ holds the block's item count (and whether its second position starts an item): read
+    uint32_t pre_two_[2] = {0, 0};   // with the repairs' control block
     std::vector<void*> owned_;
     BE& be_;
     Cfg cfg_;

@@ -17,7 +17,7 @@ def pytest_configure(config):
 # GPU tier order: the per-row parity tests first, the full-size configurations and the soak last -- the tier runs with -x, and a
 # late failure in the heaviest, newest tests must not blank the per-row evidence ("what's weak" 2)
 _GPU_ORDER = ["test_gpu_parity.py", "test_gpu_fast.py", "test_device_decoder.py", "test_benchmark_tool.py", "test_enwik8.py",
-              "test_gpu_verify.py", "test_gpu_configs.py", "test_gpu_soak.py"]
+              "test_gpu_verify.py", "test_gpu_arena.py", "test_gpu_configs.py", "test_gpu_soak.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):

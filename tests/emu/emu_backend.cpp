@@ -79,6 +79,8 @@ struct EmuBackend {
     void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void h2d_pinned(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    void d2h_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    uint64_t take_host_syncs() { return 0; }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
     bool check_hints() const { return true; }  // (the emulation verifies every count the host derives)
