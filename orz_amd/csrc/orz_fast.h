@@ -404,6 +404,7 @@ struct FastRowsWave {
         const bool mine = (int64_t)w.block() * 64 + lane < (int64_t)nent && p >= kPre;
         const uint32_t r = mine ? fast_min(K, rlen[p - kPre]) : 0;
         const uint64_t a0 = t0[me], a1 = t1[me];
+        const uint64_t a2 = mine ? ldu64(win + p + kRecText) : 0;  // the position's bytes 12..19
         if (mine) {  // how far back the sampled predecessors lie (a sample beyond the run's depth stands for its oldest member)
             uint64_t codes = 0;
             for (uint32_t m = 0; m < 8; m++) {
@@ -417,15 +418,32 @@ struct FastRowsWave {
         const uint32_t parts = cols / 16;            // lanes that share one row's piece of a pass
         for (uint32_t c0 = 0; c0 < K; c0 += cols) {
             for (uint32_t k0 = 0; k0 < cols; k0 += 8) {
-                uint64_t pack = 0;
+                // eight pairs at a time: the prefixes inside the records first (LDS only), then -- for the pairs that agree on all
+                // twelve text bytes -- the candidates' next eight bytes fetched TOGETHER; only pairs that agree on twenty bytes walk
+                // the window one after the other (before: every pair beyond twelve was a chain of its own, 32 pairs a lane in a row)
+                uint32_t ll[8], lq[8];
+                uint64_t yy[8];
+#pragma unroll
                 for (uint32_t kk = 0; kk < 8; kk++) {
                     const uint32_t k = c0 + k0 + kk;
-                    uint32_t l = 0;
+                    ll[kk] = 0; lq[kk] = 0;
                     if (k < r) {
                         const uint32_t e = me - 1 - k;
                         const uint64_t hi = t1[e];
-                        l = rec_lcp(t0[e], hi, a0, a1);
-                        if (l == kRecText) l += lcp240u(win + rec_pos(hi) + kRecText, win + p + kRecText, kMaxLen - kRecText);
+                        ll[kk] = rec_lcp(t0[e], hi, a0, a1);
+                        lq[kk] = rec_pos(hi);
+                    }
+                }
+#pragma unroll
+                for (uint32_t kk = 0; kk < 8; kk++) yy[kk] = ll[kk] == kRecText ? ldu64(win + lq[kk] + kRecText) : 0;
+                uint64_t pack = 0;
+#pragma unroll
+                for (uint32_t kk = 0; kk < 8; kk++) {
+                    uint32_t l = ll[kk];
+                    if (l == kRecText) {
+                        const uint64_t d = yy[kk] ^ a2;
+                        l = d ? kRecText + ((uint32_t)ctz64(d) >> 3)
+                              : kRecText + 8 + lcp240u(win + lq[kk] + kRecText + 8, win + p + kRecText + 8, kMaxLen - kRecText - 8);
                     }
                     pack |= (uint64_t)l << (8 * kk);
                 }
@@ -548,6 +566,16 @@ ORZ_D uint32_t near_members(const FastArgs& a, uint32_t lo, uint32_t top, uint32
     return n;
 }
 
+// Common prefix of position p with a candidate at q whose slot record agreed on all twelve text bytes; `a2` = p's bytes 12..19,
+// `y` = the candidate's, fetched TOGETHER with those of the other candidates of the trip: most such pairs part within these
+// eight bytes, and a scan was a chain of one memory round trip per candidate that got this far (a launch of FastEval lasts as
+// long as its slowest scans: as a kernel of their own, densely packed, they took 98 us).  = 12 + lcp_trips(q + 12, p + 12, 228).
+ORZ_D uint32_t lcp_after12(const uint8_t* win, uint32_t q, uint32_t p, uint64_t a2, uint64_t y) {
+    const uint64_t d = y ^ a2;
+    if (d) return kRecText + ((uint32_t)ctz64(d) >> 3);
+    return kRecText + 8 + lcp_trips(win + q + kRecText + 8, win + p + kRecText + 8, kMaxLen - kRecText - 8);
+}
+
 // ---- one round: the positions of the active range decide from the snapshot ----------------------------
 // A position is evaluated in its tile's first two rounds, and afterwards only when the item starts it looks at changed
 // (FastFlip marks it dirty) or when its tile's scan is due.  Its candidates, newest first (find_match walks the hash
@@ -589,6 +617,127 @@ struct FastEval {
             for (uint32_t b = 0; b < 8; b++) v += k0 + b < kend && q[b] >= horizon;
         }
         return v;
+    }
+    // The candidates beyond the tabulated window for position p (parts 2 and 3 of the kernel's comment): what the scan found, as
+    // farv keeps it.  `seen` = candidates the window has counted already.
+    ORZ_D uint32_t scan_far(uint32_t p, uint32_t i, uint32_t c, uint32_t h4, uint32_t h5, uint64_t codes, uint32_t j, uint32_t r, uint64_t wbits,
+                            uint32_t seen, uint32_t rnd, bool first) const {
+        const uint8_t* win = a.win;
+        (void)i; (void)first;
+        uint32_t fv;
+        {
+                const uint64_t a0 = ldu64(win + p), a1 = (uint64_t)ldu32(win + p + 8), a2 = ldu64(win + p + kRecText);
+                uint32_t fbest = 0, f510 = 0, fm1 = 0, fm2 = 0, s = seen;
+                bool fin = false;
+                // one older candidate by the serial rules of find_match; false = nothing older matters
+                auto take = [&](uint32_t q, uint32_t l) -> bool {
+                    if (l > fbest || (s < a.lazy1 && l > fm1) || (s < a.lazy2 && l > fm2)) {
+                        if (q < h4) return false;  // left the ring (asked only for candidates that matter): so did everything older
+                        if (l > fbest) { fbest = l; f510 = q >= h5; }
+                        if (s < a.lazy1 && l > fm1) fm1 = l;
+                        if (s < a.lazy2 && l > fm2) fm2 = l;
+                    }
+                    s++;
+                    return l != kMaxLen;
+                };
+                const uint32_t key = c * kHash + hash_entry(win + p);
+                const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
+                // ---- 2. item starts below the window that are not in the lists yet: four at a time -- their slots from the
+                // bitmap, their records side by side, then in order -- until the lists take over (below `cline`), the budget
+                // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
+                // inside the tiles that are still in their rounds: the lists' records lie outside it and this walk is all.)
+                const uint32_t nearn = rnd <= 1 ? a.near1 : a.near;
+                if (nearn && p > cline) {
+                    uint32_t top = j - kFastK;
+                    const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
+                    uint32_t left = fast_min(nearn, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
+                    bool more = left != 0;
+                    while (more && !fin) {
+                        uint32_t sl[4];
+                        const uint32_t ns = near_members(a, lo2, top, fast_min(left, 4u), sl);
+                        uint64_t x0[4], x1[4];
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) {
+                            const uint32_t s2 = b < ns ? sl[b] : j;
+                            x0[b] = a.stext[2 * (size_t)s2];
+                            x1[b] = a.stext[2 * (size_t)s2 + 1];
+                        }
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
+                        g_far_stats[3]++;
+#endif
+                        uint32_t ql[4], ll[4];
+                        uint64_t yy[4];
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) { ql[b] = rec_pos(x1[b]); ll[b] = rec_lcp(x0[b], x1[b], a0, a1); }
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) yy[b] = b < ns && ll[b] == kRecText ? ldu64(win + ql[b] + kRecText) : 0;
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; b++) {
+                            if (b >= ns || fin || !more) break;
+                            const uint32_t q = ql[b];
+                            if (q < cline) { more = false; break; }  // from here on the lists have them
+                            uint32_t l = ll[b];
+                            if (l == kRecText) l = lcp_after12(win, q, p, a2, yy[b]);
+                            if (!take(q, l)) fin = true;
+                            left--;
+                        }
+                        if (ns < 4 || left == 0) more = false;
+                        else top = sl[3];  // go on below the fourth
+                    }
+                }
+                // ---- 3. the run's compact list, newest record first; the window's own item starts below the line lead it
+                if (!fin) {
+                    const uint32_t nabove = fast_min(r, dist_valid(codes, p > cline ? p - cline : 0).limit);  // tabulated predecessors at or after the line (never too few)
+                    const uint32_t skip = nabove < 64 ? (uint32_t)popc64(wbits & (~0ull >> nabove)) : 0;
+                    const uint32_t avail = cnt > skip ? cnt - skip : 0;
+                    const uint64_t* top = a.cl + 2 * ((size_t)rs + avail);
+                    const uint32_t room = a.depth + a.extra > s ? a.depth + a.extra - s : 0;
+                    const uint32_t want = fast_min(room, avail);
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
+                    g_far_stats[0]++;
+#endif
+                    constexpr uint32_t kB = 8;  // records per trip, all loads of a trip in flight
+                    for (uint32_t k0 = 0; k0 < want && !fin; k0 += kB) {
+                        uint64_t x0[kB], x1[kB];
+#pragma unroll
+                        for (uint32_t b = 0; b < kB; b++) {
+                            const uint32_t k = k0 + b < want ? k0 + b : k0;
+                            x0[b] = top[-2 * (int64_t)(k + 1)];
+                            x1[b] = top[-2 * (int64_t)(k + 1) + 1];
+                        }
+                        uint32_t ql[kB], ll[kB];
+                        uint64_t yy[kB];
+#pragma unroll
+                        for (uint32_t b = 0; b < kB; b++) { ql[b] = rec_pos(x1[b]); ll[b] = rec_lcp(x0[b], x1[b], a0, a1); }
+#pragma unroll
+                        for (uint32_t b = 0; b < kB; b++) yy[b] = k0 + b < want && ll[b] == kRecText ? ldu64(win + ql[b] + kRecText) : 0;
+#pragma unroll
+                        for (uint32_t b = 0; b < kB; b++) {
+                            if (k0 + b >= want || fin) break;
+                            const uint32_t q = ql[b];
+                            uint32_t l = ll[b];
+                            if (l == kRecText) l = lcp_after12(win, q, p, a2, yy[b]);
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
+                            g_far_stats[1]++;
+                            if (l >= kRecText) g_far_stats[2]++;
+#endif
+                            if (!take(q, l)) fin = true;
+                        }
+                    }
+                }
+                fv = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
+#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
+                {
+                    const uint32_t sb = seen < 63 ? seen : 63;
+                    if (first) g_scan_hist[0][sb]++;
+                    else if (rnd == a.rounds) {
+                        g_scan_hist[1][sb]++;
+                        if (a.farv[i] != fv) { g_scan_hist[2][sb]++; g_scan_hist[3][popc64(wbits) < 63 ? popc64(wbits) : 63]++; }
+                    }
+                }
+#endif
+        }
+        return fv;
     }
     ORZ_HD void operator()(size_t tid) const {
         const uint32_t p = lo + (uint32_t)tid;
@@ -682,105 +831,12 @@ struct FastEval {
         if (!stop && longrun) {
             uint32_t fv;
             if (scan) {
-                const uint64_t a0 = ldu64(win + p), a1 = (uint64_t)ldu32(win + p + 8);
-                uint32_t fbest = 0, f510 = 0, fm1 = 0, fm2 = 0, s = seen;
-                bool fin = false;
-                // one older candidate by the serial rules of find_match; false = nothing older matters
-                auto take = [&](uint32_t q, uint32_t l) -> bool {
-                    if (l > fbest || (s < a.lazy1 && l > fm1) || (s < a.lazy2 && l > fm2)) {
-                        if (q < h4) return false;  // left the ring (asked only for candidates that matter): so did everything older
-                        if (l > fbest) { fbest = l; f510 = q >= h5; }
-                        if (s < a.lazy1 && l > fm1) fm1 = l;
-                        if (s < a.lazy2 && l > fm2) fm2 = l;
-                    }
-                    s++;
-                    return l != kMaxLen;
-                };
-                const uint32_t key = c * kHash + hash_entry(win + p);
-                const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
-                // ---- 2. item starts below the window that are not in the lists yet: four at a time -- their slots from the
-                // bitmap, their records side by side, then in order -- until the lists take over (below `cline`), the budget
-                // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
-                // inside the tiles that are still in their rounds: the lists' records lie outside it and this walk is all.)
-                const uint32_t nearn = rnd <= 1 ? a.near1 : a.near;
-                if (nearn && p > cline) {
-                    uint32_t top = j - kFastK;
-                    const uint32_t lo2 = top - rs > a.far ? top - a.far : rs;
-                    uint32_t left = fast_min(nearn, a.depth + a.extra > s ? a.depth + a.extra - s : 0);
-                    bool more = left != 0;
-                    while (more && !fin) {
-                        uint32_t sl[4];
-                        const uint32_t ns = near_members(a, lo2, top, fast_min(left, 4u), sl);
-                        uint64_t x0[4], x1[4];
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; b++) {
-                            const uint32_t s2 = b < ns ? sl[b] : j;
-                            x0[b] = a.stext[2 * (size_t)s2];
-                            x1[b] = a.stext[2 * (size_t)s2 + 1];
-                        }
-#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
-                        g_far_stats[3]++;
-#endif
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; b++) {
-                            if (b >= ns || fin || !more) break;
-                            const uint32_t q = rec_pos(x1[b]);
-                            if (q < cline) { more = false; break; }  // from here on the lists have them
-                            uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
-                            if (l == kRecText) l += lcp_trips(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-                            if (!take(q, l)) fin = true;
-                            left--;
-                        }
-                        if (ns < 4 || left == 0) more = false;
-                        else top = sl[3];  // go on below the fourth
-                    }
-                }
-                // ---- 3. the run's compact list, newest record first; the window's own item starts below the line lead it
-                if (!fin) {
-                    const uint32_t nabove = fast_min(r, dist_valid(codes, p > cline ? p - cline : 0).limit);  // tabulated predecessors at or after the line (never too few)
-                    const uint32_t skip = nabove < 64 ? (uint32_t)popc64(wbits & (~0ull >> nabove)) : 0;
-                    const uint32_t avail = cnt > skip ? cnt - skip : 0;
-                    const uint64_t* top = a.cl + 2 * ((size_t)rs + avail);
-                    const uint32_t room = a.depth + a.extra > s ? a.depth + a.extra - s : 0;
-                    const uint32_t want = fast_min(room, avail);
-#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
-                    g_far_stats[0]++;
-#endif
-                    constexpr uint32_t kB = 8;  // records per trip, all loads of a trip in flight
-                    for (uint32_t k0 = 0; k0 < want && !fin; k0 += kB) {
-                        uint64_t x0[kB], x1[kB];
-#pragma unroll
-                        for (uint32_t b = 0; b < kB; b++) {
-                            const uint32_t k = k0 + b < want ? k0 + b : k0;
-                            x0[b] = top[-2 * (int64_t)(k + 1)];
-                            x1[b] = top[-2 * (int64_t)(k + 1) + 1];
-                        }
-#pragma unroll
-                        for (uint32_t b = 0; b < kB; b++) {
-                            if (k0 + b >= want || fin) break;
-                            const uint32_t q = rec_pos(x1[b]);
-                            uint32_t l = rec_lcp(x0[b], x1[b], a0, a1);
-                            if (l == kRecText) l += lcp_trips(win + q + kRecText, win + p + kRecText, kMaxLen - kRecText);
-#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
-                            g_far_stats[1]++;
-                            if (l >= kRecText) g_far_stats[2]++;
-#endif
-                            if (!take(q, l)) fin = true;
-                        }
-                    }
-                }
-                fv = fbest | (fm1 << 8) | (fm2 << 16) | (f510 << 24) | (1u << 25);
-#if !defined(__HIPCC__) && !defined(ORZ_EMU_THREADS)
-                {
-                    const uint32_t sb = seen < 63 ? seen : 63;
-                    if (first) g_scan_hist[0][sb]++;
-                    else if (rnd == a.rounds) {
-                        g_scan_hist[1][sb]++;
-                        if (a.farv[i] != fv) { g_scan_hist[2][sb]++; g_scan_hist[3][popc64(wbits) < 63 ? popc64(wbits) : 63]++; }
-                    }
-                }
-#endif
+                // (Tried in round 5 and dropped: the scans as a kernel of their own over a densely packed list of requests -- FastEval
+                // without them 65 us at eight waves a SIMD, the scan kernel 91 us: together more than the 100 us of this kernel,
+                // whose window-only wavefronts run beside its scanning ones.)
+                fv = scan_far(p, i, c, h4, h5, codes, j, r, wbits, seen, rnd, first);
                 a.farv[i] = fv;
+
             } else {
                 fv = first ? 0 : a.farv[i];
             }
@@ -1342,8 +1398,10 @@ struct FastPrefix {
     // thread per ctx with sixteen loads a trip, or a thread per (subtile, ctx) that sums its own prefix: ~31 us a step)
     static size_t lds_bytes() { return 0; }
     template <class W>
-    ORZ_D void operator()(W& w) const {
-        const uint32_t c = w.block(), lane = w.lane();
+    ORZ_D void operator()(W& w) const { run(w, w.block()); }
+    template <class W>
+    ORZ_D void run(W& w, uint32_t c) const {
+        const uint32_t lane = w.lane();
         uint32_t carry = a.cp[(size_t)s0 * 256 + c];
         const uint32_t end = s1 + ext;
         for (uint32_t base = s0; base < end; base += 64) {
@@ -1374,6 +1432,46 @@ struct FastPrefixSerial {  // whole block, thread per ctx: sixteen independent l
         for (; s < s1; s++) {
             v += a.cm[(size_t)s * 256 + c];
             a.cp[(size_t)(s + 1) * 256 + c] = v;
+        }
+    }
+};
+
+// ---- two kernels of a step in ONE launch (round 5) ---------------------------------------------------------------------------
+// A step of the round loop is a chain of launches, most of them far too small to fill the GPU, and its end is not a chain: the
+// ordinal prefix needs the path's item counts (PathMarkWave) but not the flips, the ring horizons need the prefix but not the
+// retiring tile.  As branches of the graph on streams of their own these pairs depended on which hardware queues the runtime
+// handed out; as ONE grid whose first blocks do one job and whose last blocks the other they always run side by
+// side: FastFlip beside FastPrefix, then FastRetire beside FastHorizon.  Wave-shaped launches (64 threads a block).
+struct FlipPrefixWave {
+    FastFlip f;
+    FastPrefix p;
+    uint32_t nflip;  // positions FastFlip visits; its blocks come first
+    static size_t lds_bytes() { return 0; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        const uint32_t fb = (nflip + 63) / 64;
+        if (w.block() < fb) {
+            const uint32_t t = w.block() * 64 + w.lane();
+            if (t < nflip) f((size_t)t);
+        } else {
+            p.run(w, w.block() - fb);
+        }
+    }
+};
+struct RetireHorizonWave {
+    FastRetire r;
+    FastHorizon h;
+    uint32_t nret;  // positions of the retiring tile (0 = none this step); their blocks come first
+    static size_t lds_bytes() { return 0; }
+    template <class W>
+    ORZ_D void operator()(W& w) const {
+        const uint32_t rb = (nret + 63) / 64;
+        if (w.block() < rb) {
+            const uint32_t t = w.block() * 64 + w.lane();
+            if (t < nret) r((size_t)t);
+        } else {
+            const size_t t = (size_t)(w.block() - rb) * 64 + w.lane();
+            if (t < h.threads()) h(t);
         }
     }
 };

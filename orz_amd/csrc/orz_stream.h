@@ -271,7 +271,7 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
     static constexpr uint32_t kDirtyWords = kNumKeys / 64 + 1;  // one bit per (ctx, hash) run
-    static constexpr int kFirstPasses = 8;                      // repair passes queued before the first read-back (lists form)
+    static constexpr int kFirstPasses = 10;                     // repair passes queued before the first read-back (lists form)
     static constexpr uint32_t kRepairGrid = 16384;              // threads of the kernels that run over the repair stage's short lists
 
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions
@@ -766,6 +766,7 @@ class StreamEncoder {
         uint64_t* kdirty = reinterpret_cast<uint64_t*>(carve(kdirty_bytes));
         if ((size_t)(scratch - reinterpret_cast<uint8_t*>(entA_)) > (size_t)kWLen * 8) throw std::runtime_error("repair lists do not fit the sort buffer");
         a.k1 = k1_; a.tbits = tbits;
+
         a.near = getenv("ORZ_FAST_NEAR") ? (uint32_t)atoi(getenv("ORZ_FAST_NEAR")) : 16;
         // (in a tile's first round the walk reaches over the three tiles that are still in their rounds and its answers are
         // redone in the last round anyway: one trip of four instead of up to four trips -- FastEval 121 -> 102 us a launch,
@@ -823,6 +824,7 @@ class StreamEncoder {
             be_.launch_waves(256, FastPrefix{a, 0, 0, std::min(cpt + 1, nsub), cpt, 0}, 0);
             { const FastHorizon fh{a, 0, std::min(cpt + 1, nsub) - 1}; be_.launch(fh.threads(), fh); }
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
+            static const bool fused_steps = !(getenv("ORZ_FAST_FUSED") && !strcmp(getenv("ORZ_FAST_FUSED"), "0"));  // (experiments: every kernel a launch of its own)
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
             const uint64_t gkey = ((uint64_t)T << 32) | n;
             const bool replayed = use_graph && be_.graph_replay(gkey);
@@ -858,20 +860,30 @@ class StreamEncoder {
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
                 const uint32_t fhi = std::min(len, hi + 240);
-                be_.launch((size_t)fhi - lo + 1, FastFlip{a, lo, fhi, t_hi + 1, mark_hi, step >= R ? (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T) : 0, &fctl_->lastflips});
-                // ordinals of the range, extrapolated over the tile that starts next, and the ring horizons from them.  (As a
-                // parallel branch of the graph beside the flips these two saved 25 us a step or cost 100, depending on which
-                // hardware queues the runtime gave the two streams: one chain it is.)
-                // (... and one subtile more: the next step also evaluates the two positions behind its newest tile)
+                // The end of a step is not a chain: the ordinal prefix (extrapolated over the tile that starts next, and one subtile
+                // more: the next step also evaluates the two positions behind its newest tile) needs the path's counts but not
+                // the flips, the ring horizons need the prefix but not the retiring tile -- each pair is ONE grid (orz_fast.h),
+                // so that they run side by side whatever queues the runtime hands out.  The tile that has just had its last round
+                // is final: its item starts join the compact lists (while a later tile will still read them).
+                const FastFlip ff{a, lo, fhi, t_hi + 1, mark_hi, step >= R ? (uint32_t)std::min<uint64_t>(len, (uint64_t)lo + T) : 0, &fctl_->lastflips};
                 const uint32_t ext = std::min(cpt + 1, nsub - std::min(nsub, c0 + nc));
-                be_.launch_waves(256, FastPrefix{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0}, 0);
-                { const FastHorizon fh{a, c0, c0 + nc + ext - 1}; be_.launch(fh.threads(), fh); }
-                // the tile that has just had its last round is final: its item starts join the compact lists (while a later
-                // tile will still read them)
-                if (step >= R && step < ntile + R - 1) {
-                    const uint32_t rlo = kPre + (step - R) * T, rhi = (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T);
-                    be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
-                    be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                const FastPrefix fp{a, c0, c0 + nc, ext, cpt, step >= R ? std::min(c0 + cpt, c0 + nc) : c0};
+                const FastHorizon fh{a, c0, c0 + nc + ext - 1};
+                const bool retire = step >= R && step < ntile + R - 1;
+                const uint32_t rlo = retire ? kPre + (step - R) * T : kPre, rhi = retire ? (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T) : kPre;
+                if (fused_steps) {
+                    const uint32_t nflip = fhi - lo + 1, nret = rhi - rlo;
+                    be_.launch_waves((size_t)(nflip + 63) / 64 + 256, FlipPrefixWave{ff, fp, nflip}, 0);
+                    be_.launch_waves((size_t)(nret + 63) / 64 + (fh.threads() + 63) / 64, RetireHorizonWave{FastRetire{a, rlo, rhi, fcut_}, fh, nret}, 0);
+                    if (retire) be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                } else {
+                    be_.launch((size_t)fhi - lo + 1, ff);
+                    be_.launch_waves(256, fp, 0);
+                    be_.launch(fh.threads(), fh);
+                    if (retire) {
+                        be_.launch(rhi - rlo, FastRetire{a, rlo, rhi, fcut_});
+                        be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                    }
                 }
                 stats.sweeps++;
             }
