@@ -1856,16 +1856,16 @@ struct FastRecutL {  // the same over the pass's cut list
         for (uint32_t k = (uint32_t)tid; k < n; k += nthreads) f(cutlist[k]);
     }
 };
-struct FastSourceL {  // FastSource over the subtiles' match lists: kListThreads threads a subtile
-    FastSource f;
+struct FastSourceL {  // FastSource over the subtiles' match lists: `per` threads a subtile (the first pass, every match: one thread a
+    FastSource f;     // list slot -- a thread that takes several matches walks for them one after the other; later passes: a few)
     const uint16_t* mlist;
     const uint32_t* mcnt;
-    uint32_t nsub;
+    uint32_t nsub, per;
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t s = (uint32_t)(tid / kListThreads);
+        const uint32_t s = (uint32_t)(tid / per);
         if (s >= nsub || f.ctl->done) return;
         const uint32_t c = mcnt[s];
-        for (uint32_t k = (uint32_t)(tid % kListThreads); k < c; k += kListThreads) f((size_t)s * kSub + mlist[(size_t)s * kSubMatches + k]);
+        for (uint32_t k = (uint32_t)(tid % per); k < c; k += per) f((size_t)s * kSub + mlist[(size_t)s * kSubMatches + k]);
     }
 };
 struct KbitVals {  // v[s] = s + 1 where the word-update bit of slot s is set, else 0 (for the running maximum)

@@ -887,9 +887,6 @@ class StreamEncoder {
                 }
                 stats.sweeps++;
             }
-            capture.on = false;
-            if (use_graph && !replayed) be_.graph_capture_end(gkey);
-            debug_dump("r", n, nullptr);
             // ---- frozen boundaries: sources, cuts, exact predictor -- until nothing changes.  The passes are launched in
             // groups without the host in between: a pass that finds nothing to repair sets `done` on the device and the
             // kernels of later passes return at once; the control block is read once per group.
@@ -898,31 +895,11 @@ class StreamEncoder {
             // 258 us a launch of FastSourceL on the text workload, 64 -> 160 us for +0.02 % of output, 32 -> 147 us, +0.07 %, 16: +0.4 %)
             // The cap follows the level's depth (24 / 64 / 184 at -l0 / -l1 / -l2): with 64 at -l2 the text workload came out +0.28 %.
             const uint32_t src_cap = getenv("ORZ_FAST_SRCCAP") ? (uint32_t)atoi(getenv("ORZ_FAST_SRCCAP")) : 4 * a.depth + 4;  // (0 = no limit)
-            // The round loop is queued (≈ 25 ms of device work) and the host would only wait for it at the first read-back of the
-            // repairs: the output of the block that used the NEXT tail set two blocks ago is fetched now -- its copies run on
-            // the copy stream beside the rounds instead of between this block's parse and its item stage, where the main
-            // stream stood idle for them.
-            // (chunk_ends = nullptr is right here: callers that ask for chunk ends -- the object-level API -- drain every block at
-            // once (post_stage's last line), so they never have a block pending at this point)
-            if (ts_[cur_set_].pending && !pend_order_.empty() && pend_order_.front() == cur_set_) collect_one(out, nullptr);
-            FastCtl h{};
-            be_.launch(1, FastCtlReset{fctl_});
-            int pass = 0;
-            if (repair_lists) {
-                be_.memset(tbits, 0, tbits_bytes);
-                be_.memset(kdirty, 0, kdirty_bytes);
-                be_.memset(fcok_, 0, 256 * 4);  // item starts the repairs added per context (FastCokGrow)
-            }
             static const bool ord_ballots = !(getenv("ORZ_FAST_ORD") && !strcmp(getenv("ORZ_FAST_ORD"), "table"));  // (experiments: the LDS-table form)
             const FastFlip flip_all{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips};
             const uint32_t tw = n / 64 + 1;  // words of tbits that can hold a bit (positions kPre .. len)
-            // Lists form: the first group is queued WITHOUT a read-back -- the commit and the item count follow it on the stream
-            // and the control block is read together with the count, ONE wait for both (round 5; before: one after the sixth
-            // pass, one for the count).  A block that is not done after kFirstPasses passes (rare) goes on in groups of two
-            // with a read-back each, and its commit and count are redone.
-            for (int group = 0; group < 64 && !h.done; group++) {
-                const int todo = group == 0 ? (repair_lists ? kFirstPasses : 6) : 2;  // (text: five passes that repair something and one that finds nothing)
-                for (int k = 0; k < todo && repair_lists; k++, pass++) {
+            int pass = 0;
+            auto lists_pass = [&]() {
                     // the bitmaps in slot order follow the path: everywhere before the first pass, from then on at the positions
                     // the repair kernels rewrote
                     if (pass == 0) be_.launch((size_t)n + 1, flip_all);
@@ -943,7 +920,8 @@ class StreamEncoder {
                     be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
                     fs.cutlist = cutlist; fs.ncut = &fctl_->ncut;
-                    be_.launch((size_t)nsub * kListThreads, FastSourceL{fs, mlist, mcnt, nsub});
+                    const uint32_t per = pass == 0 ? kSubMatches : kListThreads;
+                    be_.launch((size_t)nsub * per, FastSourceL{fs, mlist, mcnt, nsub, per});
                     FastRecut rc{a, fcut_, rd_out};
                     rc.wextra = wextra; rc.nwx = &fctl_->nwx; rc.cgrow = fcok_;
                     be_.launch(kRepairGrid, FastRecutL{rc, cutlist, fctl_, kRepairGrid});
@@ -956,8 +934,58 @@ class StreamEncoder {
                     be_.memset(kdirty, 0, kdirty_bytes);
                     be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fcok_, fctl_, kRepairGrid});
                     be_.launch(1, FastPassEnd{fctl_});
+            };
+            // ... and what follows a group of passes in the lists form: the running maximum of the FINAL update bits (FastCommit,
+            // FastWordsCarry), the per-position arrays of the post stage (idempotent: a block that turns out not to be done
+            // commits again) and the item count
+            auto lists_tail = [&]() {
+                be_.launch(nk, KbitVals{kbits_, nk, f32_});
+                be_.inclusive_max_scan_u32(f32_, flaste_, nk);
+                be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
+                be_.launch(n, Flags32{S_, n, f32_});
+                be_.exclusive_scan_u32(f32_, sc32_, n);
+                be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
+            };
+            // Lists form: the first group of passes, the commit and the item count are queued behind the rounds WITHOUT a read-back
+            // -- and, for a full block, inside the same captured graph: one graph launch per block for rounds + repairs + commit --,
+            // then the control block is read together with the count, ONE wait for both (round 5; before: one after the sixth
+            // pass, one for the count).  A block that is not done after kFirstPasses passes (rare) goes on in groups of two with
+            // a read-back each, and its commit and count are redone.
+            if (repair_lists && !replayed) {
+                be_.launch(1, FastCtlReset{fctl_});
+                be_.memset(tbits, 0, tbits_bytes);
+                be_.memset(kdirty, 0, kdirty_bytes);
+                be_.memset(fcok_, 0, 256 * 4);  // item starts the repairs added per context (FastCokGrow)
+                for (int k = 0; k < kFirstPasses; k++, pass++) lists_pass();
+                lists_tail();
+            }
+            capture.on = false;
+            if (use_graph && !replayed) be_.graph_capture_end(gkey);
+            debug_dump("r", n, nullptr);
+            // The parse is queued (≈ 25 ms of device work) and the host would only wait for it at the read-back below: the
+            // output of the block that used the NEXT tail set two blocks ago is fetched now -- its copies run on the copy
+            // stream beside the parse instead of between this block's parse and its item stage, where the main stream stood
+            // idle for them.
+            // (chunk_ends = nullptr is right here: callers that ask for chunk ends -- the object-level API -- drain every block at
+            // once (post_stage's last line), so they never have a block pending at this point)
+            if (ts_[cur_set_].pending && !pend_order_.empty() && pend_order_.front() == cur_set_) collect_one(out, nullptr);
+            FastCtl h{};
+            if (repair_lists) {
+                pass = kFirstPasses;
+                for (int group = 0; group < 64; group++) {
+                    be_.d2h_async(&h, fctl_, sizeof h);
+                    be_.d2h_async(pre_two_, tailkey_ + 3, 8);
+                    be_.sync();
+                    pre_items_valid_ = h.done != 0;
+                    if (h.done) break;
+                    for (int k = 0; k < 2; k++, pass++) lists_pass();
+                    lists_tail();
                 }
-                for (int k = 0; k < todo && !repair_lists; k++, pass++) {
+            } else {
+                be_.launch(1, FastCtlReset{fctl_});
+                for (int group = 0; group < 64 && !h.done; group++) {
+                    const int todo = group == 0 ? 6 : 2;  // (text: five passes that repair something and one that finds nothing)
+                    for (int k = 0; k < todo; k++, pass++) {
                     be_.launch((size_t)n + 1, FastFlip{a, kPre, len, ~0u, 0, 0, &fctl_->lastflips});
                     // exact ordinals of the item starts: per-(subtile, ctx) counts, their prefix, rank inside the subtile
                     be_.launch_waves(nsub, CountWave{a, 0}, CountWave::lds_bytes());
@@ -982,21 +1010,7 @@ class StreamEncoder {
                     be_.launch(n, FastWordApply{a, fcut_, rd_out});
 #endif
                     be_.launch(1, FastPassEnd{fctl_});
-                }
-                if (repair_lists) {
-                    // the running maximum of the FINAL update bits (FastCommit, FastWordsCarry), the per-position arrays of the
-                    // post stage (idempotent: a block that turns out not to be done commits again) and the item count
-                    be_.launch(nk, KbitVals{kbits_, nk, f32_});
-                    be_.inclusive_max_scan_u32(f32_, flaste_, nk);
-                    be_.launch(n, FastCommit{a, flaste_, &fctl_->lt, S_, TY_, ML_, W0_});
-                    be_.launch(n, Flags32{S_, n, f32_});
-                    be_.exclusive_scan_u32(f32_, sc32_, n);
-                    be_.launch(1, SumLast{sc32_, f32_, n - 1, tailkey_ + 3});
-                    be_.d2h_async(&h, fctl_, sizeof h);
-                    be_.d2h_async(pre_two_, tailkey_ + 3, 8);
-                    be_.sync();
-                    pre_items_valid_ = h.done != 0;
-                } else {
+                    }
                     be_.d2h(&h, fctl_, sizeof h);
                 }
             }
