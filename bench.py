@@ -438,6 +438,7 @@ def main():
                 "input": "resident in HBM",
             },
             "compressed_bytes": len(out),
+            "compressed_sha256": hashlib.sha256(bytes(out)).hexdigest(),  # (profiles/r05_emulation_100MB.txt: the host emulation's stream of the same workload)
             "ratio": round(len(out) / len(data), 5),
             "items_per_byte": round(agg["items"] / args.steps / len(data), 4),
             "rounds_or_sweeps_per_step": agg["sweeps"] // args.steps,

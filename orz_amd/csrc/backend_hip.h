@@ -860,11 +860,13 @@ class HipBackend {
         size_t sz = tmp_bytes_;
         ORZ_HIP_CHECK(rocprim::radix_sort_pairs(tmp_, sz, ctx, ctx_sorted, rocprim::counting_iterator<uint32_t>(0), perm, n, 0, 9, stream_));
     }
-    const uint64_t* sort_u64(uint64_t* a, uint64_t* b, size_t n, int bits) {
+    // stable sort of 64-bit keys on their bits [begin_bit, bits): the callers' keys come in the order of their low part (item
+    // index / position), so only the high part has to be sorted -- half the passes (round 5)
+    const uint64_t* sort_u64(uint64_t* a, uint64_t* b, size_t n, int bits, int begin_bit = 0) {
         if (n == 0) return a;
         Bracket br(*this, profile_ ? KernelNames::lib("(radix sort, 64-bit keys)") : 0);
         size_t sz = tmp_bytes_;
-        ORZ_HIP_CHECK(rocprim::radix_sort_keys(tmp_, sz, a, b, n, 0, (unsigned)bits, stream_));
+        ORZ_HIP_CHECK(rocprim::radix_sort_keys(tmp_, sz, a, b, n, (unsigned)begin_bit, (unsigned)bits, stream_));
         return b;
     }
     void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {

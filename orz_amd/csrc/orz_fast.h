@@ -214,6 +214,11 @@ struct FastSlotInitWave {
     uint32_t nent;
     uint64_t* vbits;
     uint8_t* rlen;
+    // ... and, in the same pass over the slots (round 5: one kernel less, the slot positions and keys read once), the slot records
+    // (12 text bytes + the position, the heads of the compact lists, their counters); win == nullptr: none
+    const uint8_t* win = nullptr;
+    uint64_t *stext = nullptr, *cl = nullptr;
+    uint32_t* ccnt = nullptr;
     static size_t lds_bytes() { return 0; }
     template <class W>
     ORZ_D void operator()(W& w) const {
@@ -222,8 +227,19 @@ struct FastSlotInitWave {
         const uint32_t p = valid ? epos[j] : ~0u;
         const uint64_t m = w.ballot(valid && p < kPre);
         if (w.lane() == 0) vbits[w.block()] = m;
-        if (!valid || p < kPre || !keys) return;  // (keys == nullptr: bitmap only, the run depths are already there)
-        const uint32_t d = j - runstart[keys[j]];
+        if (!valid || !keys) return;  // (keys == nullptr: bitmap only, the run depths are already there)
+        const uint32_t key = keys[j], rs = runstart[key];
+        if (win) {
+            const uint64_t lo = ldu64(win + p), hi = (uint64_t)ldu32(win + p + 8) | ((uint64_t)p << 32);
+            stext[2 * (size_t)j] = lo; stext[2 * (size_t)j + 1] = hi;
+            if (p < kPre) {
+                cl[2 * (size_t)j] = lo; cl[2 * (size_t)j + 1] = hi;
+                // the history slots lead their run (stable sort: history positions first): the last of them knows how many there are
+                if (j + 1 == nent || keys[j + 1] != key || epos[j + 1] >= kPre) ccnt[key] = j + 1 - rs;
+            }
+        }
+        if (p < kPre) return;
+        const uint32_t d = j - rs;
         rlen[p - kPre] = (uint8_t)(d < 255 ? d : 255);
     }
 };
@@ -355,26 +371,6 @@ ORZ_D uint32_t rec_lcp(uint64_t lo_a, uint64_t hi_a, uint64_t lo_b, uint64_t hi_
 // staged in LDS once, so a pair costs one LDS read; only pairs that agree on all 12 bytes go to the window.
 // The rows leave through LDS as well, 64 columns at a time, so that every 64-byte piece of a row is written by
 // four neighbouring lanes in one go (a lane storing its own row eight bytes at a time costs a partial line per store).
-struct FastText {  // the slot records, in slot order (one scattered read per slot, once per block)
-    const uint8_t* win;
-    const uint32_t *epos, *keys;
-    uint32_t nent;
-    uint64_t* stext;
-    uint64_t* cl;    // the history slots of a run are final item starts: the head of its compact list (FastRetire appends)
-    uint32_t* ccnt;  // (zeroed) records per list
-    const uint32_t* runstart;
-    ORZ_HD void operator()(size_t j) const {
-        if (j >= nent) return;
-        const uint32_t q = epos[j];
-        const uint64_t lo = ldu64(win + q), hi = (uint64_t)ldu32(win + q + 8) | ((uint64_t)q << 32);
-        stext[2 * j] = lo; stext[2 * j + 1] = hi;
-        if (q < kPre) {
-            cl[2 * j] = lo; cl[2 * j + 1] = hi;
-            // the history slots lead their run (stable sort: history positions first): the last of them knows how many there are
-            if (j + 1 == nent || keys[j + 1] != keys[j] || epos[j + 1] >= kPre) ccnt[keys[j]] = (uint32_t)j + 1 - runstart[keys[j]];
-        }
-    }
-};
 struct FastRowsWave {
     const uint8_t* win;
     const uint32_t* epos;

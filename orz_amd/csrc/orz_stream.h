@@ -724,7 +724,6 @@ class StreamEncoder {
         const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
         be_.memset(vbits_ + nent / 64, 0, 16);  // (the words behind the last slot; FastSlotInitWave writes the others whole)
         be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
-        be_.launch_waves(((size_t)nent + 63) / 64, FastSlotInitWave{epos_, slot_keys, runstart_, nent, vbits_, frlen_}, 0);
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
         be_.launch_waves(((size_t)nk + 63) / 64, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_}, FastWordMasks::lds_bytes());
         // history item starts per (unified subtile, ctx) and their prefix: what the ring horizons reach back into
@@ -734,7 +733,11 @@ class StreamEncoder {
         col_scan(fhcm_, kHistSub, fhpre_);
         uint64_t* stext = fstext_;
         be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
-        be_.launch(nent, FastText{win, epos_, slot_keys, nent, stext, fcl_, fccnt_, runstart_});
+        {
+            FastSlotInitWave si{epos_, slot_keys, runstart_, nent, vbits_, frlen_};
+            si.win = win; si.stext = stext; si.cl = fcl_; si.ccnt = fccnt_;
+            be_.launch_waves(((size_t)nent + 63) / 64, si, 0);
+        }
         be_.timed_begin(2);
         be_.launch_waves(((size_t)nent + 63) / 64, FastRowsWave{win, epos_, stext, frlen_, nent, K, frows_, frdist_}, FastRowsWave::lds_bytes(K));
         be_.timed_end(2);
@@ -816,7 +819,7 @@ class StreamEncoder {
             be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
             be_.memset(&fctl_->lastflips, 0, 4);
-            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);  // (compact lists: every run starts with its history slots, FastText)
+            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);  // (compact lists: every run starts with its history slots, FastSlotInitWave)
             // ---- pipelined Gauss-Seidel rounds
             const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
@@ -1084,7 +1087,7 @@ class StreamEncoder {
         if (inject_kind_ && inject_kind_ != kViLenMin2) be_.launch(1, VerInjectK{inject_kind_, inject_nth_, t.ipos, nitems, TY_, ML_, SRC_, ORD_, win, S_});  // (tests of the gate)
         // len_min of each reference (keys reuse the sort buffers)
         be_.launch(nitems, LenMinKeys{t.ipos, TY_, SRC_, nitems, entA_});
-        const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
+        const uint64_t* lk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits, kPosBits);  // (the keys come in position order: a stable sort by source)
         be_.launch(nitems, LenMinEval{lk, nitems, ML_, LENMIN_, LMV_});
         be_.launch(nitems, LenMinCommit{lk, nitems, ML_, LMV_, LENMIN_});
         if (inject_kind_ == kViLenMin2) be_.launch(1, VerInjectLmv{inject_nth_, t.ipos, nitems, TY_, LMV_});  // (tests of the gate)
@@ -1153,11 +1156,11 @@ class StreamEncoder {
             be_.launch(nitems, VerOrdinals{v});
             be_.launch(nitems, VerMatches{v});
             be_.launch(nitems, VerLmKeys{v, entA_});
-            const uint64_t* lmk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits);
+            const uint64_t* lmk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits, kPosBits);  // (the keys come in item order)
             be_.launch(nitems, VerLenMin{v, lmk});
             be_.launch(nitems, VerLmCommit{v, lmk});
             be_.launch(nitems, VerWordEvents{v, entA_});
-            const uint64_t* evs = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits - 9);  // 15 key bits + 25 position bits + the sentinel's bit
+            const uint64_t* evs = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits - 9, kPosBits);  // 15 key bits + the sentinel's bit above 25 position bits that come in order
             be_.launch(nitems, VerWords{v, evs});
             be_.launch(nitems, VerWordsCarry{v, evs});
             be_.launch(256, VerCarry{v});

@@ -230,9 +230,9 @@ struct EmuBackend {
             orz::rank_chunk(a, ch, c, rows, [&]() {});
         }
     }
-    const uint64_t* sort_u64(uint64_t* a, uint64_t*, size_t n, int bits) {
+    const uint64_t* sort_u64(uint64_t* a, uint64_t*, size_t n, int bits, int begin_bit = 0) {
         uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-        std::stable_sort(a, a + n, [mask](uint64_t x, uint64_t y) { return (x & mask) < (y & mask); });
+        std::stable_sort(a, a + n, [mask, begin_bit](uint64_t x, uint64_t y) { return ((x & mask) >> begin_bit) < ((y & mask) >> begin_bit); });
         return a;
     }
     void sort_by_ctx(const uint16_t* ctx, uint16_t* ctx_sorted, uint32_t* perm, size_t n) {

@@ -28,7 +28,7 @@ cd $REPO
 [ -s $OUT/${TAG}_pmc_hbm_traffic_16MiB_l1.json ] && cp $OUT/${TAG}_pmc_hbm_traffic_16MiB_l1.json $REPO/profiles/${TAG}_pmc_hbm_traffic_16MiB_l1.json
 timeout 600 python bench.py --steps 3 --warmup 1 2>$OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench_100MB_l1.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace_bench.json 2>$OUT/${TAG}_trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-members > $OUT/${TAG}_trace_bench.json 2>$OUT/${TAG}_trace.err
 DB=$(find $OUT/${TAG}_trace -name '*_results.db' | head -1)
 [ -n "$DB" ] && python $REPO/tools/rocpd_summary.py $DB > $OUT/${TAG}_bench_100MB_l1_kernel_stats.csv
 # where the wall time goes: lead before the first ranking launch, gaps between the launches, time after the last one
