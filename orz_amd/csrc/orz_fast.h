@@ -1330,15 +1330,16 @@ struct FastFlip {
         if (dv) {
             if (y < last_hi) atom_add32(lastflips, 1);
             if (a.dbg & 64) atom_add64(&a.stats[16], 1);
-            atom_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
-            if (sw) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));  // (looking at the word first to save the atomic: 44 -> 54 us, a load among the stores)
+            // (the summary bit only has to be set by the flip that makes an empty word non-empty: the XOR hands back the word it found)
+            const uint64_t was = atom_fetch_xor64(&a.vbits[j >> 6], 1ull << (j & 63));
+            if (sw && was == 0) atom_or64(&a.v1[j >> 12], 1ull << ((j >> 6) & 63));
             a.mfb[i] = (uint8_t)sw;
             mark(false, j, nv);
         }
         if (de) {
             if (a.dbg & 64) atom_add64(&a.stats[17], 1);
-            atom_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
-            if (ew) atom_or64(&a.k1[ku >> 12], 1ull << ((ku >> 6) & 63));
+            const uint64_t kwas = atom_fetch_xor64(&a.kbits[ku >> 6], 1ull << (ku & 63));
+            if (ew && kwas == 0) atom_or64(&a.k1[ku >> 12], 1ull << ((ku >> 6) & 63));
             a.efb[i] = (uint8_t)ew;
             mark(true, ku, nk);
             if (kdirty) { const uint32_t key2 = hash2(a.win, y - 3); atom_or64(&kdirty[key2 >> 6], 1ull << (key2 & 63)); }

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-python tools/dev/bisect_emu.py farwalk4
+python tools/dev/bisect_emu.py flip-summary
 run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-members 2>$OUT/r05k_$tag.err | tail -1 > $OUT/r05k_$tag.json
 python - <<PY
 import json
