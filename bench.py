@@ -234,8 +234,9 @@ def kernel_table_rows(ktable, nbytes, pmc):
         if not n:
             continue
         tr = None
+        base = name.split("<")[0].split(" ")[0]
         for k, v in (pmc or {}).items():
-            if k.endswith("<" + name + ">") or k == name:
+            if k.endswith("<" + base + ">") or k == name or (base == "orz_symrank_kernel" and k == base):
                 tr = v
         rows.append({"kernel": name, "launches_per_block": round(n / blocks, 1), "avg_launch_us": round(ms / n * 1e3, 2),
                      "ms_per_block": round(ms / blocks, 3), "hbm_bytes_per_launch": tr,

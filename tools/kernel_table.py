@@ -34,9 +34,10 @@ def main():
     ap.add_argument("--blocks", type=float, default=24.0, help="16 MiB blocks the stats file covers (bench --steps 2 --warmup 1 + profile pass = 24)")
     ap.add_argument("--pmc")
     ap.add_argument("--min-ms", type=float, default=0.05)
+    ap.add_argument("--into", help="a markdown file: the table replaces what stands between <!-- KERNEL_TABLE_BEGIN --> and <!-- KERNEL_TABLE_END -->")
     a = ap.parse_args()
     d = json.loads(open(a.bench).read().strip().splitlines()[-1])
-    rows = {r["kernel"].split(" ")[0].split("<")[0]: r for r in d["kernel_table"]["rows"]}
+    rows = {r["kernel"]: r for r in d["kernel_table"]["rows"]}
     prof = {}
     if a.stats:
         for r in csv.DictReader(open(a.stats)):
@@ -44,23 +45,42 @@ def main():
             c, t = prof.get(k, (0, 0.0))
             prof[k] = (c + int(r["calls"]), t + float(r["total_ns"]))
     pmc = json.load(open(a.pmc)).get("by_name", {}) if a.pmc else {}
-    pmcs = {short(k) if "orz_" in k and "<" not in k else re.sub(r".*<(.*)>", r"\\1", k): v for k, v in pmc.items()}
-    print("| kernel | launches / block | avg launch (events) | ms / block (events) | ms / block (rocprofv3) | HBM bytes / launch (PMC) | GB/s |")
-    print("|---|---|---|---|---|---|---|")
+    pmcs = {}
+    for k, v in pmc.items():
+        m = re.search(r"<([A-Za-z0-9]+)>", k)
+        pmcs.setdefault(m.group(1) if m else short(k), v)
+    out = []
+    _print = out.append
+    _print("| kernel | launches / block | avg launch (events) | ms / block (events) | ms / block (rocprofv3) | HBM bytes / launch (PMC) | GB/s |")
+    _print("|---|---|---|---|---|---|---|")
     tot_e = tot_p = 0.0
+    lib = {"(fill)": "(fill)", "(scan)": "(scan)", "(scan, running maximum)": "(scan)", "(radix sort, pairs)": "(radix sort)",
+           "(radix sort, 64-bit keys)": "(radix sort)", "(radix sort, items by context)": "(radix sort)", "orz_symrank_kernel (+ guard)": "orz_symrank_kernel"}
+    shown = set()
+    all_prof = sum(t for k, (c, t) in prof.items() if "symrank" not in k) / 1e6 / a.blocks
     for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_block"]):
-        p = prof.get(k)
+        pk = lib.get(k, k.split("<")[0])
+        p = prof.get(pk) if pk not in shown else None  # (the library calls of one kind share a row of the stats file: shown once)
+        shown.add(pk)
         pms = p[1] / 1e6 / a.blocks if p else None
         if "symrank" not in k:
             tot_e += r["ms_per_block"]
-            tot_p += pms or 0.0
+            pass
         if r["ms_per_block"] < a.min_ms:
             continue
-        tr = pmcs.get(k) or r.get("hbm_bytes_per_launch")
+        tr = pmcs.get(k.split("<")[0]) or pmcs.get(pk) or r.get("hbm_bytes_per_launch")
         gbs = tr / (r["avg_launch_us"] * 1e-6) / 1e9 if tr else None
-        print("| `%s` | %.1f | %.1f us | %.3f | %s | %s | %s |" % (k, r["launches_per_block"], r["avg_launch_us"], r["ms_per_block"],
+        _print("| `%s` | %.1f | %.1f us | %.3f | %s | %s | %s |" % (k, r["launches_per_block"], r["avg_launch_us"], r["ms_per_block"],
                                                               "%.3f" % pms if pms is not None else "", "%.1f MB" % (tr / 1e6) if tr else "", "%.0f" % gbs if gbs else ""))
-    print("| **sum without the symbol ranking** | | | **%.2f** | **%s** | | |" % (tot_e, "%.2f" % tot_p if tot_p else ""))
+    _print("| **sum without the symbol ranking** | | | **%.2f** | **%s** | | |" % (tot_e, "%.2f" % all_prof if prof else ""))
+    text = "\n".join(out) + "\n"
+    if a.into:
+        doc = open(a.into).read()
+        b0, b1 = "<!-- KERNEL_TABLE_BEGIN -->", "<!-- KERNEL_TABLE_END -->"
+        i, j = doc.index(b0) + len(b0), doc.index(b1)
+        open(a.into, "w").write(doc[:i] + "\n" + text + doc[j:])
+    else:
+        print(text, end="")
 
 
 if __name__ == "__main__":

@@ -27,11 +27,17 @@ if __name__ == "__main__":
         rows.append({"kernel": name[:100], "dispatches": int(max(nf, nw)),
                      "fetch_KiB_per_dispatch": round(sf / nf, 1) if nf else None,
                      "write_KiB_per_dispatch": round(sw / nw, 1) if nw else None})
-    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes; scattered loads count 128 B per line, see pmc_calibrate.py)", "kernels": rows[:32]}
+    res = {"units": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes; scattered loads count 128 B per line, see pmc_calibrate.py)", "kernels": rows[:80]}
+    res["total_bytes_all_kernels"] = int(sum(((r["fetch_KiB_per_dispatch"] or 0) + (r["write_KiB_per_dispatch"] or 0)) * 1024 * r["dispatches"] for r in rows))
     # HBM bytes per launch under the names bench.py uses for its roofline rows
     short = {"FastEval": "orz_thread_kernel<FastEval>", "ParseWave": "orz_wave_kernel<ParseWave>", "orz_symrank_kernel": "orz_symrank_kernel",
              "FastRowsWave": "orz_wave_kernel<FastRowsWave>", "PathUpWave": "orz_wave_kernel<PathUpWave>"}
     res["by_name"] = {}
+    import re
+    for r in rows:  # every kernel of the library under the functor's name, as bench.py's kernel_table spells it (round 5)
+        m = re.search(r"orz_(?:thread_kernel(?:_occ)?|wave_kernel|group_kernel)INS_\d+([A-Za-z0-9]+?)(?:I[a-z]E)?EEEvT_", r["kernel"])
+        if m:
+            res["by_name"]["<%s>" % m.group(1)] = int(((r["fetch_KiB_per_dispatch"] or 0) + (r["write_KiB_per_dispatch"] or 0)) * 1024)
     for r in rows:
         for key, name in short.items():
             if key in r["kernel"]:
