@@ -637,7 +637,9 @@ struct FastEval {
                     return l != kMaxLen;
                 };
                 const uint32_t key = c * kHash + hash_entry(win + p);
-                const uint32_t rs = a.runstart[key], cnt = a.ccnt[key];
+                // (the records a retiring tile appended in the step before are counted in cnew until the next FastDecide's grid
+                // folds them into ccnt -- PathUpWave's piggy-backed FastRetireDone)
+                const uint32_t rs = a.runstart[key], cnt = a.ccnt[key] + a.cnew[key];
                 // ---- 2. item starts below the window that are not in the lists yet: four at a time -- their slots from the
                 // bitmap, their records side by side, then in order -- until the lists take over (below `cline`), the budget
                 // is spent or `near` of them were looked at.  (One hot context -- zeros with noise -- has its whole ring
@@ -1057,16 +1059,54 @@ ORZ_D void st8_pad68(uint8_t* tab, uint32_t x, uint64_t v) {
 struct PathUpWave {
     FastArgs a;
     uint32_t c0;
+    // round 5: the launch can also DECIDE (FastDecide's job: every part makes the chunk's decisions from ev for its own staging --
+    // four times the arithmetic, one launch less -- and stores its quarter of ty / nl) and fold the counters of the tile that
+    // retired in the step before (FastRetireDone: the blocks behind the chunks' 4 x nchunks).  Alone a step is 20 us longer that
+    // way (round 2's measurement); under eight encoders a launch waits ~100 us for its turn whatever its size (rocprofv3, eight encoders: FastDecide 4.9 -> 124 us,
+    // FastRetireDone 6.5 -> 125 us, a fill 4.5 -> 118 us): the number of launches a block is what the aggregate pays for.
+    uint32_t decide = 0, nup = 0;  // decide: 0 = advances come from a.nl; nup: blocks that belong to the chunks
+    FastRetireDone done{};
     static size_t lds_bytes() { return 2 * 64 * 68 + 64; }
     template <class W>
     ORZ_D void operator()(W& w) const {
+        if (decide && w.block() >= nup) {  // the piggy-backed FastRetireDone
+            const uint32_t t = (w.block() - nup) * 64 + w.lane();
+            done((size_t)t);
+            return;
+        }
         uint8_t* nlL = w.lds();
         uint8_t* x0L = nlL + 64 * 68 + 32;
         const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
         for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
             const uint32_t x = (k * 64 + lane) * 8;
-            st8_pad68(nlL, x, x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0);
+            if (!decide) {
+                st8_pad68(nlL, x, x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0);
+                continue;
+            }
+            uint64_t nlw = 0, tyw = 0;
+            if (x < clen) {
+                const uint32_t i0 = (cs - kPre) + x;  // (a multiple of 8: the ten answers the eight decisions look at)
+                uint32_t e[10];
+#pragma unroll
+                for (uint32_t q = 0; q < 10; q++) e[q] = cs + x + q < a.len ? a.ev[i0 + q] : 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) {
+                    const uint32_t p = cs + x + q;
+                    const uint32_t d = p < a.len ? fast_decide(p, a.len, e[q], e[q + 1], e[q + 2]) : 0;
+                    tyw |= (uint64_t)(d & 0xff) << (8 * q);
+                    nlw |= (uint64_t)((d >> 8) & 0xff) << (8 * q);
+                }
+                if ((x >> 10) == part) {  // every part stores a quarter (positions < clen only: a chunk's tail word is cut below)
+                    if (x + 8 <= clen) {
+                        *reinterpret_cast<uint64_t*>(a.ty + i0) = tyw;
+                        *reinterpret_cast<uint64_t*>(a.nl + i0) = nlw;
+                    } else {
+                        for (uint32_t q = 0; x + q < clen; q++) { a.ty[i0 + q] = (uint8_t)(tyw >> (8 * q)); a.nl[i0 + q] = (uint8_t)(nlw >> (8 * q)); }
+                    }
+                }
+            }
+            st8_pad68(nlL, x, nlw);
         }
         w.sync();
         // Exits of the lane's own segment by a backward sweep (a position either leaves the segment or inherits the exit of the

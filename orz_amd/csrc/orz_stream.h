@@ -855,10 +855,21 @@ class StreamEncoder {
                 // (a 64-register build of FastEval -- eight waves per SIMD instead of six, 41 registers spilled -- measured 134 vs 124 us)
                 be_.launch(hi2 - lo, FastEval{a, lo, hi2, r1lo, r2lo, step, cline});
                 be_.timed_end();
-                be_.launch(hi - lo, FastDecide{a, lo, hi});
                 const uint32_t c0 = t_lo * cpt, nc = (hi - (kPre + c0 * kSub) + kSub - 1) / kSub, nt = t_hi - t_lo + 1;
                 be_.timed_begin(3);
-                be_.launch_waves((size_t)nc * 4, PathUpWave{a, c0}, PathUpWave::lds_bytes());
+                if (fused_steps) {
+                    // ONE launch decides (FastDecide), draws up the chunk maps (PathUpWave) and folds the counters of the tile that
+                    // retired in the step before (FastRetireDone): under several encoders a launch waits its turn for ~100 us
+                    // whatever its size, so a step is six launches now (round 4: ten)
+                    const bool had_retire = step - 1 >= R && step - 1 < ntile + R - 1;
+                    const uint32_t plo = had_retire ? kPre + (step - 1 - R) * T : kPre, phi = had_retire ? (uint32_t)std::min<uint64_t>(len, (uint64_t)plo + T) : kPre;
+                    PathUpWave up{a, c0};
+                    up.decide = 1; up.nup = nc * 4; up.done = FastRetireDone{a, plo, phi, fcut_};
+                    be_.launch_waves((size_t)nc * 4 + (phi - plo + 63) / 64, up, PathUpWave::lds_bytes());
+                } else {
+                    be_.launch(hi - lo, FastDecide{a, lo, hi});
+                    be_.launch_waves((size_t)nc * 4, PathUpWave{a, c0}, PathUpWave::lds_bytes());
+                }
                 be_.timed_end(3);
                 be_.launch_group(PathTileDown{a, t_lo, nt});
                 be_.launch_waves(nc, PathMarkWave{a, c0}, PathMarkWave::lds_bytes());
@@ -878,7 +889,7 @@ class StreamEncoder {
                     const uint32_t nflip = fhi - lo + 1, nret = rhi - rlo;
                     be_.launch_waves((size_t)(nflip + 63) / 64 + 256, FlipPrefixWave{ff, fp, nflip}, 0);
                     be_.launch_waves((size_t)(nret + 63) / 64 + (fh.threads() + 63) / 64, RetireHorizonWave{FastRetire{a, rlo, rhi, fcut_}, fh, nret}, 0);
-                    if (retire) be_.launch(rhi - rlo, FastRetireDone{a, rlo, rhi, fcut_});
+                    // (FastRetireDone: in the next step's FastDecide grid -- every retiring step is followed by one)
                 } else {
                     be_.launch((size_t)fhi - lo + 1, ff);
                     be_.launch_waves(256, fp, 0);
