@@ -414,6 +414,27 @@ def main():
 
         order = sorted(range(4), key=lambda i: -kt[i][0])
         roofs = [r for r in (roof(i) for i in order) if r]
+        # ... and every other kernel of the profiled pass that takes a millisecond or more of a 16 MiB block (task 7):
+        # the same arithmetic from the per-name table (one profiled pass over the workload)
+        blocks = max(1.0, len(data) / float(1 << 24))
+        seen_k = {r["kernel"].split("<")[-1].rstrip(">") for r in roofs}
+        for name, ms, n in ktable:
+            kname = name.split("<")[0].split(" ")[0]
+            if not n or kname in seen_k or "symrank" in kname or ms / blocks < 1.0:
+                continue
+            avg_s = ms / 1e3 / n
+            bpl = ALGO_BYTES_PER_INPUT_BYTE * len(data) / n
+            tr = None
+            for k, v in (pmc or {}).items():
+                if k.endswith("<" + kname + ">"):
+                    tr = v
+            roofs.append({"bound": "hbm", "kernel": name, "achieved": round(bpl / avg_s / 1e9, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(bpl / avg_s / 1e9 / HBM_PEAK_GBS, 8), "traffic": tr,
+                          "traffic_source": ("from_profile: " + pmc_file) if tr is not None else None,
+                          "hbm_gbs": round(tr / avg_s / 1e9, 3) if tr is not None else None,
+                          "hbm_frac_of_peak": round(tr / avg_s / 1e9 / HBM_PEAK_GBS, 6) if tr is not None else None,
+                          "launches_per_step": n, "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": round(bpl, 1),
+                          "device_ms_per_step": round(ms, 2)})
         res = {
             "metric": "orz -l1 encode throughput (enwik8-shaped text, 100 MB, one 16 MiB block in flight)",
             "value": round(value, 3),
