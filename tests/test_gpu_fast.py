@@ -408,3 +408,31 @@ def test_more_items_than_the_tail_buffers_start_with(oracle):
         enc.close()
     oracle.assert_decodes_to(out, data, "random bytes")
     oracle.assert_decodes_to(out2, text, "text after the buffers grew")
+
+
+def test_host_waits_per_block_and_the_kernel_table(oracle):
+    """round 5: one wait per block for the parse (control block + item count together), two when a block's output is collected --
+    counted by the library (orz_encode_stats.host_syncs); and a profiled encode names every kernel it launched
+    (orz_stream_get_kernel_table)"""
+    import corpus
+    import orz_amd
+
+    data = corpus.enwik_like(70_000_000)  # four full blocks and a part
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        enc.encode(data[:20_000_000])  # (warm-up: graph capture, first-use allocations)
+        out, st = enc.encode(data, stats=True)
+        assert st["blocks"] == 5
+        assert st["host_syncs"] <= 4 * st["blocks"] + 4, st  # (3 a block + the call's own opening and closing waits; round 4: 9 a block and more)
+        enc.set_profile(True)
+        out2, st2 = enc.encode(data[:20_000_000], stats=True)
+        table = enc.kernel_table()
+        enc.set_profile(False)
+    finally:
+        enc.close()
+    oracle.assert_decodes_to(out, data, "70 MB of text")
+    names = {name for name, ms, n in table}
+    for must in ("FastEval", "PathUpWave", "PathMarkWave", "FlipPrefixWave", "RetireHorizonWave", "FastRowsWave", "RepairListWave", "FastSourceL", "OrdWave2", "VerLenMin"):
+        assert must in names, (must, sorted(names))
+    assert all(ms > 0 and n > 0 for name, ms, n in table)
+    assert any(name.startswith("orz_symrank_kernel") for name in names)
