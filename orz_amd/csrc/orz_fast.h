@@ -589,8 +589,10 @@ ORZ_D uint32_t lcp_after12(const uint8_t* win, uint32_t q, uint32_t p, uint64_t 
 // All parts together may look at more than `depth` candidates -- the depth is the reference's speed limit, not a rule of
 // the format -- which is why this parse can come out smaller than the reference's.
 #if !defined(__HIPCC__)
-inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-inline unsigned long long g_scan_hist[4][64] = {};  // (experiments) [0] first-round scans by window candidates seen, [1] last-round ones, [2] last-round ones whose answer differs from the remembered one, [3] ... by item starts in the window  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
+inline unsigned long long g_eval_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (host emulation only: positions visited, evaluated, by round-1 / dirty / scan-due)
+// (host emulation only, ORZ_SCAN_HIST) scans by the candidates the window had counted: [0] first-round scans, [1] last-round ones,
+// [2] last-round ones whose answer differs from the remembered one, [3] the same by item starts in the window
+inline unsigned long long g_scan_hist[4][64] = {};
 #endif
 struct FastEval {
     FastArgs a;
