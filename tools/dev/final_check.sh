@@ -1,5 +1,8 @@
 #!/bin/bash
-# dev: the whole GPU tier once more on the shipped library
 export TMPDIR=/tmp
-timeout 1100 python -u -m pytest tests -m gpu -q --timeout=400 --durations=8 > gpurun_out/r05_pytest_gpu.log 2>&1
-tail -12 gpurun_out/r05_pytest_gpu.log
+for nr in 16 8 12; do
+ORZ_FAST_NEAR=$nr timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-members 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d['kernel_table']
+print('near=$nr', d['value'], d['compressed_bytes'], d['roundtrip_ok'], 'sum', t['sum_ms_per_block_without_symbol_ranking'], [(r['kernel'][:14], r['avg_launch_us']) for r in t['rows'][1:3]])"
+done
