@@ -80,7 +80,7 @@ def _meminfo_available_bytes():
     return None
 
 
-def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, device=0):
+def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, device=0, nproc=None):
     """Outside the timed region, rank 0 at N=1 only: the aggregate path of BASELINE configs[2]/[3] on ONE GPU and its CPU baseline
     (the reference's harness, /root/reference/benchmark-tool/src/main.rs:57-114, times an encoder
     process and verifies its output by decoding it).
@@ -109,7 +109,7 @@ def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, 
     del src
     streams = odist.split_members(blob)
     assert n == len(members) == len(streams)
-    res = members_check_and_cpu(members, streams, level)
+    res = members_check_and_cpu(members, streams, level, nproc=nproc)
     gpu_mbs = len(data) / t_gpu / 1e6
     res["members"].update({"value": round(gpu_mbs, 1), "unit": "MB/s", "encoders_on_one_gpu": jobs, "seconds": round(t_gpu, 3),
                            "input": "resident in HBM",
@@ -118,7 +118,7 @@ def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, 
     return res
 
 
-def members_check_and_cpu(members, streams, level, max_procs=None):
+def members_check_and_cpu(members, streams, level, max_procs=None, nproc=None):
     """the host half of members_leg: `streams[k]` must decode to `members[k]` with the oracle's decoder (a process each);
     the oracle's encoder on the same members, one process per host core, timed"""
     import shutil
@@ -182,6 +182,8 @@ def members_check_and_cpu(members, streams, level, max_procs=None):
             ladder.append(c)
             c *= 4
         ladder.append(cap)
+        if nproc:  # (a later leg of the same run: the process count the first leg's ladder found best, probed once at this level)
+            ladder = [min(nproc, cap)]
         probe = []
         for c in ladder:
             dt = run_encoders(c, lambda k: os.path.join(work, "slice.in"), lambda k: os.path.join(work, "s%d.orz" % k))
@@ -335,12 +337,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the finished stream stays in HBM (orz_stream_encode_to_device, framed on the device) and the gather sends it from
+    # there; N = 1: the headline's timed region ends with the stream in a host buffer (orz_stream_encode), as before
+    dout = torch.empty(orz_amd.stream_bound(src.numel()), dtype=torch.uint8, device=dev) if distributed else None
+
     def step():
-        # (the stream stays in the buffer the library returned; the gather below sends it from there)
-        out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True, raw=True)
+        if distributed:
+            n_out, st = enc.encode_to_device(src.data_ptr(), src.numel(), dout.data_ptr(), dout.numel(), stats=True)
+            out = dout[:n_out]
+        else:
+            out, st = enc.encode_device(src.data_ptr(), src.numel(), stats=True, raw=True)
         if distributed:  # the job's only exchange: gather the finished bitstreams on rank 0
             tg = time.time()
-            got = odist.gather_members({rank: out}, world, rank, world, device=dev if backend == "nccl" else None, to_host=False)
+            payload = out if backend == "nccl" else out.cpu()
+            got = odist.gather_members({rank: payload}, world, rank, world, device=dev if backend == "nccl" else None, to_host=False)
             if rank == 0:  # (the members of the other ranks stay in rank 0's HBM: gathered, not copied out again)
                 assert all(g is not None and len(g) > 0 for g in got)
             gather_s[0] += time.time() - tg
@@ -435,6 +445,7 @@ def main():
                           "hbm_frac_of_peak": round(tr / avg_s / 1e9 / HBM_PEAK_GBS, 6) if tr is not None else None,
                           "launches_per_step": n, "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": round(bpl, 1),
                           "device_ms_per_step": round(ms, 2)})
+        out_bytes = out.cpu().numpy().tobytes() if isinstance(out, torch.Tensor) else bytes(out)
         res = {
             "metric": "orz -l1 encode throughput (enwik8-shaped text, 100 MB, one 16 MiB block in flight)",
             "value": round(value, 3),
@@ -459,9 +470,9 @@ def main():
                 "encoder": cfg,  # read back through orz_stream_get_config
                 "input": "resident in HBM",
             },
-            "compressed_bytes": len(out),
-            "compressed_sha256": hashlib.sha256(bytes(out)).hexdigest(),  # (profiles/r05_emulation_100MB.txt: the host emulation's stream of the same workload)
-            "ratio": round(len(out) / len(data), 5),
+            "compressed_bytes": len(out_bytes),
+            "compressed_sha256": hashlib.sha256(out_bytes).hexdigest(),  # (profiles/r05_emulation_100MB.txt: the host emulation's stream of the same workload)
+            "ratio": round(len(out_bytes) / len(data), 5),
             "items_per_byte": round(agg["items"] / args.steps / len(data), 4),
             "rounds_or_sweeps_per_step": agg["sweeps"] // args.steps,
             "repairs_per_step": agg["seg_evals"] // args.steps if cfg["mode"] == 1 else None,
@@ -490,22 +501,34 @@ def main():
         }
         # parity of what was timed, outside the timed region: the last timed stream through the oracle's decoder, and its
         # size against the oracle's encoder (the cpu_baseline leg encodes the same bytes)
-        ok, dec_s = oracle_check(data, bytes(out))
+        ok, dec_s = oracle_check(data, out_bytes)
         res["roundtrip_ok"] = bool(ok)
         res["roundtrip_checker"] = "oracle decoder (oracle/orz_oracle.c), %.2f s" % dec_s
         res["size_delta_pct"] = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:  # (rank 0, whatever N: the same one-thread oracle pass over the unrotated workload)
             res["cpu_baseline"] = cpu_baseline(base, LEVEL)
             ref = res["cpu_baseline"]["compressed_bytes"]
-            res["size_delta_pct"] = round(100.0 * (len(out) - ref) / ref, 4)
-        elif not args.no_cpu_baseline:
-            res["cpu_baseline"] = None
+            res["size_delta_pct"] = round(100.0 * (len(out_bytes) - ref) / ref, 4)
         if world == 1 and not args.no_members:
             enc.close()  # (the lone encoder's ~5 GB go back before eight more are built)
             try:
                 res.update(members_leg(base, LEVEL, total=args.members_bytes, device=local_rank))
             except Exception as e:  # the headline line must not be lost to its annex
                 res["members"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # BASELINE configs[2] / configs[4] at -l2 (src/main.rs:97-102: 45/27/18), ~0.5 GB each, eight encoders, every member
+            # through the oracle's decoder, size against the oracle on the same split, the many-core CPU baseline at -l2 beside it
+            nproc = (res.get("cpu_baseline_members") or {}).get("cores")
+            l2_total = min(args.members_bytes, 8 << 26)
+            for key, make in (("members_l2_text", lambda: base), ("members_l2_zeros", lambda: corpus.zeros_noise(l2_total))):
+                try:
+                    leg = members_leg(make(), 2, total=l2_total, device=local_rank, nproc=nproc)
+                    leg["members"]["cpu_baseline_members"] = leg["cpu_baseline_members"]
+                    leg["members"]["gpu_over_cpu_members"] = leg["gpu_over_cpu_members"]
+                    leg["members"]["workload"] = ("BASELINE configs[2]: enwik8-shaped text, -l2" if key.endswith("text") else
+                                                  "BASELINE configs[4]: zeros + 1 % noise, -l2") + ", %d bytes in 64 MiB members" % l2_total
+                    res[key] = leg["members"]
+                except Exception as e:
+                    res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(res), flush=True)
     enc.close()
     if distributed:

@@ -139,6 +139,14 @@ int orz_stream_set_tuning(orz_stream*, unsigned seg_bytes, unsigned window_segs)
 int orz_stream_encode(orz_stream*, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
                       orz_encode_stats* stats);
 void orz_free(void* p);
+/* The same, with the finished stream left in DEVICE memory the caller owns (round 6): `d_dst` = `d_cap` bytes on the stream's
+ * device; *dst_len bytes are written -- { LEB128(t) chunk[t] }* and the EOF byte, framed on the device (src/lib.rs:79-80,89).
+ * The analogue of the reference handing LZEncoder::encode a caller-owned `tbuf` (src/lz.rs:89-95), for a whole stream: what the
+ * multi-GPU gather sends from where it lies.  d_cap >= orz_stream_bound(n) always suffices; a buffer that turns out too small
+ * fails the encode (ORZ_ENOMEM) without a byte of the overflowing block written.  One host wait per 16 MiB block and one per stream. */
+size_t orz_stream_bound(size_t n);
+int orz_stream_encode_to_device(orz_stream*, const void* src, size_t n, int src_on_device, uint8_t* d_dst, size_t d_cap,
+                                size_t* dst_len, orz_encode_stats* stats);
 
 /* Per-item trace of the last orz_stream_encode call (diagnostics / stage-level parity tests):
  * what the parse decided for each item, in stream order.  Mirrors the reference's MatchItem
@@ -176,6 +184,12 @@ orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_
 void orz_members_free(orz_members*);
 int orz_members_encode(orz_members*, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
                        size_t* dst_len, size_t* n_members_out);
+/* The same with the members' streams left in DEVICE memory the caller owns (round 6; all workers on ONE device): they are
+ * written into `d_dst` (`d_cap` bytes on that device) in whatever order they finish; member k's stream is the
+ * lens[k] bytes at d_dst + offs[k] (`offs`, `lens`: host arrays of at least (n + member_bytes - 1) / member_bytes entries,
+ * 1 for n = 0).  d_cap >= orz_stream_bound(member_bytes) * members always suffices; ORZ_ENOMEM when the buffer fills. */
+int orz_members_encode_to_device(orz_members*, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t* d_dst,
+                                 size_t d_cap, size_t* offs, size_t* lens, size_t* n_members_out);
 /* decodes every stream of a concatenation (a plain single stream is the 1-member case) */
 int orz_decode_members_mem(const uint8_t* src, size_t n, uint8_t** dst, size_t* dst_len, size_t* n_members_out);
 

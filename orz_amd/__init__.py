@@ -6,7 +6,7 @@ kernels for gfx950 behind the C ABI of include/orz_hip.h).
 """
 from ._native import LIB_PATH, EncodeStats, LZCfg  # noqa: F401
 from .api import (LZEncoder, OrzError, MemberEncoder, StreamEncoder, cfg_for_level, decode, decode_bytes,  # noqa: F401
-                  decode_members, decode_members_device, encode, encode_bytes, huffman_tables)
+                  decode_members, decode_members_device, encode, encode_bytes, huffman_tables, stream_bound)
 
 LZ_BLOCK_SIZE = (1 << 25) - 1  # src/lib.rs:31
 SBVEC_SENTINEL_LEN = 480  # src/lib.rs:54

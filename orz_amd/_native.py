@@ -131,6 +131,19 @@ SYMBOLS = [
          ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(EncodeStats)],
     ),
     ("orz_free", None, [ctypes.c_void_p]),
+    ("orz_stream_bound", ctypes.c_size_t, [ctypes.c_size_t]),
+    (
+        "orz_stream_encode_to_device",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(EncodeStats)],
+    ),
+    (
+        "orz_members_encode_to_device",
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
+    ),
     ("orz_members_new_multi", ctypes.c_void_p, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(LZCfg), ctypes.c_int]),
     ("orz_members_new", ctypes.c_void_p, [ctypes.c_int, ctypes.POINTER(LZCfg), ctypes.c_int]),
     ("orz_members_free", None, [ctypes.c_void_p]),

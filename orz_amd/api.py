@@ -29,6 +29,11 @@ def cfg_for_level(level):
     return cfg
 
 
+def stream_bound(nbytes):
+    """device bytes that always hold the stream of `nbytes` input bytes (orz_stream_bound)"""
+    return int(_native.load().orz_stream_bound(int(nbytes)))
+
+
 class OrzBuffer:
     """A stream the library returned (malloc'ed by orz_stream_encode), held without copying; freed with orz_free."""
 
@@ -142,6 +147,18 @@ class StreamEncoder:
         out, st = self._encode(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, stats, raw)
         return (out, st) if stats else out
 
+    def encode_to_device(self, src_ptr, nbytes, dst_ptr, dst_cap, src_on_device=True, stats=False):
+        """Encode into DEVICE memory the caller owns (orz_stream_encode_to_device): the finished stream -- framed on the
+        device -- is left at `dst_ptr` (`dst_cap` bytes on this encoder's GPU; `stream_bound(nbytes)` always suffices).
+        Returns its length (and the stats dict).  What the multi-GPU gather sends from where it lies."""
+        dlen = ctypes.c_size_t()
+        st = EncodeStats()
+        rc = self._lib.orz_stream_encode_to_device(self._h, ctypes.c_void_p(int(src_ptr)), int(nbytes), 1 if src_on_device else 0,
+                                                   ctypes.c_void_p(int(dst_ptr)), int(dst_cap), ctypes.byref(dlen),
+                                                   ctypes.byref(st) if stats else None)
+        _check(rc, "orz_stream_encode_to_device")
+        return (dlen.value, st.as_dict()) if stats else dlen.value
+
     def set_item_trace(self, on=True):
         _check(self._lib.orz_stream_set_item_trace(self._h, 1 if on else 0), "orz_stream_set_item_trace")
 
@@ -250,6 +267,18 @@ class MemberEncoder:
 
     def encode_device(self, dev_ptr, nbytes, member_bytes=1 << 26):
         return self._run(ctypes.c_void_p(int(dev_ptr)), int(nbytes), True, member_bytes)
+
+    def encode_to_device(self, src_ptr, nbytes, dst_ptr, dst_cap, member_bytes=1 << 26, src_on_device=True):
+        """The members' streams left in DEVICE memory the caller owns (orz_members_encode_to_device; one GPU): returns
+        [(offset, length)] per member, in member order, into the buffer at `dst_ptr`."""
+        nm = 1 if nbytes == 0 else (int(nbytes) + int(member_bytes) - 1) // int(member_bytes)
+        offs, lens = (ctypes.c_size_t * nm)(), (ctypes.c_size_t * nm)()
+        got = ctypes.c_size_t()
+        rc = self._lib.orz_members_encode_to_device(self._h, ctypes.c_void_p(int(src_ptr)), int(nbytes), 1 if src_on_device else 0,
+                                                    int(member_bytes), ctypes.c_void_p(int(dst_ptr)), int(dst_cap), offs, lens,
+                                                    ctypes.byref(got))
+        _check(rc, "orz_members_encode_to_device")
+        return [(offs[k], lens[k]) for k in range(got.value)]
 
     def close(self):
         if self._h:

@@ -527,45 +527,14 @@ class StreamPool {
     }
 
    private:
-    // ORZ_CU_PART (experiments, round 5): the encoders of a process each on a share of the GPU's compute units instead of all
-    // of them on all -- "x<N>": share k = the CUs whose index is k modulo N (the driver deals a mask's bits out to the XCDs in
-    // turn, so with N = 8 a share is one XCD and its L2), "c<N>": N contiguous ranges of the mask; a trailing "m": only the
-    // main (parse) stream is masked, the ranking / tail / copy streams keep the whole device.
+    // (Round 5 measured two other ways to share the GPU here -- a share of the compute units per encoder through
+    // hipExtStreamCreateWithCUMask, and several encoders on one main stream -- both worse; the knobs are gone.)
     static Set create(bool rank_prio) {
         Set t;
         int prio_low = 0, prio_high = 0;
         ORZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        static const char* part = getenv("ORZ_CU_PART");
-        static std::atomic<unsigned> serial{0};
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        bool masked = false, main_only = false;
-        if (part && (part[0] == 'x' || part[0] == 'c') && atoi(part + 1) > 1) {
-            const unsigned n = (unsigned)atoi(part + 1), k = serial.fetch_add(1) % n;
-            int cus = 0;
-            ORZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-            if (cus > 256) cus = 256;
-            for (int b = 0; b < cus; b++) {
-                const bool mine = part[0] == 'x' ? (unsigned)b % n == k : (unsigned)b * n / (unsigned)cus == k;
-                if (mine) mask[b >> 5] |= 1u << (b & 31);
-            }
-            masked = true;
-            main_only = part[strlen(part) - 1] == 'm';
-        }
-        // ORZ_SHARE_MAIN=<k> (experiments, round 5): k encoders in a row take the SAME main stream -- their parse kernels follow
-        // each other in submission order instead of running side by side (what the runtime's queue mapping did by accident
-        // for a process's first eight encoders: main streams in pairs on one hardware queue)
-        static const int share = getenv("ORZ_SHARE_MAIN") ? atoi(getenv("ORZ_SHARE_MAIN")) : 0;
-        static hipStream_t shared_main = nullptr;
-        static unsigned shared_left = 0;
         for (int i = 0; i < kStreams; i++) {
-            if (i == 0 && share > 1 && !masked) {
-                if (!shared_left) { ORZ_HIP_CHECK(hipStreamCreateWithFlags(&shared_main, hipStreamNonBlocking)); shared_left = (unsigned)share; }
-                shared_left--;
-                t.s[0] = shared_main;
-                continue;
-            }
-            if (masked && (i == 0 || !main_only)) ORZ_HIP_CHECK(hipExtStreamCreateWithCUMask(&t.s[i], 8, mask));
-            else if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
+            if (i == 1 && rank_prio) ORZ_HIP_CHECK(hipStreamCreateWithPriority(&t.s[i], hipStreamNonBlocking, prio_high));
             else ORZ_HIP_CHECK(hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking));
         }
         return t;
@@ -788,6 +757,10 @@ class HipBackend {
         }
     }
     void sync() { ORZ_HIP_CHECK(hipStreamSynchronize(stream_)); nsync_++; }
+    // the closing time stamp of an encode whose stream stays on the device: recorded on the stream that finishes it (the copy
+    // stream, behind the last frame kernel), so that no extra wait on the main stream is needed to read the elapsed time
+    void set_end_event(hipEvent_t e) { end_ev_ = e; }
+    void mark_end() { if (end_ev_) ORZ_HIP_CHECK(hipEventRecord(end_ev_, stream_)); }
     void parse_token_acquire() { if (!lone_) ParseTokens::of(device_).acquire(); }
     void parse_token_release() { if (!lone_) ParseTokens::of(device_).release(); }
     // counts the host derives instead of reading them back are verified against the device only on request
@@ -971,8 +944,7 @@ class HipBackend {
         ORZ_HIP_CHECK(hipGraphLaunch(it->second, stream_));
         return true;
     }
-    // (captured on a stream of the backend's own: the main stream may be shared with another encoder's thread -- ORZ_SHARE_MAIN --
-    // whose launches must not end up in this graph; nothing executes during a capture, the graph is launched on the main stream)
+    // (captured on a stream of the backend's own; nothing executes during a capture, the graph is launched on the main stream)
     void graph_capture_begin() {
         if (!cap_stream_) ORZ_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
         run_stream_ = stream_;
@@ -1010,7 +982,9 @@ class HipBackend {
         graph_exec_.clear();
     }
     // profile mode: HIP-event brackets around the kernels inside the round loop (so no graph replay)
-    void set_profile(bool on) { profile_ = on; }
+    void set_profile(bool on) { profile_ = on; nev_used_ = 0; nest_ = 0; }
+    // the brackets of a profiled encode nobody collected (stats == NULL) must not pile up, nor leak into the next table
+    void begin_encode() { nev_used_ = 0; nest_ = 0; ev_used_ = 0; }
     bool profile() const { return profile_; }
 
     // Symbol ranking of one block, guarded.  The ranks of the hand-scheduled kernel are checked against the one property
@@ -1079,7 +1053,8 @@ class HipBackend {
     bool lone_ = true, rank_prio_ = false;
     hipStream_t stream_ = nullptr;
     hipStream_t cap_stream_ = nullptr, run_stream_ = nullptr;  // graph capture (see graph_capture_begin)
-    static constexpr int kStreams = StreamPool::kStreams, kEvents = 8;  // (stream 3 only copies finished output to the host: no temporary storage)
+    hipEvent_t end_ev_ = nullptr;
+    static constexpr int kStreams = StreamPool::kStreams, kEvents = 16;  // (stream 3 only copies finished output to the host: no temporary storage)
     hipStream_t streams_[kStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sev_[kEvents];
     void* tmps_[kStreams] = {nullptr, nullptr, nullptr, nullptr};

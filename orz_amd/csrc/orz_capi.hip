@@ -5,6 +5,7 @@
 // There is no CPU fallback: if no HIP device is usable every constructor fails with ORZ_ENODEV.
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
 #include <string>
@@ -266,60 +267,94 @@ int orz_stream_get_config(orz_stream* s, orz_stream_config* out) {
     out->unit_bytes = s->enc->unit_bytes();
     return ORZ_OK;
 }
+// One stream through the encoder with the finished stream left in device memory (`d_dst` / `d_cap`: the caller's buffer, or nullptr
+// for the encoder's own): the common body of orz_stream_encode and orz_stream_encode_to_device.  Throws.
+static orz::StreamEncoder<orz::HipBackend>::DeviceResult stream_encode_device(orz_stream* s, const void* src, size_t n, int src_on_device,
+                                                                              uint8_t* d_dst, size_t d_cap, orz_encode_stats* stats) {
+    orz::HipBackend& be = *s->be;
+    be.set_timing(stats != nullptr);
+    be.begin_encode();
+    struct Events {  // destroyed on every path out of this function
+        orz::HipBackend& be;
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { be.set_end_event(nullptr); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev{be};
+    ORZ_HIP_CHECK(hipSetDevice(be.device()));
+    ORZ_HIP_CHECK(hipEventCreate(&ev.a));
+    ORZ_HIP_CHECK(hipEventCreate(&ev.b));
+    ORZ_HIP_CHECK(hipEventRecord(ev.a, be.stream()));
+    be.set_end_event(ev.b);  // (recorded behind the stream's last frame kernel, before the closing wait: finish_device)
+    s->trace.clear();
+    struct Pin {  // host input: page-lock it for the call so the block uploads are real asynchronous DMA
+        void* p = nullptr;
+        ~Pin() { if (p) (void)hipHostUnregister(p); }
+    } pin;
+    bool pinned = false;
+    if (!src_on_device && n >= (1u << 20) && hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) {
+        pin.p = const_cast<void*>(src);
+        pinned = true;
+    } else {
+        (void)hipGetLastError();  // (registration refused: pageable copies, synchronised per block)
+    }
+    const auto r = orz::encode_stream_device(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, d_dst, d_cap, pinned);
+    if (stats) {
+        float total = 0;
+        ORZ_HIP_CHECK(hipEventElapsedTime(&total, ev.a, ev.b));
+        const orz::EncodeStats& st = s->enc->stats;
+        stats->blocks = st.blocks; stats->sweeps = st.sweeps; stats->seg_evals = st.seg_evals;
+        stats->items = st.items; stats->chunks = st.chunks; stats->in_bytes = st.in_bytes;
+        stats->out_bytes = r.len;
+        stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
+        stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
+        stats->total_ms = total;
+        stats->host_syncs = st.host_syncs + be.take_host_syncs();
+        if (be.profile()) s->ktable = be.collect_named();
+    }
+    return r;
+}
 int orz_stream_encode(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t** dst, size_t* dst_len,
                       orz_encode_stats* stats) {
     if (!s || !dst || !dst_len || (!src && n)) return fail(ORZ_EINVAL, "null argument");
     if (!s->enc) return fail(ORZ_ENOMEM, "the stream has no encoder (a reconfiguration ran out of device memory)");
     try {
-        orz::ByteBuf out;
-        out.reserve(n / 3 + 4096);
-        orz::HipBackend& be = *s->be;
-        be.set_timing(stats != nullptr);
-        struct Events {  // destroyed on every path out of this function
-            hipEvent_t a = nullptr, b = nullptr;
-            ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-        } ev;
-        ORZ_HIP_CHECK(hipSetDevice(be.device()));
-        ORZ_HIP_CHECK(hipEventCreate(&ev.a));
-        ORZ_HIP_CHECK(hipEventCreate(&ev.b));
-        hipEvent_t e0 = ev.a, e1 = ev.b;
-        ORZ_HIP_CHECK(hipEventRecord(e0, be.stream()));
-        s->trace.clear();
-        struct Pin {  // host input: page-lock it for the call so the block uploads are real asynchronous DMA
-            void* p = nullptr;
-            ~Pin() { if (p) (void)hipHostUnregister(p); }
-        } pin;
-        bool pinned = false;
-        if (!src_on_device && n >= (1u << 20) && hipHostRegister(const_cast<void*>(src), n, hipHostRegisterDefault) == hipSuccess) {
-            pin.p = const_cast<void*>(src);
-            pinned = true;
-        } else {
-            (void)hipGetLastError();  // (registration refused: pageable copies, synchronised per block)
+        const auto r = stream_encode_device(s, src, n, src_on_device, nullptr, 0, stats);
+        // the finished stream comes to the host in ONE copy (round 6; before: a wait for the sizes and one for the bytes of every block)
+        uint8_t* p = (uint8_t*)std::malloc(r.len ? r.len : 1);
+        if (!p) return fail(ORZ_ENOMEM, "out of host memory");
+        const hipError_t ce = hipMemcpy(p, r.data, r.len, hipMemcpyDeviceToHost);
+        if (stats) stats->host_syncs += 1;
+        if (ce != hipSuccess) { std::free(p); return fail(ORZ_ENODEV, hipGetErrorString(ce)); }
+        if (verify_decode_on()) {
+            try { verify_stream_decode((const uint8_t*)src, n, src_on_device != 0, p, r.len); } catch (...) { std::free(p); throw; }
         }
-        orz::encode_stream(*s->enc, be, (const uint8_t*)src, n, src_on_device != 0, out, pinned);
-        ORZ_HIP_CHECK(hipEventRecord(e1, be.stream()));  // (before the host-side decode verification: its time is not GPU time)
-        if (verify_decode_on()) verify_stream_decode((const uint8_t*)src, n, src_on_device != 0, out.data(), out.size());
-        be.sync();
-        float total = 0;
-        ORZ_HIP_CHECK(hipEventElapsedTime(&total, e0, e1));
-        if (stats) {
-            const orz::EncodeStats& st = s->enc->stats;
-            stats->blocks = st.blocks; stats->sweeps = st.sweeps; stats->seg_evals = st.seg_evals;
-            stats->items = st.items; stats->chunks = st.chunks; stats->in_bytes = st.in_bytes;
-            stats->out_bytes = out.size();
-            stats->t_prep_s = st.t_prep; stats->t_parse_s = st.t_parse; stats->t_post_s = st.t_post;
-            stats->parse_kernel_ms = be.collect_timed(&stats->parse_launches, s->kernel_ms, s->kernel_n);
-            stats->total_ms = total;
-            stats->host_syncs = st.host_syncs + be.take_host_syncs();
-            if (be.profile()) s->ktable = be.collect_named();
-        }
-        *dst_len = out.size();
-        *dst = out.release();
+        *dst_len = r.len;
+        *dst = p;
         return ORZ_OK;
     } catch (const std::bad_alloc&) {
         return fail(ORZ_ENOMEM, "out of host memory");
     } catch (const std::exception& e) {
         return fail(ORZ_ENODEV, e.what());
+    }
+}
+size_t orz_stream_bound(size_t n) { return orz::stream_bound(n); }
+int orz_stream_encode_to_device(orz_stream* s, const void* src, size_t n, int src_on_device, uint8_t* d_dst, size_t d_cap,
+                                size_t* dst_len, orz_encode_stats* stats) {
+    if (!s || !d_dst || !dst_len || (!src && n)) return fail(ORZ_EINVAL, "null argument");
+    if (!s->enc) return fail(ORZ_ENOMEM, "the stream has no encoder (a reconfiguration ran out of device memory)");
+    try {
+        const auto r = stream_encode_device(s, src, n, src_on_device, d_dst, d_cap, stats);
+        if (verify_decode_on()) {
+            std::vector<uint8_t> host(r.len);
+            ORZ_HIP_CHECK(hipMemcpy(host.data(), r.data, r.len, hipMemcpyDeviceToHost));
+            verify_stream_decode((const uint8_t*)src, n, src_on_device != 0, host.data(), host.size());
+        }
+        *dst_len = r.len;
+        return ORZ_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(ORZ_ENOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        const std::string msg = e.what();
+        return fail(msg.find("output buffer is too small") != std::string::npos ? ORZ_ENOMEM : ORZ_ENODEV, msg);
     }
 }
 
@@ -347,6 +382,7 @@ long orz_stream_get_item_trace(orz_stream* s, orz_item* out, size_t cap) {
 // ------------------------------------------------------------------------------ members
 struct orz_members {
     std::vector<orz_stream*> workers;
+    std::map<int, std::pair<uint8_t*, size_t>> arena;  // per device: where the finished members of a job are collected (orz_members_encode)
 };
 orz_members* orz_members_new_multi(const int* devices, int n_devices, const orz_lzcfg* cfg, int jobs_per_device) {
     if (!cfg_ok(cfg) || !devices || n_devices < 1 || n_devices > 64 || jobs_per_device < 1 || jobs_per_device > 64) {
@@ -371,8 +407,85 @@ orz_members* orz_members_new(int device, const orz_lzcfg* cfg, int jobs) { retur
 void orz_members_free(orz_members* m) {
     if (!m) return;
     for (orz_stream* w : m->workers) orz_stream_free(w);
+    for (auto& kv : m->arena)
+        if (kv.second.first) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.first); }
     delete m;
 }
+// The members of a job on the workers' devices.  A worker leaves a finished member in its encoder's own device buffer
+// (encode_stream_device: one host wait per block, one per member) and moves it -- device to device, on its copy stream, no host
+// wait: the next member's frame kernels queue behind the copy -- into the job's ARENA on that device at an offset drawn from an
+// atomic counter; `place[k]` says where member k lies.  Arena = the caller's buffer (orz_members_encode_to_device) or one the
+// members object owns; a member that does not fit an OWNED arena goes to host memory instead (incompressible input: the arena
+// is sized for ratio 0.5), into the caller's it fails the job.
+namespace {
+struct MemberPlace { int device = -1; size_t off = 0, len = 0; std::vector<uint8_t> host; };
+struct MemberArena {
+    int device; uint8_t* p; size_t cap; bool caller;
+    std::atomic<size_t> used{0};
+    MemberArena(int d, uint8_t* q, size_t c, bool cl) : device(d), p(q), cap(c), caller(cl) {}
+};
+int members_run(orz_members* m, const void* src, size_t n, int src_on_device, size_t member_bytes, std::vector<std::unique_ptr<MemberArena>>& arenas,
+                std::vector<MemberPlace>& place) {
+    const size_t nm = place.size();
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc{ORZ_OK};
+    std::string err;
+    const bool verify = verify_decode_on();
+    auto arena_of = [&](int dev) -> MemberArena* {
+        for (auto& a : arenas) if (a->device == dev) return a.get();
+        return nullptr;
+    };
+    auto work = [&](orz_stream* s) {
+        try {
+            orz::HipBackend& be = *s->be;
+            ORZ_HIP_CHECK(hipSetDevice(be.device()));  // every host thread talks to its worker's device
+            MemberArena* ar = arena_of(be.device());
+            bool copied = false;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= nm || rc.load() != ORZ_OK) break;
+                if (!s->enc) throw std::runtime_error("a worker has no encoder (a reconfiguration ran out of device memory)");
+                const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
+                be.begin_encode();
+                const auto r = orz::encode_stream_device(*s->enc, be, (const uint8_t*)src + off, len, src_on_device != 0, nullptr, 0);
+                MemberPlace& pl = place[i];
+                pl.len = r.len;
+                const size_t at = ar ? ar->used.fetch_add(r.len) : 0;
+                if (ar && at + r.len <= ar->cap) {
+                    pl.device = be.device(); pl.off = at;
+                    be.select(3);
+                    be.d2d(ar->p + at, r.data, r.len);
+                    be.select(0);
+                    copied = true;
+                } else {
+                    if (ar && ar->caller) throw std::runtime_error("the output buffer is too small for the members' streams");
+                    pl.host.resize(r.len);
+                    ORZ_HIP_CHECK(hipMemcpy(pl.host.data(), r.data, r.len, hipMemcpyDeviceToHost));
+                }
+                if (verify) {
+                    std::vector<uint8_t> h(r.len);
+                    ORZ_HIP_CHECK(hipMemcpy(h.data(), r.data, r.len, hipMemcpyDeviceToHost));
+                    verify_stream_decode((const uint8_t*)src + off, len, src_on_device != 0, h.data(), h.size());
+                }
+            }
+            if (copied) { be.select(3); be.sync(); be.select(0); }  // (the worker's moves into the arena: one wait per job)
+        } catch (const std::exception& e) {
+            int expect = ORZ_OK;
+            const std::string msg = e.what();
+            if (rc.compare_exchange_strong(expect, msg.find("output buffer is too small") != std::string::npos ? ORZ_ENOMEM : ORZ_ENODEV)) err = msg;
+        }
+    };
+    struct Joiner {  // joins whatever was started, also when starting a later thread throws
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } joiner;
+    for (size_t i = 1; i < m->workers.size(); i++) joiner.th.emplace_back(work, m->workers[i]);
+    work(m->workers[0]);
+    for (auto& t : joiner.th) t.join();
+    if (rc.load() != ORZ_OK) return fail(rc.load(), err);
+    return ORZ_OK;
+}
+}  // namespace
 int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t** dst,
                        size_t* dst_len, size_t* n_members_out) {
     if (!m || !dst || !dst_len || (!src && n) || member_bytes == 0) return fail(ORZ_EINVAL, "bad argument");
@@ -383,46 +496,77 @@ int orz_members_encode(orz_members* m, const void* src, size_t n, int src_on_dev
     }
     try {
         const size_t nm = n == 0 ? 1 : (n + member_bytes - 1) / member_bytes;
-        std::vector<std::vector<uint8_t>> outs(nm);
-        std::atomic<size_t> next{0};
-        std::atomic<int> rc{ORZ_OK};
-        std::string err;
-        const bool verify = verify_decode_on();
-        auto work = [&](orz_stream* s) {
-            try {
-                ORZ_HIP_CHECK(hipSetDevice(s->be->device()));  // every host thread talks to its worker's device
-                for (;;) {
-                    const size_t i = next.fetch_add(1);
-                    if (i >= nm || rc.load() != ORZ_OK) return;
-                    if (!s->enc) throw std::runtime_error("a worker has no encoder (a reconfiguration ran out of device memory)");
-                    const size_t off = i * member_bytes, len = n == 0 ? 0 : std::min(member_bytes, n - off);
-                    orz::encode_stream(*s->enc, *s->be, (const uint8_t*)src + off, len, src_on_device != 0, outs[i]);
-                    if (verify) verify_stream_decode((const uint8_t*)src + off, len, src_on_device != 0, outs[i].data(), outs[i].size());
-                }
-            } catch (const std::exception& e) {
-                int expect = ORZ_OK;
-                if (rc.compare_exchange_strong(expect, ORZ_ENODEV)) err = e.what();
+        // an arena per device the workers sit on, owned by the members object and kept between calls: sized for ratio 0.5 (text:
+        // 0.28) or the streams' bound, whichever is smaller
+        std::vector<std::unique_ptr<MemberArena>> arenas;
+        const size_t want = std::min(nm * orz::stream_bound(std::min(member_bytes, n ? n : 1)), n / 2 + nm * 65536 + (32u << 20));
+        for (orz_stream* w : m->workers) {
+            const int dev = w->be->device();
+            bool have = false;
+            for (auto& a : arenas) have = have || a->device == dev;
+            if (have) continue;
+            auto& slot = m->arena[dev];
+            if (slot.second < want) {
+                ORZ_HIP_CHECK(hipSetDevice(dev));
+                if (slot.first) (void)hipFree(slot.first);
+                slot = {nullptr, 0};
+                void* p = nullptr;
+                if (hipMalloc(&p, want) == hipSuccess) slot = {(uint8_t*)p, want};
+                else (void)hipGetLastError();  // (no arena on this device: its members go through host memory)
             }
-        };
-        struct Joiner {  // joins whatever was started, also when starting a later thread throws
-            std::vector<std::thread> th;
-            ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
-        } joiner;
-        for (size_t i = 1; i < m->workers.size(); i++) joiner.th.emplace_back(work, m->workers[i]);
-        work(m->workers[0]);
-        for (auto& t : joiner.th) t.join();
-        if (rc.load() != ORZ_OK) return fail(rc.load(), err);
+            if (slot.first) {
+                std::unique_ptr<MemberArena> a(new MemberArena(dev, slot.first, slot.second, false));
+                arenas.push_back(std::move(a));
+            }
+        }
+        std::vector<MemberPlace> place(nm);
+        const int rc = members_run(m, src, n, src_on_device, member_bytes, arenas, place);
+        if (rc != ORZ_OK) return rc;
+        // the members in input order: ONE copy each, from where it lies to its place in the result (round 6; before: device ->
+        // a vector per member -> the result)
         size_t total = 0;
-        for (auto& o : outs) total += o.size();
+        for (auto& pl : place) total += pl.len;
         uint8_t* p = (uint8_t*)std::malloc(total ? total : 1);
         if (!p) return fail(ORZ_ENOMEM, "malloc failed");
         size_t at = 0;
-        for (auto& o : outs) { std::memcpy(p + at, o.data(), o.size()); at += o.size(); }
+        int cur = -1;
+        for (auto& pl : place) {
+            if (pl.device >= 0) {
+                if (cur != pl.device) { (void)hipSetDevice(pl.device); cur = pl.device; }
+                uint8_t* base = nullptr;
+                for (auto& a : arenas) if (a->device == pl.device) base = a->p;
+                const hipError_t ce = hipMemcpy(p + at, base + pl.off, pl.len, hipMemcpyDeviceToHost);
+                if (ce != hipSuccess) { std::free(p); return fail(ORZ_ENODEV, hipGetErrorString(ce)); }
+            } else {
+                std::memcpy(p + at, pl.host.data(), pl.len);
+            }
+            at += pl.len;
+        }
         *dst = p;
         *dst_len = total;
         if (n_members_out) *n_members_out = nm;
         return ORZ_OK;
     } catch (const std::exception& e) {  // (allocation / thread start failures never cross the C boundary)
+        return fail(ORZ_ENOMEM, e.what());
+    }
+}
+int orz_members_encode_to_device(orz_members* m, const void* src, size_t n, int src_on_device, size_t member_bytes, uint8_t* d_dst,
+                                 size_t d_cap, size_t* offs, size_t* lens, size_t* n_members_out) {
+    if (!m || !d_dst || !offs || !lens || (!src && n) || member_bytes == 0) return fail(ORZ_EINVAL, "bad argument");
+    const int d0 = m->workers[0]->be->device();
+    for (orz_stream* w : m->workers)
+        if (w->be->device() != d0) return fail(ORZ_EINVAL, "device-resident output needs all workers on one device");
+    try {
+        const size_t nm = n == 0 ? 1 : (n + member_bytes - 1) / member_bytes;
+        std::vector<std::unique_ptr<MemberArena>> arenas;
+        arenas.emplace_back(new MemberArena(d0, d_dst, d_cap, true));
+        std::vector<MemberPlace> place(nm);
+        const int rc = members_run(m, src, n, src_on_device, member_bytes, arenas, place);
+        if (rc != ORZ_OK) return rc;
+        for (size_t k = 0; k < nm; k++) { offs[k] = place[k].off; lens[k] = place[k].len; }
+        if (n_members_out) *n_members_out = nm;
+        return ORZ_OK;
+    } catch (const std::exception& e) {
         return fail(ORZ_ENOMEM, e.what());
     }
 }

@@ -13,6 +13,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -140,10 +141,14 @@ int main(int argc, char** argv) {
             fprintf(stderr, "Error: \"encoding failed: %s\"\n", orz_last_error());
             // the streaming entry point hands blocks on as they are finished: what a failed encode left behind is a truncated
             // stream, and it goes -- a named target only, never stdout
+            // -- and only a REGULAR file (`orz encode in /dev/null` run as root must not unlink the device node, nor
+            // a FIFO; what the open stream refers to is asked, not the name)
             if (pos.size() >= 2) {
+                struct stat st;
+                const bool regular = fstat(fileno(io.out), &st) == 0 && S_ISREG(st.st_mode);
                 fclose(io.out);
                 io.out = nullptr;
-                if (remove(pos[1].c_str()) == 0) fprintf(stderr, "(the incomplete output %s was removed)\n", pos[1].c_str());
+                if (regular && remove(pos[1].c_str()) == 0) fprintf(stderr, "(the incomplete output %s was removed)\n", pos[1].c_str());
             }
             return 1;
         }

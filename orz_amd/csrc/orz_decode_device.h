@@ -321,6 +321,7 @@ struct DecodeMember {
                 // the window (hash1(sbuf, spos - 1)), the register here still holds the overrun bytes
                 if (spos >= kPre) {
                     const uint64_t mo = (uint64_t)spos - kPre + slid;
+                    if (mo > out_len) return kDecSizeMismatch;  // (a cut that lands past the member's region -- those bytes were never stored)
                     tail = 0;
                     for (uint32_t k = 8; k >= 1; k--) tail = (tail << 8) | (mo >= k ? (uint64_t)out[mo - k] : 0);
                 }

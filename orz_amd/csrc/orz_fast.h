@@ -45,6 +45,8 @@ constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the hi
 constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
 constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile.  Measured on a full block,
 constexpr uint32_t kFastRounds = 4;                // emulator, vs the oracle: text -l1 256 K x 3 / x 4: -0.00 / -0.04 %, 512 K x 3: +0.2 %;
+constexpr uint32_t kSettledTile = 262144;          // the schedule of a block that follows a block of settled, text-like statistics
+constexpr uint32_t kSettledRounds = 3;             // (StreamEncoder::fast_parse, round 6): one round less costs text nothing
                                                    // zeros + noise -l2 (one hot context, item starts that depend on each other over long
                                                    // distances): 256 K x 3 / x 4 / x 5: +0.81 / +0.46 / +0.40 %, 512 K x 4: +1.5 %
 
@@ -199,6 +201,47 @@ ORZ_D DistBracket dist_valid(uint64_t codes, uint32_t budget) {
     return b;
 }
 
+// Several buffers zeroed by ONE launch (round 6): the resets in front of a block's rounds were 17 fill dispatches, each a launch
+// that under eight encoders waits ~118 us for its turn whatever its size (rocprofv3, round 5) -- and 244 fill dispatches a block
+// in all.  Thread per 16-byte unit over the ranges laid end to end; a range may start and end anywhere (its first and last unit
+// are written byte by byte where they reach outside it).
+struct ZeroRanges {
+    static constexpr int kMax = 24;
+    uint8_t* base[kMax];      // start of each range rounded down to 16
+    uint32_t lead[kMax];      // bytes of the first unit in front of the range
+    uint64_t bytes[kMax];     // length of the range
+    uint32_t ustart[kMax + 1];  // first unit of each range
+    int n = 0;
+    void add(void* p, size_t len) {  // (host side, while the launch is put together)
+        if (!len) return;
+        if (n >= kMax) return;  // (callers check full() and launch in two goes)
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p), a0 = a & ~(uintptr_t)15;
+        base[n] = reinterpret_cast<uint8_t*>(a0);
+        lead[n] = (uint32_t)(a - a0);
+        bytes[n] = len;
+        if (n == 0) ustart[0] = 0;
+        ustart[n + 1] = ustart[n] + (uint32_t)((lead[n] + len + 15) / 16);
+        n++;
+    }
+    bool full() const { return n >= kMax; }
+    size_t units() const { return n ? ustart[n] : 0; }
+    ORZ_HD void operator()(size_t tid) const {
+        if (!n || tid >= ustart[n]) return;
+        int r = 0;
+#pragma unroll 1
+        for (int k = 1; k < n; k++) r += tid >= ustart[k] ? 1 : 0;
+        const uint64_t u = tid - ustart[r], lo = u * 16, first = lead[r], end = first + bytes[r];
+        uint8_t* q = base[r] + lo;
+        if (lo >= first && lo + 16 <= end) {
+            uint64_t* w = reinterpret_cast<uint64_t*>(q);
+            w[0] = 0; w[1] = 0;
+        } else {
+            for (uint32_t b = 0; b < 16; b++)
+                if (lo + b >= first && lo + b < end) q[b] = 0;
+        }
+    }
+};
+
 // runs (ctx, hash) that gained an item start in a repair pass: one bit per run key
 ORZ_D void mark_run(const uint8_t* win, uint64_t* rdirty, uint32_t x) {
     const uint32_t key = bucket_key(win, x);
@@ -315,11 +358,15 @@ struct HistCountWave {
 };
 // Exclusive prefix down the columns of a [rows][256] table in three small launches (groups of 64 rows): group sums,
 // their prefix per column, then the rows of each group.  out[0][c] must hold the base; out gets rows + 1 rows.
+struct FastCtl;
+ORZ_HD bool passes_done(const FastCtl* ctl);  // (defined with FastCtl below: a repair-stage kernel returns at once when the passes are done)
 struct ColScanGroups {
     const uint32_t* in;
     uint32_t rows;
     uint32_t* gsum;  // [groups][256]
+    const FastCtl* ctl = nullptr;
     ORZ_HD void operator()(size_t tid) const {
+        if (passes_done(ctl)) return;
         const uint32_t c = (uint32_t)(tid & 255), g = (uint32_t)(tid >> 8);
         if (g * 64 >= rows) return;
         uint32_t v = 0;
@@ -331,8 +378,9 @@ struct ColScanTop {
     uint32_t* gsum;
     uint32_t rows;
     const uint32_t* out;  // out[0][c] = base
+    const FastCtl* ctl = nullptr;
     ORZ_HD void operator()(size_t c) const {
-        if (c >= 256) return;
+        if (c >= 256 || passes_done(ctl)) return;
         uint32_t v = out[c];
         for (uint32_t g = 0; g * 64 < rows; g++) {
             const uint32_t t = gsum[(size_t)g * 256 + c];
@@ -345,7 +393,9 @@ struct ColScanRows {
     const uint32_t *in, *gsum;
     uint32_t rows;
     uint32_t* out;
+    const FastCtl* ctl = nullptr;
     ORZ_HD void operator()(size_t tid) const {
+        if (passes_done(ctl)) return;
         const uint32_t c = (uint32_t)(tid & 255), g = (uint32_t)(tid >> 8);
         if (g * 64 >= rows) return;
         uint32_t v = gsum[(size_t)g * 256 + c];
@@ -1532,13 +1582,16 @@ struct FastCtl {
                          // arguments: the loop is replayed as a graph whose arguments are those of the block it was captured on
     uint32_t ncut, nfix;  // entries of the running pass's cut list (FastSource -> FastRecutL) / WORD-fix list (FastWordCheckL -> FastWordApplyL)
     uint32_t nwx;         // ... and of the list of WORD items FastRecut made in this pass (the subtiles' lists were drawn up before it)
+    uint32_t hot, hotacc; // item starts of the block's busiest ring context when the last pass began (the host picks the NEXT block's
+                          // schedule from it, round 6) / its accumulator (FastItemTotal)
 };
+ORZ_HD bool passes_done(const FastCtl* ctl) { return ctl && ctl->done; }
 struct FastCtlReset {
     FastCtl* ctl;
     ORZ_HD void operator()(size_t tid) const {
         if (tid) return;
         ctl->chg = 0; ctl->done = 0; ctl->total = 0; ctl->passes = 0; ctl->nmem = 0; ctl->acc = 0;  // (lastflips: reset before the rounds)
-        ctl->ncut = 0; ctl->nfix = 0; ctl->nwx = 0;
+        ctl->ncut = 0; ctl->nfix = 0; ctl->nwx = 0; ctl->hot = 0; ctl->hotacc = 0;
     }
 };
 struct FastSetNent {
@@ -1558,6 +1611,8 @@ struct FastPassEnd {
         ctl->chg = 0;
         ctl->nmem = ctl->acc;
         ctl->acc = 0;
+        ctl->hot = ctl->hotacc;
+        ctl->hotacc = 0;
         ctl->ncut = 0; ctl->nfix = 0; ctl->nwx = 0;  // (the lists of the pass were consumed by FastRecutL / FastWordApplyL)
     }
 };
@@ -1579,8 +1634,9 @@ struct FastFlipSparse {  // thread per word of tbits
     FastFlip f;          // (lo / hi unused; mark_hi = last_hi = 0, next_entry = ~0u)
     uint32_t nwords;     // words of tbits that can hold a bit: positions kPre .. len
     uint64_t* kdirty;
+    const FastCtl* ctl = nullptr;
     ORZ_HD void operator()(size_t w) const {
-        if (w >= nwords) return;
+        if (w >= nwords || passes_done(ctl)) return;
         uint64_t m = f.a.tbits[w];
         if (!m) return;
         f.a.tbits[w] = 0;
@@ -1604,9 +1660,11 @@ struct RepairListWave {
     const uint64_t* rdirty;   // nullptr: every match (the first pass)
     const uint8_t* edge;
     const uint32_t* cok;
+    const FastCtl* ctl = nullptr;
     static size_t lds_bytes() { return 256 * 4; }
     template <class W>
     ORZ_D void operator()(W& w) const {
+        if (passes_done(ctl)) return;  // (the passes queued behind the one that found nothing walked the whole block all the same)
         uint32_t* cnt = (uint32_t*)w.lds();
         const uint32_t s = w.block(), lane = w.lane();
         for (uint32_t c = lane; c < 256; c += 64) cnt[c] = 0;
@@ -1658,7 +1716,9 @@ struct FastItemTotal {  // item starts of the block from the per-ctx ordinals (t
     FastCtl* ctl;
     ORZ_HD void operator()(size_t c) const {
         if (c >= 256 || ctl->done) return;
-        atom_add32(&ctl->acc, cp[(size_t)nsub * 256 + c] - cp[c]);
+        const uint32_t mine = cp[(size_t)nsub * 256 + c] - cp[c];
+        atom_add32(&ctl->acc, mine);
+        atom_max32(&ctl->hotacc, mine);
     }
 };
 // Exact ring ordinals (Bucket.head arithmetic, src/matcher.rs:62-80) of the block's item starts without sorting them:
@@ -2035,8 +2095,17 @@ struct FastWordCheckL {  // FastWordCheck over the subtiles' WORD lists; the ver
 struct FastCokGrow {  // thread per ctx: has the context gained at most kEdgeMargin item starts since the first pass? (= FastCtxOk, from
     const uint32_t* cgrow;  // the counters FastRecut / FastWordApplyL keep instead of the pass's ordinals)
     uint32_t* cok;
+    // round 6: the launch also clears the run flags this pass will set (`rd_out`: nwords words, nullptr = cleared elsewhere) --
+    // it was a fill dispatch of its own in every pass; nothing reads them between the pass before's FastSourceL and this
+    // pass's FastRecutL.  Returns at once when the passes are done.
+    uint64_t* rd_out = nullptr;
+    uint32_t nwords = 0;
+    const FastCtl* ctl = nullptr;
+    ORZ_HD size_t threads() const { return nwords > 256 ? nwords : 256; }
     ORZ_HD void operator()(size_t c) const {
+        if (ctl && ctl->done) return;
         if (c < 256) cok[c] = cgrow[c] <= FastSource::kEdgeMargin;
+        if (rd_out && c < nwords) rd_out[c] = 0;
     }
 };
 struct FastWordApplyL {  // FastWordApply over the fix list (a launch of its own: see FastWordCheck)
@@ -2046,7 +2115,10 @@ struct FastWordApplyL {  // FastWordApply over the fix list (a launch of its own
     uint32_t* cgrow;
     const FastCtl* ctl;
     uint32_t nthreads;
+    uint64_t* kdirty = nullptr;  // [512] round 6: cleared here (FastWordCheckL, the launch before, was its last reader of the pass) instead
+                                 // of by a fill dispatch of its own
     ORZ_HD void operator()(size_t tid) const {
+        if (kdirty && tid < 512) kdirty[tid] = 0;
         const uint32_t n = ctl->nfix;
         for (uint32_t k = (uint32_t)tid; k < n; k += nthreads) {
             const uint32_t i = fixlist[k], p = kPre + i;

@@ -143,6 +143,7 @@ typedef uint32_t orz_u32_unaligned __attribute__((aligned(1)));
 typedef uint64_t orz_u64_unaligned __attribute__((aligned(1)));
 ORZ_D uint32_t ldu32(const uint8_t* p) { return *reinterpret_cast<const orz_u32_unaligned*>(p); }
 ORZ_D uint64_t ldu64(const uint8_t* p) { return *reinterpret_cast<const orz_u64_unaligned*>(p); }
+ORZ_D void stu64(uint8_t* p, uint64_t v) { *reinterpret_cast<orz_u64_unaligned*>(p) = v; }
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 ORZ_D uint64_t atom_xchg64(uint64_t* p, uint64_t v) { return atomicExch((unsigned long long*)p, (unsigned long long)v); }
@@ -150,6 +151,7 @@ ORZ_D uint64_t atom_load64(const uint64_t* p) { return __hip_atomic_load(p, __AT
 ORZ_D void atom_store64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ORZ_D void spin_pause() { __builtin_amdgcn_s_sleep(2); }
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ORZ_D void atom_max32(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 ORZ_D int clz64(uint64_t v) { return __clzll((long long)v); }
@@ -162,6 +164,7 @@ ORZ_D SlotRec ld_rec(const SlotRec* p) {
 #else
 ORZ_D uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 ORZ_D uint64_t ldu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+ORZ_D void stu64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 // (real relaxed atomics on the host as well: the race check of tests/race runs a launch's threads on several host threads)
 ORZ_D void atom_or64(uint64_t* p, uint64_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 ORZ_D void atom_and64(uint64_t* p, uint64_t v) { __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
@@ -172,6 +175,10 @@ ORZ_D void spin_pause() {}
 ORZ_D void atom_min32(uint32_t* p, uint32_t v) {
     uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+ORZ_D void atom_max32(uint32_t* p, uint32_t v) {
+    uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 ORZ_D void atom_add32(uint32_t* p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 ORZ_D void atom_add64(unsigned long long* p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -223,6 +223,131 @@ struct ChunkTotals {  // total payload bits of each chunk = header + items
     }
 };
 
+// ---- the finished stream in DEVICE memory (round 6) -------------------------------------------------------------------------
+// Until round 5 the host framed every block: it read the chunk sizes and the guards' flags (one wait), then every chunk's bytes
+// (another wait) -- 2 of the 3.83 host waits per block -- and the finished stream existed in host memory only (the multi-GPU
+// gather copied it back to the device to send it).  Now the device frames: FrameChunks appends { LEB128(t) chunk[t] }*
+// (src/lib.rs:79-80, src/ioutil.rs:79-88) of a block to the stream at the offset the control block holds, behind that block's
+// tail stage and gate on the copy stream, and REFUSES to when the block's guards have a finding (the validity gate, the
+// ranking guard's second run, a full buffer): the failure is sticky, nothing of that block or a later one is framed, and the
+// host learns it when it reads the control block at the end of the stream -- "nothing of this block is handed out" holds.
+enum : uint32_t { kOutOk = 0, kOutGate = 1, kOutRank = 2, kOutFull = 3, kOutChunk = 4 };
+struct OutCtl {
+    unsigned long long off;   // bytes of the stream framed so far
+    unsigned long long cap;   // bytes the buffer holds
+    uint32_t fail;            // what stopped the framing (kOut*), sticky
+    uint32_t fail_block;
+    uint32_t redo;            // blocks whose symbol ranking the guard repeated
+    uint32_t rankdiff;        // (ORZ_SYMRANK_VERIFY) ranks that differed between two runs
+    uint32_t rank_bad[2];     // impossible ranks after the first / second run of the failing block
+    uint32_t blocks;          // blocks framed
+    uint32_t pad;
+    uint32_t gate[kVeCount];  // the gate's findings of the failing block
+};
+struct FrameLayout {  // what a block appends, from its chunk totals: every thread of FrameChunks and FrameAdvance derives the same
+    const uint32_t* tot;      // [nchunks] payload bits of each chunk
+    const uint32_t* flags;    // [4 + kVeCount] ranking guard | gate findings (TailSet::srflags)
+    uint32_t nchunks;
+    uint32_t capwords;        // words a chunk's staging area holds
+    ORZ_HD uint32_t verdict(const OutCtl* ctl, uint64_t* total) const {
+        if (ctl->fail) return ctl->fail;
+        if (flags[1]) return kOutRank;
+        for (uint32_t c = 0; c < kVeFirst; c++)
+            if (flags[4 + c]) return kOutGate;
+        uint64_t t = 0;
+        for (uint32_t i = 0; i < nchunks; i++) {
+            const uint64_t tb = ((uint64_t)tot[i] + 31) / 32 * 4;  // finish pads to 32 bits, src/coder.rs:75-82
+            if (tb / 4 > capwords) return kOutChunk;
+            uint64_t v = tb, lenb = 1;
+            while (v >= 128) { lenb++; v /= 128; }
+            t += lenb + tb;
+        }
+        *total = t;
+        return ctl->off + t > ctl->cap ? kOutFull : kOutOk;
+    }
+};
+struct FrameChunks {  // grid-stride, thread per 16 payload bytes; thread 0 writes the length prefixes
+    FrameLayout lay;
+    const uint32_t* words;    // [nchunks][capwords] the chunks' payloads (TailSet::out)
+    const OutCtl* ctl;
+    uint8_t* dst;
+    uint32_t nthreads;
+    ORZ_HD void operator()(size_t tid) const {
+        uint64_t total = 0;
+        if (lay.verdict(ctl, &total) != kOutOk) return;
+        uint64_t at = ctl->off;
+        for (uint32_t i = 0; i < lay.nchunks; i++) {
+            const uint64_t tb = ((uint64_t)lay.tot[i] + 31) / 32 * 4;
+            if (tid == 0) {  // write_len, src/ioutil.rs:79-88
+                uint64_t v = tb, q = at;
+                while (v >= 128) { dst[q++] = (uint8_t)(128 + v % 128); v /= 128; }
+                dst[q] = (uint8_t)v;
+            }
+            { uint64_t v = tb; at++; while (v >= 128) { at++; v /= 128; } }
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(words + (size_t)i * lay.capwords);
+            for (uint64_t u = (uint64_t)tid * 16; u < tb; u += (uint64_t)nthreads * 16) {
+                if (u + 16 <= tb) {
+                    const uint64_t a = *reinterpret_cast<const uint64_t*>(src + u), b = *reinterpret_cast<const uint64_t*>(src + u + 8);
+                    stu64(dst + at + u, a); stu64(dst + at + u + 8, b);
+                } else {
+                    for (uint64_t k = u; k < tb; k++) dst[at + k] = src[k];
+                }
+            }
+            at += tb;
+        }
+    }
+};
+struct FrameAdvance {  // one thread, the launch behind FrameChunks: moves the offset or records why the block was not framed
+    FrameLayout lay;
+    OutCtl* ctl;
+    uint32_t block;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid) return;
+        if (lay.flags[0]) ctl->redo++;
+        ctl->rankdiff += lay.flags[2];
+        uint64_t total = 0;
+        const uint32_t v = lay.verdict(ctl, &total);
+        if (v == kOutOk) { ctl->off += total; ctl->blocks++; return; }
+        if (ctl->fail) return;  // (an earlier block's failure stands)
+        ctl->fail = v; ctl->fail_block = block;
+        ctl->rank_bad[0] = lay.flags[0]; ctl->rank_bad[1] = lay.flags[1];
+        for (uint32_t c = 0; c < kVeCount; c++) ctl->gate[c] = lay.flags[4 + c];
+    }
+};
+struct FrameReset {  // a new stream: an empty buffer of `cap` bytes
+    OutCtl* ctl;
+    unsigned long long cap;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid) return;
+        ctl->off = 0; ctl->cap = cap; ctl->fail = kOutOk; ctl->fail_block = 0; ctl->redo = 0; ctl->rankdiff = 0;
+        ctl->rank_bad[0] = ctl->rank_bad[1] = 0; ctl->blocks = 0; ctl->pad = 0;
+        for (uint32_t c = 0; c < kVeCount; c++) ctl->gate[c] = 0;
+    }
+};
+struct FrameEof {  // the EOF chunk: write_len(0), src/lib.rs:89
+    OutCtl* ctl;
+    uint8_t* dst;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid || ctl->fail) return;
+        if (ctl->off + 1 > ctl->cap) { ctl->fail = kOutFull; return; }
+        dst[ctl->off] = 0;
+        ctl->off += 1;
+    }
+};
+struct FrameInject {  // (tests of ORZ_VERIFY=decode) one bit of the stream's first chunk flipped behind every guard
+    uint8_t* dst;
+    unsigned long long at;
+    ORZ_HD void operator()(size_t tid) const {
+        if (tid) return;
+        uint64_t tb = 0, lenb = 0, sh = 0;
+        for (;;) { const uint8_t b = dst[lenb++]; tb |= (uint64_t)(b & 0x7f) << sh; sh += 7; if (!(b & 0x80)) break; }
+        if (at < tb) dst[lenb + at] ^= 1;
+    }
+};
+// bytes that always hold the stream of n input bytes: an item costs at most 15 bits (a literal) / 40 bits for at least four
+// bytes (a match) / 15 bits for two (WORD), a chunk's three tables and the census header a few kilobytes, LEB128 and padding a few bytes
+inline size_t stream_bound(size_t n) { return 2 * n + n / 64 + (1u << 20); }
+
 // Output bytes of an encode call: grows like a vector but does not zero what it is about to receive from the device, and
 // hands its malloc'ed buffer to the caller (the C ABI returns it; orz_free releases it) instead of copying it.
 class ByteBuf {
@@ -285,6 +410,13 @@ class StreamEncoder {
             // run predecessors tabulated per position: item starts are about a quarter of a run's positions on text and far
             // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
             fK_ = kFastK;  // (deeper runs: the compact lists of final item starts, FastEval / FastRetire)
+            sched_auto_ = ftile_ == kFastTile && frounds_ == kFastRounds;
+            if (const char* sc = getenv("ORZ_FAST_SCHED")) {
+                unsigned t = 0, r = 0;
+                if (sscanf(sc, "%ux%u", &t, &r) == 2 && t >= kSub && t % kSub == 0 && t <= kNewMax && r >= 1 && r <= 64) { sched_tile_ = t; sched_rounds_ = r; }
+                else if (!strcmp(sc, "0")) sched_auto_ = false;
+                else throw std::runtime_error("ORZ_FAST_SCHED must be 0 or <tile>x<rounds>");
+            }
             if (const char* u = getenv("ORZ_FAST_UNIT")) unit_ = (uint32_t)atoi(u);
             if (unit_ < (1u << 20) || unit_ > kNewMax || unit_ % kSub) throw std::runtime_error("ORZ_FAST_UNIT must be a multiple of 4096 in [1 MiB, 16 MiB]");
             cur_unit_ = unit_;
@@ -422,6 +554,7 @@ class StreamEncoder {
             srstate_ = take<uint16_t>((size_t)512 * kSrWords);
             srbackup_ = take<uint16_t>((size_t)512 * kSrWords);
             outoff_ = take<uint64_t>(kMaxChunks);
+            octl_ = take<OutCtl>(1);
             {
                 std::vector<uint64_t> off(kMaxChunks);
                 for (uint32_t i = 0; i < kMaxChunks; i++) off[i] = (uint64_t)i * kChunkCapWords;
@@ -449,8 +582,14 @@ class StreamEncoder {
         be_.memset(vrec_, 0, (size_t)kPre * 4);  // (no item starts in the history of a new stream)
         be_.memset(vwords_, 0, 65536);
         be_.launch(256, VerReset{vctx_, vlast_});
-        be_.select(1); be_.sync(); be_.select(2); be_.sync(); be_.select(3); be_.sync(); be_.select(0);
-        for (TailSet& t : ts_) t.pending = false;
+        // whatever an earlier stream left on the side streams (an encode that failed half-way; a finished one left nothing) is
+        // ordered BEFORE this stream's work without the host waiting for it (round 6: these were three host waits per stream):
+        // the main stream waits for the side streams, and the side streams start every block behind an event of the main one
+        for (int k = 1; k <= 3; k++) { be_.select(k); be_.record(kEvIdle + k - 1); }
+        be_.select(0);
+        for (int k = 1; k <= 3; k++) be_.wait(kEvIdle + k - 1);
+        for (TailSet& t : ts_) { t.pending = false; t.framed = false; }
+        dev_out_ = false;
         pend_order_.clear();
         cur_set_ = 0;
         if (fast_) {
@@ -464,6 +603,7 @@ class StreamEncoder {
             be_.poison(fev_, nn * 4);
         }
         lt_carry_ = kTyLit;
+        settled_next_ = false;
         hist_hint_ = ~0u;
         if (fast_) { const uint32_t lt = kTyLit; be_.h2d(&fctl_->lt, &lt, 4); }
         stream_start_ = true;
@@ -528,8 +668,21 @@ class StreamEncoder {
         be_.sort_pairs_u32(keysA, keysB, valsA, epos_, nent, 21);
         be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_, nullptr});
         be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
-        be_.memset(krun_, 0, 32769 * 4);
-        be_.memset(krunend_, 0, 32769 * 4);
+        if (fast_) {
+            // every reset the prep and the post stage need, ONE launch (round 6; before: eight fill dispatches)
+            ZeroRanges z;
+            z.add(krun_, 32769 * 4);
+            z.add(krunend_, 32769 * 4);
+            z.add(vbits_ + nent / 64, 16);  // (the words behind the last slot; FastSlotInitWave writes the others whole)
+            z.add(LENMIN_ + kPre, kWLen - kPre);
+            z.add(fhpre_, 256 * 4);
+            z.add(fccnt_, (size_t)(kNumKeys + 1) * 4);
+            if (stream_start_) z.add(fhcm_, (size_t)kHistSub * 256 * 4);
+            be_.launch(z.units(), z);
+        } else {
+            be_.memset(krun_, 0, 32769 * 4);
+            be_.memset(krunend_, 0, 32769 * 4);
+        }
         be_.launch((size_t)n + 1, ScatterSlots{kkeysB, kpos_, n + 1, kidx_, krun_, krunend_});
         if (fast_) {
             double tf = be_.now();  // (no sync here: the prep kernels are queued, the parse follows on the same stream)
@@ -682,11 +835,12 @@ class StreamEncoder {
     }
 
     // exclusive prefix down the 256 columns of in[rows][256] -> out[rows + 1][256] (out[0] holds the base)
-    void col_scan(const uint32_t* in, uint32_t rows, uint32_t* out) {
+    // (`ctl`: the repair passes' scans return at once when the passes are done)
+    void col_scan(const uint32_t* in, uint32_t rows, uint32_t* out, const FastCtl* ctl = nullptr) {
         const size_t groups = (rows + 63) / 64;
-        be_.launch(groups * 256, ColScanGroups{in, rows, fgsum_});
-        be_.launch(256, ColScanTop{fgsum_, rows, out});
-        be_.launch(groups * 256, ColScanRows{in, fgsum_, rows, out});
+        be_.launch(groups * 256, ColScanGroups{in, rows, fgsum_, ctl});
+        be_.launch(256, ColScanTop{fgsum_, rows, out, ctl});
+        be_.launch(groups * 256, ColScanRows{in, fgsum_, rows, out, ctl});
     }
 
     // Diagnostics (ORZ_DEBUG_DUMP=<dir>, ORZ_DEBUG_POS=<window offset>): the per-position state of the fast parse in a window of
@@ -722,17 +876,12 @@ class StreamEncoder {
     void fast_parse(uint32_t n, uint32_t len, uint32_t nent, const uint32_t* slot_keys, const uint32_t* word_keys, OutT& out) {
         const uint8_t* win = dwin();
         const uint32_t nk = n + 1, K = fK_, nsub = (n + kSub - 1) / kSub, nvw = nent / 64 + 2;  // nvw: words of the item-start bitmap
-        be_.memset(vbits_ + nent / 64, 0, 16);  // (the words behind the last slot; FastSlotInitWave writes the others whole)
-        be_.memset(LENMIN_ + kPre, 0, kWLen - kPre);
         be_.launch(nk, FastKw{win, kpos_, nk, fkw_});
         be_.launch_waves(((size_t)nk + 63) / 64, FastWordMasks{kpos_, word_keys, krun_, fkw_, wsnap_, nk, fwmask_, fkmeta_}, FastWordMasks::lds_bytes());
         // history item starts per (unified subtile, ctx) and their prefix: what the ring horizons reach back into
-        if (stream_start_) be_.memset(fhcm_, 0, (size_t)kHistSub * 256 * 4);
-        else be_.launch_waves(kHistSub, HistCountWave{win, S_, fhcm_}, HistCountWave::lds_bytes());
-        be_.memset(fhpre_, 0, 256 * 4);
+        if (!stream_start_) be_.launch_waves(kHistSub, HistCountWave{win, S_, fhcm_}, HistCountWave::lds_bytes());  // (a new stream: zeroed in encode_block)
         col_scan(fhcm_, kHistSub, fhpre_);
         uint64_t* stext = fstext_;
-        be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
         {
             FastSlotInitWave si{epos_, slot_keys, runstart_, nent, vbits_, frlen_};
             si.win = win; si.stext = stext; si.cl = fcl_; si.ccnt = fccnt_;
@@ -787,7 +936,16 @@ class StreamEncoder {
         // Tile size: the configured one for full blocks; short inputs take finer tiles (the step count stays small
         // anyway), and a block whose parse turns out unstable -- many items lost their source -- is redone with tiles
         // a quarter the size (match-dense, highly repetitive data; never seen on text).
-        uint32_t T = ftile_;
+        // Rounds: R per tile -- and, since round 6, a SCHEDULE PER BLOCK.  The default (256 K x 4) is what zeros with noise need (one
+        // hot context whose item starts depend on each other over long distances: +0.46 % against +0.81 % at three rounds); text
+        // loses nothing at three rounds (a full block, emulation: +0.045 % at 256 K x 4, +0.041 % at 256 K x 3) and a quarter of
+        // FastEval's work goes.  Which kind a block is, the block BEFORE it says (its statistics came with the parse's read-back:
+        // no extra wait, and the same choice on every run -- reused encoders, the emulation): text-like = at least one item per ten
+        // bytes, the busiest ring context under a quarter of the items, under half a per cent of the items repaired.  A stream's
+        // first block, short blocks, and a block whose parse turns out unstable under the settled schedule (it is redone) take
+        // the default.  ORZ_FAST_SCHED=0: off; =<tile>x<rounds>: another settled schedule (experiments).
+        uint32_t T = ftile_, R = frounds_;
+        bool settled = false;
         {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
@@ -798,30 +956,41 @@ class StreamEncoder {
             // output for text but +1 % for zeros with noise, and 2 ms of 330 per 100 MB: off.
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 1;
             if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
+            if (sched_auto_ && settled_next_ && n >= cur_unit_ && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
         }
         for (int attempt = 0;; attempt++) {
             a.tile = T;
+            a.rounds = R;
             if (attempt) {  // (the first attempt finds the bitmap and the list counters as the prep left them)
                 be_.memset(vbits_ + nent / 64, 0, 16);
                 be_.launch_waves(((size_t)nent + 63) / 64, FastSlotInitWave{epos_, nullptr, runstart_, nent, vbits_, frlen_}, 0);
                 be_.memset(fccnt_, 0, (size_t)(kNumKeys + 1) * 4);
                 be_.launch(nent, FastListReset{epos_, slot_keys, runstart_, nent, fccnt_});
             }
-            be_.memset(kbits_, 0, ((size_t)n / 64 + 2) * 8);
-            be_.memset(k1_, 0, ((size_t)kNewMax / 4096 + 2) * 8);
-            be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             const size_t nn = (size_t)n + 264;
-            // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
-            be_.memset(fty_, 0, nn); be_.memset(fnl_, 0, nn); be_.memset(fpt_, 0, nn);
-            be_.memset(fmf_, 0, nn); be_.memset(fef_, 0, nn);
-            be_.memset(fsbits_, 0, ((size_t)n / 64 + 8) * 8);
-            be_.memset(fcm_, 0, (size_t)(nsub + 2) * 256 * 4);
-            be_.memset(fcp_, 0, (size_t)(nsub + 2) * 256 * 4);
+            {   // the round state and the repair stage's lists, ONE launch (round 6; before: fifteen fill dispatches)
+                // (ev / farv / dirty need no reset: a position's first evaluation of a parse overwrites them before they are read)
+                ZeroRanges z;
+                z.add(kbits_, ((size_t)n / 64 + 2) * 8);
+                z.add(k1_, ((size_t)kNewMax / 4096 + 2) * 8);
+                z.add(fty_, nn); z.add(fnl_, nn); z.add(fpt_, nn); z.add(fmf_, nn); z.add(fef_, nn);
+                z.add(fsbits_, ((size_t)n / 64 + 8) * 8);
+                z.add(fcm_, (size_t)(nsub + 2) * 256 * 4);
+                z.add(fcp_, (size_t)(nsub + 2) * 256 * 4);
+                z.add(&fctl_->lastflips, 4);
+                z.add(fcnew_, (size_t)(kNumKeys + 1) * 4);  // (compact lists: every run starts with its history slots, FastSlotInitWave)
+                if (repair_lists) {
+                    z.add(tbits, tbits_bytes);
+                    z.add(kdirty, kdirty_bytes);
+                    z.add(fcok_, 256 * 4);  // item starts the repairs added per context (FastCokGrow)
+                    z.add(frdirty_ + kDirtyWords, (size_t)kDirtyWords * 8);  // (the first pass's rd_out; later ones: FastPassBegin)
+                }
+                be_.launch(z.units(), z);
+            }
+            be_.launch(nvw / 64 + 1, V1Build{vbits_, nvw, v1_});
             be_.launch(256, FastCpInit{ctxcount_, fcp_, ftentry_});
-            be_.memset(&fctl_->lastflips, 0, 4);
-            be_.memset(fcnew_, 0, (size_t)(kNumKeys + 1) * 4);  // (compact lists: every run starts with its history slots, FastSlotInitWave)
             // ---- pipelined Gauss-Seidel rounds
-            const uint32_t R = frounds_, ntile = (n + T - 1) / T, cpt = T / kSub;
+            const uint32_t ntile = (n + T - 1) / T, cpt = T / kSub;
             // ring horizons of the first tile (no counts yet: the history alone)
             // (one subtile more than the tile: the first step also evaluates the two positions behind it for the lazy rules)
             be_.launch_waves(256, FastPrefix{a, 0, 0, std::min(cpt + 1, nsub), cpt, 0}, 0);
@@ -829,7 +998,7 @@ class StreamEncoder {
             // a full block's round loop is the same launch sequence every time: replay it as a hipGraph
             static const bool fused_steps = !(getenv("ORZ_FAST_FUSED") && !strcmp(getenv("ORZ_FAST_FUSED"), "0"));  // (experiments: every kernel a launch of its own)
             const bool use_graph = be_.graphs_enabled() && (n == kNewMax || n == cur_unit_);
-            const uint64_t gkey = ((uint64_t)T << 32) | n;
+            const uint64_t gkey = ((uint64_t)R << 58) | ((uint64_t)T << 32) | n;
             const bool replayed = use_graph && be_.graph_replay(gkey);
             struct CaptureGuard {  // a launch that throws inside the capture must not leave the stream capturing
                 BE& be;
@@ -917,21 +1086,25 @@ class StreamEncoder {
                     // the bitmaps in slot order follow the path: everywhere before the first pass, from then on at the positions
                     // the repair kernels rewrote
                     if (pass == 0) be_.launch((size_t)n + 1, flip_all);
-                    else be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
+                    else be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty, fctl_});
                     // exact ordinals of the item starts (per-(subtile, ctx) counts, their prefix, rank inside the subtile) and the
                     // subtiles' lists of matches and WORD items
                     uint64_t* rd_in = frdirty_ + (size_t)(pass & 1) * kDirtyWords;
                     uint64_t* rd_out = frdirty_ + (size_t)((pass + 1) & 1) * kDirtyWords;
                     // (which contexts have grown by more than the edge margin since the first pass: from the counters the rewrite
                     // kernels keep -- the lists below are drawn up before this pass's ordinals exist)
-                    be_.launch(256, FastCokGrow{fcok_, fcok_ + 256});
-                    be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt, pass && incr_repairs ? rd_in : nullptr, fdirty_, fcok_ + 256},
+                    {   // (+ the clearing of this pass's run flags; the first pass's were cleared with the round state)
+                        FastCokGrow cg{fcok_, fcok_ + 256};
+                        cg.ctl = fctl_;
+                        if (pass) { cg.rd_out = rd_out; cg.nwords = kDirtyWords; }
+                        be_.launch(cg.threads(), cg);
+                    }
+                    be_.launch_waves(nsub, RepairListWave{a, mlist, wlist, mcnt, wcnt, pass && incr_repairs ? rd_in : nullptr, fdirty_, fcok_ + 256, fctl_},
                                      RepairListWave::lds_bytes());
-                    col_scan(fcm_, nsub, fcp_);
+                    col_scan(fcm_, nsub, fcp_, fctl_);
                     be_.launch(256, FastItemTotal{fcp_, nsub, fctl_});
                     if (ord_ballots) be_.launch_waves(nsub, OrdWave2{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave2::lds_bytes());
                     else be_.launch_waves(nsub, OrdWave{win, fsbits_, fcp_, n, ORD_, fctl_}, OrdWave::lds_bytes());
-                    be_.memset(rd_out, 0, (size_t)kDirtyWords * 8);
                     FastSource fs{a, SRC_, fcut_, pass && incr_repairs ? rd_in : nullptr, src_cap, fctl_, fdirty_, fcok_ + 256};
                     fs.cutlist = cutlist; fs.ncut = &fctl_->ncut;
                     const uint32_t per = kListThreads;  // (the first pass with a thread per list slot -- 1024 a subtile, no loop: 138 -> 197 us a launch)
@@ -939,14 +1112,13 @@ class StreamEncoder {
                     FastRecut rc{a, fcut_, rd_out};
                     rc.wextra = wextra; rc.nwx = &fctl_->nwx; rc.cgrow = fcok_;
                     be_.launch(kRepairGrid, FastRecutL{rc, cutlist, fctl_, kRepairGrid});
-                    be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty});
+                    be_.launch(tw, FastFlipSparse{flip_all, tw, kdirty, fctl_});
                     if (pass == 0) {  // every WORD item against the running maximum of the update bits; later passes search (FastWordCheckL)
                         be_.launch(nk, KbitVals{kbits_, nk, f32_});
                         be_.inclusive_max_scan_u32(f32_, flaste_, nk);
                     }
                     be_.launch((size_t)nsub * kListThreads, FastWordCheckL{a, pass == 0 ? flaste_ : nullptr, kdirty, wextra, fixlist, fctl_, wlist, wcnt, nsub});
-                    be_.memset(kdirty, 0, kdirty_bytes);
-                    be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fcok_, fctl_, kRepairGrid});
+                    be_.launch(kRepairGrid, FastWordApplyL{a, fixlist, rd_out, fcok_, fctl_, kRepairGrid, kdirty});
                     be_.launch(1, FastPassEnd{fctl_});
             };
             // ... and what follows a group of passes in the lists form: the running maximum of the FINAL update bits (FastCommit,
@@ -967,9 +1139,6 @@ class StreamEncoder {
             // a read-back each, and its commit and count are redone.
             if (repair_lists && !replayed) {
                 be_.launch(1, FastCtlReset{fctl_});
-                be_.memset(tbits, 0, tbits_bytes);
-                be_.memset(kdirty, 0, kdirty_bytes);
-                be_.memset(fcok_, 0, 256 * 4);  // item starts the repairs added per context (FastCokGrow)
                 for (int k = 0; k < kFirstPasses; k++, pass++) lists_pass();
                 lists_tail();
             }
@@ -1037,9 +1206,14 @@ class StreamEncoder {
             // synthetic text (tests' "mixed" shape, 8 MB): one parse +0.49 % vs the oracle, redone at 64 K tiles below it.
             static const uint32_t redo_div = getenv("ORZ_FAST_REDO_DIV") ? (uint32_t)std::max(1, atoi(getenv("ORZ_FAST_REDO_DIV"))) : 100;
             if (T <= kSub || (uint64_t)h.total * redo_div < (uint64_t)h.nmem || (uint64_t)h.total * 2000 < (uint64_t)n) break;
-            T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
+            if (settled) { T = ftile_; R = frounds_; settled = false; }  // (the settled schedule did not suit this block: the default first)
+            else T = std::max<uint32_t>(kSub, (T / 4 + kSub - 1) / kSub * kSub);
             stats.seg_evals -= h.total;  // (count the repairs of the parse that is kept)
         }
+        // the next block's schedule, from this block's statistics (see above)
+        settled_next_ = n == kNewMax && (uint64_t)hfin_.nmem * 10 >= n && (uint64_t)hfin_.hot * 4 <= hfin_.nmem && (uint64_t)hfin_.total * 200 < hfin_.nmem;
+        if (getenv("ORZ_FAST_SHOWSCHED")) fprintf(stderr, "block %llu: T=%u R=%u%s; items %u, busiest context %u, repairs %u -> next block %s\n", (unsigned long long)stats.blocks, T, R,
+                                                  settled ? " (settled)" : "", hfin_.nmem, hfin_.hot, hfin_.total, settled_next_ ? "settled" : "default");
         if (a.dbg & 64) {  // diagnostics: counters of the flips
             unsigned long long h[32];
             be_.d2h(h, a.stats, sizeof h);
@@ -1077,6 +1251,9 @@ class StreamEncoder {
         TailSet& t = ts_[b];
         // ---- the block that used this set two blocks ago has long finished: take its output (in block order)
         if (t.pending) collect_one(out, nullptr);
+        // (device output: the frame kernels of the block that used this set before run on the copy stream -- this block's stages
+        // must not overwrite the chunk buffers and flags they read; the side streams follow the main stream's events)
+        if (t.framed) { be_.wait(kEvOut + b); t.framed = false; }
         // ---- items
         uint32_t nitems = 0;
         {
@@ -1209,6 +1386,29 @@ class StreamEncoder {
         // the ranking chain standing idle, measured).
         MainStreamGuard back_to_main{be_};
         const int set = (int)(&t - ts_);
+        if (dev_out_) {
+            // the stream stays in device memory: the device frames the block behind its tail stage and gate, no host wait, no read-back
+            be_.select(3);
+            be_.wait(kEvTail + set);
+            be_.wait(kEvGate + set);
+            const FrameLayout lay{t.tot, t.srflags, nchunks, (uint32_t)kChunkCapWords};
+            be_.launch(kFrameThreads, FrameChunks{lay, t.out, octl_, dout_, kFrameThreads});
+            be_.launch(1, FrameAdvance{lay, octl_, t.block});
+            if (out_inject_ && t.block == 0 && nchunks) be_.launch(1, FrameInject{dout_, (unsigned long long)out_inject_});  // (tests of ORZ_VERIFY=decode)
+            be_.record(kEvOut + set);
+            t.framed = true;
+            if (chunk_ends) {  // end_spos of each chunk, src/lz.rs:268 (callers that ask for them read every block at once)
+                for (uint32_t i = 0; i < nchunks; i++) {
+                    uint32_t e = len;
+                    const uint32_t i1 = (i + 1) << 20;
+                    if (i1 < nitems) be_.d2h(&e, t.ipos + i1, 4);
+                    chunk_ends->push_back(e);
+                }
+            }
+            collect_trace(t, nitems, len);
+            be_.select(0);
+            return;
+        }
         if (getenv("ORZ_COPY_STREAM") && atoi(getenv("ORZ_COPY_STREAM")) == 0) be_.select(2);  // (experiments)
         else { be_.select(3); be_.wait(kEvTail + set); }
         be_.wait(kEvGate + set);
@@ -1262,6 +1462,12 @@ class StreamEncoder {
         if (out_inject_ && t.block == 0 && nchunks && out_inject_ < tb_of[0]) out.data()[at_of[0] + out_inject_] ^= 1;  // (tests of ORZ_VERIFY=decode)
         if (chunk_ends)
             for (uint32_t i = 0; i < nchunks; i++) chunk_ends->push_back(ends[i]);
+        collect_trace(t, nitems, len);
+        be_.select(0);
+    }
+    // the optional per-item trace of a collected block (parity tests)
+    template <class TS>
+    void collect_trace(TS& t, uint32_t nitems, uint32_t len) {
         if (trace) {
             const size_t at = trace->pos.size();
             trace->block.resize(at + nitems, t.block);
@@ -1290,7 +1496,56 @@ class StreamEncoder {
                 trace->mlen[at + i] = is_match ? hml[p] : 0;
             }
         }
-        be_.select(0);
+    }
+    // ---- the stream in device memory (round 6): FrameChunks appends every block to `dbuf` (nullptr: a buffer of the encoder's own,
+    // grown to `cap`) instead of the host collecting it; finish_device() closes the stream and says how long it is.  Call after
+    // reset(), before the first block.
+    void begin_device_output(uint8_t* dbuf, size_t cap) {
+        if (!dbuf) {
+            if (cap > own_cap_) {
+                if (own_out_) { be_.free(own_out_); owned_.erase(std::find(owned_.begin(), owned_.end(), (void*)own_out_)); own_out_ = nullptr; own_cap_ = 0; }
+                own_out_ = take<uint8_t>(cap, false);
+                own_cap_ = cap;
+            }
+            dbuf = own_out_;
+        }
+        dout_ = dbuf;
+        dev_out_ = true;
+        MainStreamGuard back_to_main{be_};
+        be_.select(3);
+        be_.launch(1, FrameReset{octl_, (unsigned long long)cap});
+    }
+    bool device_output() const { return dev_out_; }
+    struct DeviceResult { const uint8_t* data; size_t len; };
+    DeviceResult finish_device() {
+        if (!dev_out_) throw std::runtime_error("finish_device without begin_device_output");
+        ByteBuf none;
+        collect(none, nullptr);  // (frames what is pending)
+        {
+            MainStreamGuard back_to_main{be_};
+            be_.select(3);
+            be_.launch(1, FrameEof{octl_, dout_});  // EOF chunk, src/lib.rs:89
+            be_.mark_end();                          // (the encode's closing time stamp: the stream is complete here)
+            be_.d2h(&hctl_, octl_, sizeof hctl_);    // ONE wait: the stream's length and whatever stopped it
+        }
+        dev_out_ = false;
+        stats.host_syncs += be_.take_host_syncs();
+        const OutCtl& h = hctl_;
+        if (h.rankdiff) fprintf(stderr, "orz: two runs of the symbol ranking from the same tables differ in %u ranks\n", h.rankdiff);
+        if (h.redo) {
+            stats.rank_redos += h.redo;
+            fprintf(stderr, "orz: the symbol ranking of %u block(s) was repeated by its guard\n", h.redo);
+        }
+        if (h.fail == kOutGate) report_gate(h.gate, h.fail_block);
+        if (h.fail == kOutRank) {
+            fprintf(stderr, "orz: the symbol ranking of block %u was repeated (%u impossible ranks in its first run; %u after the second)\n", h.fail_block, h.rank_bad[0], h.rank_bad[1]);
+            throw std::runtime_error("symbol ranking produced impossible ranks twice: the encode fails, nothing of this block is handed out");
+        }
+        if (h.fail == kOutFull) throw std::runtime_error("the output buffer is too small for the stream (block " + std::to_string(h.fail_block) + ")");
+        if (h.fail == kOutChunk) throw std::runtime_error("chunk payload overflow");
+        if (fast_ && stats.blocks && verify_mode() == 2) report_verify("stream");
+        stats.out_bytes = (uint64_t)h.off;
+        return DeviceResult{dout_, (size_t)h.off};
     }
     template <class OutT>
     void finish(OutT& out) {
@@ -1419,6 +1674,9 @@ class StreamEncoder {
     uint32_t seg_, wsegs_, ring_ = 0, nseg_max_ = 0, dmax_ = 0;
     bool fast_ = false;
     uint32_t ftile_ = kFastTile, frounds_ = kFastRounds, fK_ = kFastK;
+    // the per-block schedule (fast_parse): on unless the caller chose tile / rounds itself
+    bool sched_auto_ = false, settled_next_ = false;
+    uint32_t sched_tile_ = kSettledTile, sched_rounds_ = kSettledRounds;
     bool lead_block_ = false;
     uint8_t *frows_ = nullptr, *frlen_ = nullptr, *fty_ = nullptr, *fnl_ = nullptr, *fpt_ = nullptr, *fmf_ = nullptr, *fef_ = nullptr,
             *fx0_ = nullptr, *fx1_ = nullptr, *fx2_ = nullptr, *fdirty_ = nullptr;
@@ -1445,10 +1703,12 @@ class StreamEncoder {
         uint16_t* hc = nullptr;
         uint32_t *hdrbits = nullptr, *tot = nullptr, *out = nullptr, *srflags = nullptr;
         bool pending = false;
+        bool framed = false;  // device output: the set's frame kernels were queued (the next block of the set waits for kEvOut)
         uint32_t cap = 0;  // items the per-item buffers hold (grow_tail_set)
         uint32_t nitems = 0, nchunks = 0, len = 0, block = 0;
     };
-    static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4, kEvGate = 6;  // event numbers (+ set index)
+    static constexpr int kEvItems = 0, kEvRank = 2, kEvTail = 4, kEvGate = 6, kEvOut = 8, kEvIdle = 10;  // event numbers (+ set index; kEvIdle + side stream - 1)
+    static constexpr uint32_t kFrameThreads = 1u << 18;  // FrameChunks' grid: 4 MiB of payload per sweep of the grid
     struct MainStreamGuard {  // whatever happens while a side stream is selected, the backend goes back to the main one
         BE& be;
         ~MainStreamGuard() { be.select(0); }
@@ -1536,6 +1796,13 @@ class StreamEncoder {
     size_t out_inject_ = 0;  // byte of the stream's first chunk whose lowest bit is flipped on its way out (0 = none)
     uint16_t* srbackup_ = nullptr;  // the tables before the running block's ranking (the guard's second run starts from them)
     uint64_t* outoff_;
+    // the stream in device memory (begin_device_output)
+    bool dev_out_ = false;
+    uint8_t* dout_ = nullptr;      // where the stream goes: the caller's buffer or own_out_
+    uint8_t* own_out_ = nullptr;
+    size_t own_cap_ = 0;
+    OutCtl* octl_ = nullptr;
+    OutCtl hctl_{};
 };
 
 // orz::encode (src/lib.rs:58-92) over a memory buffer that the backend can read with h2d():
@@ -1557,6 +1824,28 @@ void encode_stream(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n,
     enc.finish(out);
     out.push_back(0);  // EOF chunk, src/lib.rs:89
     enc.stats.out_bytes = out.size();
+}
+
+// The same with the finished stream left in DEVICE memory (round 6): `dbuf` = a device buffer of `cap` bytes the caller owns, or
+// nullptr for one of the encoder's own (valid until the encoder's next stream).  One host wait per block (the parse's control
+// block + item count) and one for the whole stream.
+template <class BE>
+typename StreamEncoder<BE>::DeviceResult encode_stream_device(StreamEncoder<BE>& enc, BE& be, const uint8_t* src, size_t n, bool src_on_device,
+                                                              uint8_t* dbuf, size_t cap, bool src_pinned = false) {
+    enc.reset();
+    enc.begin_device_output(dbuf, dbuf ? cap : stream_bound(n));
+    ByteBuf none;
+    size_t off = 0;
+    while (off < n) {
+        uint32_t take = (uint32_t)std::min<size_t>(n - off, kNewMax);
+        if (src_on_device) be.d2d(enc.dwin() + kPre, src + off, take);
+        else if (src_pinned) be.h2d_pinned(enc.dwin() + kPre, src + off, take);
+        else be.h2d(enc.dwin() + kPre, src + off, take);
+        enc.encode_block_units(take, off == 0 && n > enc.unit_bytes(), none);
+        off += take;
+        if (off < n) enc.slide();
+    }
+    return enc.finish_device();
 }
 
 }  // namespace orz

@@ -40,7 +40,16 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
     from .api import OrzBuffer
 
     single_buf = len(mine) == 1 and isinstance(local[mine[0]], OrzBuffer)
-    if single_buf:
+    # members that lie in device memory already (uint8 tensors on `dev`: StreamEncoder.encode_to_device, round 6) are sent from
+    # where they lie -- no copy to the host and back (before: every member went device -> host -> device -> wire)
+    on_dev = bool(mine) and all(isinstance(local[m], torch.Tensor) for m in mine)
+    if on_dev:
+        parts = [local[m].reshape(-1) for m in mine]
+        flat = (parts[0] if len(parts) == 1 else torch.cat(parts)) if sum(p.numel() for p in parts) else None
+        blob = flat if flat is not None else torch.empty(0, dtype=torch.uint8, device=dev)
+        if flat is not None and flat.device != torch.device(dev):
+            flat = flat.to(dev)
+    elif single_buf:
         blob = local[mine[0]]
         flat = torch.frombuffer(blob.view(), dtype=torch.uint8) if len(blob) else None
     else:
@@ -64,7 +73,10 @@ def gather_members(local, n_members, rank, world, device=None, to_host=True):
     for r in range(world):
         ms = members_of_rank(n_members, r, world)
         if r == 0:
-            raw = bytes(blob) if (to_host or not single_buf) else blob  # to_host: always plain bytes
+            if on_dev:
+                raw = blob.cpu().numpy().tobytes() if to_host else blob
+            else:
+                raw = bytes(blob) if (to_host or not single_buf) else blob  # to_host: always plain bytes
         elif r in bufs:
             raw = bufs[r].cpu().numpy().tobytes() if to_host else bufs[r]
         else:

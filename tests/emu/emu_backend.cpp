@@ -83,6 +83,7 @@ struct EmuBackend {
     uint64_t take_host_syncs() { return 0; }
     void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
     void sync() {}
+    void mark_end() {}
     bool check_hints() const { return true; }  // (the emulation verifies every count the host derives)
     uint32_t handoff_polls() const { return 1; }  // blocks run one after another here: waiting cannot help
     uint32_t handoff_deadline() const { return 0; }
@@ -324,6 +325,24 @@ extern "C" int emu_encode_fast(const uint8_t* src, size_t n, int depth, int lazy
     } catch (const std::exception& e) {
         g_emu_err = e.what();
         if (!std::getenv("ORZ_VERIFY_INJECT")) std::fprintf(stderr, "emu_encode_fast: %s\n", e.what());
+        return -1;
+    }
+}
+// the same through the device-output path (round 6: FrameChunks / FrameAdvance / FrameEof frame the stream in "device" memory);
+// cap = 0: the encoder's own buffer, else a caller buffer of that many bytes.  Returns -1 with the message in emu_last_error().
+extern "C" int emu_encode_fast_device(const uint8_t* src, size_t n, int depth, int lazy1, int lazy2, size_t cap, uint8_t** dst, size_t* dst_len) {
+    try {
+        EmuBackend be;
+        orz::Cfg cfg{depth, lazy1, lazy2};
+        orz::StreamEncoder<EmuBackend> enc(be, cfg, 62, 64, true, orz::kFastTile, orz::kFastRounds);
+        std::vector<uint8_t> mine(cap);
+        const auto r = orz::encode_stream_device(enc, be, src, n, false, cap ? mine.data() : nullptr, cap);
+        *dst = (uint8_t*)std::malloc(r.len ? r.len : 1);
+        std::memcpy(*dst, r.data, r.len);
+        *dst_len = r.len;
+        return 0;
+    } catch (const std::exception& e) {
+        g_emu_err = e.what();
         return -1;
     }
 }
