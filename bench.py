@@ -301,7 +301,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (ORZ_BENCH_FORCE_DIST=1: the distributed branch at world size 1 -- tests/test_gpu_device_output.py runs it under torchrun with
+    # the nccl backend so that the RCCL path has executed on the one GPU a test box has)
+    distributed = world > 1 or (os.environ.get("ORZ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     # test hook: ORZ_BENCH_BACKEND=gloo + ORZ_BENCH_DEVICE=0 runs several ranks on ONE GPU (RCCL refuses that)
     backend = os.environ.get("ORZ_BENCH_BACKEND", "nccl")
     if "ORZ_BENCH_DEVICE" in os.environ:

@@ -798,6 +798,10 @@ class HipBackend {
     void launch_waves(size_t nblocks, const K& k, size_t lds_bytes) {
         if (!nblocks) return;
         Bracket br(*this, profile_ ? KernelNames::of<K>() : 0);
+        if (lds_bytes > 64 * 1024) {  // more than 64 KB of dynamic LDS (a CU of gfx950 has 160 KB) has to be asked for once per kernel
+            static const hipError_t big = hipFuncSetAttribute(reinterpret_cast<const void*>(&orz_wave_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            if (big != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(big));
+        }
         hipLaunchKernelGGL(orz_wave_kernel<K>, dim3((unsigned)nblocks), dim3(64), lds_bytes, stream_, k);
         ORZ_HIP_CHECK(hipGetLastError());
     }

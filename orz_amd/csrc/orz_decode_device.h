@@ -9,6 +9,14 @@
 // HBM per member, the last eight decoded bytes in a register so the three context hashes need no loads,
 // canonical Huffman tables as 2^max_len-entry lookup tables in the blob.
 //
+// Round 6: the small hot state moved to LDS -- the words[] table (64 KB), a 12-bit first-level lookup table per Huffman table
+// (3 x 8 KB; codes longer than 12 bits fall through to the full table in the blob) and the 256 ring heads: 89 KB a wavefront, so a
+// CU runs one member -- and the chain of dependent memory round trips per item got shorter: the rank table's candidates
+// value[r], value[r + 1] are asked for together with index[excluded symbol] (the rank i is one of the two), a match whose source
+// does not overlap it is copied eight bytes a load, the bit reader refills with one 4-byte load.  Still ONE lane per member: what
+// bounds it now is the rank tables (800 KB) and the rings (6.3 MB) of a member, which live in L2 / Infinity Cache -- two to four
+// dependent round trips of 200..900 cycles per item.
+//
 // A member decodes straight into its place in the output buffer (positions before the member's first byte read as
 // zero, as the reference's window does), so the window never has to be MOVED: ring nodes hold offsets into the member,
 // and the reference's slide (src/lib.rs:119-124; Bucket::forward, src/matcher.rs:82-87) is a counter -- a node whose
@@ -22,6 +30,7 @@
 #include <vector>
 
 #include "orz_common.h"
+#include "orz_parse.h"  // (ldu32 / ldu64 / stu64: unaligned loads and stores)
 
 namespace orz {
 
@@ -50,6 +59,15 @@ struct DecodeLayout {  // byte offsets into one member's state blob
     static constexpr size_t kBytes = (kOrder + 1024 + 255) / 256 * 256;
 };
 
+struct DecodeLds {  // byte offsets into a member's LDS (DecodeMember::lds_bytes())
+    static constexpr uint32_t kPrimBits = 12;
+    static constexpr size_t kWords = 0;                                  // [32768][2] words[]
+    static constexpr size_t kPrim = kWords + 65536;                      // [3][4096] u16 first-level lookup: (symbol << 4) | length, kLong = look in the full table
+    static constexpr size_t kHead = kPrim + (size_t)3 * 4096 * 2;        // [256] u32 ring heads
+    static constexpr size_t kBytes = kHead + 256 * 4;
+};
+constexpr uint16_t kDecLong = 0xffff;  // (no real entry: a symbol is below 512 and a length below 16)
+
 struct DecodeArgs {
     const uint8_t* src;        // the container
     const uint64_t* m_begin;   // [members] offset of the member's first chunk-length prefix
@@ -73,7 +91,7 @@ struct DecodeMember {
         ORZ_HD void fill() {
             if (have >= 32) return;
             uint32_t w = 0;  // reading past the chunk yields zeros: the encoder padded to 32 bits
-            if (at + 4 <= n) w = ((uint32_t)p[at] << 24) | ((uint32_t)p[at + 1] << 16) | ((uint32_t)p[at + 2] << 8) | p[at + 3];
+            if (at + 4 <= n) { const uint32_t le = ldu32(p + at); w = (le << 24) | ((le & 0xff00) << 8) | ((le >> 8) & 0xff00) | (le >> 24); }
             else for (uint32_t i = 0; i < 4; i++) w = (w << 8) | (at + i < n ? p[at + i] : 0);
             at += 4;
             acc = (acc << 32) | w;
@@ -104,7 +122,7 @@ struct DecodeMember {
     };
 
     // canonical code -> lookup table (src/coder.rs:124-141, src/huffman.rs:118-167); returns max_len, 99 = bad
-    ORZ_HD static uint32_t read_table(Bits& br, uint8_t* lens, uint16_t* lut) {
+    ORZ_HD static uint32_t read_table(Bits& br, uint8_t* lens, uint16_t* lut, uint16_t* prim) {
         bool bad = false;
         const uint32_t max_len = br.varint(bad);
         if (!bad && max_len == 16) return 98;
@@ -122,6 +140,10 @@ struct DecodeMember {
         }
         const uint32_t size = 1u << max_len;
         for (uint32_t i = 0; i < size; i++) lut[i] = 0;
+        // the first-level table over the code's first P = min(max_len, 12) bits: codes of at most P bits resolve there (LDS), a
+        // prefix of longer codes says so (kDecLong) and the full table in the blob is asked
+        const uint32_t P = max_len < DecodeLds::kPrimBits ? max_len : DecodeLds::kPrimBits, down = max_len - P;
+        for (uint32_t i = 0; i < (1u << P); i++) prim[i] = 0;
         uint32_t code = 0, cur = 1;
         for (uint32_t L = 1; L <= max_len; L++)
             for (uint32_t sy = 0; sy < ns; sy++) {
@@ -131,34 +153,44 @@ struct DecodeMember {
                 if (base + (1u << rest) > size) return 99;
                 const uint16_t e = (uint16_t)((sy << 4) | L);
                 for (uint32_t i = 0; i < (1u << rest); i++) lut[base + i] = e;
+                if (L <= P) { for (uint32_t i = 0; i < (1u << (P - L)); i++) prim[(base >> down) + i] = e; }
+                else prim[base >> down] = kDecLong;
                 code++;
             }
         return max_len;
     }
-    ORZ_HD static uint32_t sym(Bits& br, const uint16_t* lut, uint32_t max_len) {
+    ORZ_HD static uint32_t sym(Bits& br, const uint16_t* lut, const uint16_t* prim, uint32_t max_len) {
         if (max_len == 0) return 0;
-        const uint32_t e = lut[br.peek(max_len)];
+        const uint32_t P = max_len < DecodeLds::kPrimBits ? max_len : DecodeLds::kPrimBits;
+        uint32_t e = prim[br.peek(P)];
+        if (e == kDecLong) e = lut[br.peek(max_len)];
         br.skip(e & 15);
         return e >> 4;
     }
 
+    static size_t lds_bytes() { return DecodeLds::kBytes; }
     template <class W>
     ORZ_D void operator()(W& w) const {
-        if (w.lane() != 0 || w.block() >= a.count) return;
+        if (w.block() >= a.count) return;
+        uint32_t* l32 = (uint32_t*)w.lds();  // words[] and the ring heads start at zero (LZContext::new, src/lz.rs:57-66): all lanes clear them
+        for (uint32_t i = w.lane(); i < DecodeLds::kBytes / 4; i += 64) l32[i] = 0;
+        w.sync();
+        if (w.lane() != 0) return;
         const uint32_t m = a.first + w.block();
-        a.status[m] = run(m, a.state + (size_t)w.block() * DecodeLayout::kBytes);
+        a.status[m] = run(m, a.state + (size_t)w.block() * DecodeLayout::kBytes, w.lds());
     }
 
-    ORZ_HD uint32_t run(uint32_t m, uint8_t* st) const {
+    ORZ_HD uint32_t run(uint32_t m, uint8_t* st, uint8_t* lds) const {
         uint32_t* ring_pos = (uint32_t*)(st + DecodeLayout::kRingPos);
         uint8_t* ring_min = st + DecodeLayout::kRingMin;
         uint8_t* ring_exp = st + DecodeLayout::kRingExp;
-        uint32_t* head = (uint32_t*)(st + DecodeLayout::kHead);
+        uint32_t* head = (uint32_t*)(lds + DecodeLds::kHead);
+        uint16_t* prim = (uint16_t*)(lds + DecodeLds::kPrim);
         uint16_t* rank_val = (uint16_t*)(st + DecodeLayout::kRankVal);
         uint16_t* rank_idx = (uint16_t*)(st + DecodeLayout::kRankIdx);
         uint32_t* rank_cnt = (uint32_t*)(st + DecodeLayout::kRankCnt);
         uint32_t* rank_sum = (uint32_t*)(st + DecodeLayout::kRankSum);
-        uint8_t* words = st + DecodeLayout::kWords;
+        uint8_t* words = lds + DecodeLds::kWords;
         uint16_t* lut = (uint16_t*)(st + DecodeLayout::kLut);
         uint8_t* lens = st + DecodeLayout::kLens;
         uint16_t* order = (uint16_t*)(st + DecodeLayout::kOrder);
@@ -211,12 +243,12 @@ struct DecodeMember {
             if (bad) return kDecBadData;
             uint32_t ml[3];
             for (int k = 0; k < 3; k++) {
-                ml[k] = read_table(br, lens, lut + (size_t)k * 32768);
+                ml[k] = read_table(br, lens, lut + (size_t)k * 32768, prim + (size_t)k * 4096);
                 if (ml[k] == 99) return kDecBadData;
                 if (ml[k] == 98) return kDecDeepTable;
             }
             for (uint32_t it = 0; it < n_items; it++) {
-                const uint32_t r = sym(br, lut + (after_literal ? 32768 : 0), ml[after_literal ? 1 : 0]);
+                const uint32_t r = sym(br, lut + (after_literal ? 32768 : 0), prim + (after_literal ? 4096 : 0), ml[after_literal ? 1 : 0]);
                 if (r >= kSyms) return kDecBadData;
                 // hash1(spos-1), hash2(spos-1) from the last three bytes (src/lz.rs:482-492)
                 const uint8_t b1 = (uint8_t)tail, b2 = (uint8_t)(tail >> 8), b3 = (uint8_t)(tail >> 16);
@@ -227,12 +259,14 @@ struct DecodeMember {
                 const uint32_t c = ctx | (after_literal ? 256u : 0u);
                 uint16_t* val = rank_val + (size_t)c * kSyms;
                 uint16_t* idx = rank_idx + (size_t)c * kSyms;
+                // (the rank is r or r + 1 -- or the excluded symbol's: both candidates are asked for with index[excluded], one round trip)
                 const uint32_t iu = idx[w0];
+                const uint16_t va = val[r < kSyms - 1 ? r : 0], vb = val[r + 1 < kSyms ? r + 1 : 0];
+                uint32_t cnt = rank_cnt[c], sum = rank_sum[c];
                 const uint32_t i = r == kSyms - 1 ? iu : r + (r >= iu ? 1u : 0u);
                 if (i >= kSyms) return kDecBadData;
-                const uint16_t v = val[i];
+                const uint16_t v = r == kSyms - 1 ? val[i] : (i == r ? va : vb);
                 {
-                    uint32_t cnt = rank_cnt[c], sum = rank_sum[c];
                     if (cnt > kSyms) { cnt = cnt * 9 / 10; sum = sum * 9 / 10; }
                     cnt += 1;
                     sum += i;
@@ -257,7 +291,7 @@ struct DecodeMember {
                 // src/lz.rs:478): such bytes are decoded but not stored -- the next member's bytes live there
                 const uint32_t opos = spos - kPre + slid;
                 if (opos >= out_len) return kDecSizeMismatch;  // an item STARTING past the end: not a stream of this size
-                uint32_t ro = 0, len = 0;
+                uint32_t ro = 0, len = 0, mn_raw = 0;  // (mn_raw: the source node's len_min as the match read it -- its update below needs no second load)
                 bool match = false;
                 if (v == kWordSym) {
                     out[opos] = w0;
@@ -275,21 +309,45 @@ struct DecodeMember {
                     ro = base + br.bits(roid >> 1);
                     if (ro >= kRing) return kDecBadData;
                     const uint32_t node = (head[ctx] + kRing - ro) % kRing;
-                    const uint32_t enc = lenid == 5 ? sym(br, lut + 2 * 32768, ml[2]) : lenid;
+                    const uint32_t enc = lenid == 5 ? sym(br, lut + 2 * 32768, prim + 2 * 4096, ml[2]) : lenid;
                     // ring nodes hold 1 + the member offset of their item (0 = never written: the reference's pos 0)
                     const uint32_t srec = ring_pos[(size_t)ctx * kRing + node];
                     uint32_t mn = ring_min[(size_t)ctx * kRing + node], ex = ring_exp[(size_t)ctx * kRing + node];
+                    mn_raw = mn;
                     if (mn < kMinLen) mn = kMinLen;
                     if (ex < kMinLen) ex = kMinLen;
                     len = enc + mn > ex ? enc + mn : (enc > 0 ? enc + mn - 1 : ex);  // src/lz.rs:459-467
                     // dead: never written, or slid out of the window (window offset = member offset + kPre - slid <= 0)
                     if (srec == 0 || (uint64_t)(srec - 1) + kPre <= (uint64_t)slid || srec - 1 >= opos || len > kMaxLen + 127) return kDecBadData;
                     const uint32_t src = srec - 1;
-                    for (uint32_t k = 0; k < len; k++) {  // overlap-safe forward copy
-                        const uint32_t sp = src + k;
-                        const uint8_t b = sp < out_len ? out[sp] : 0;
-                        if (opos + k < out_len) out[opos + k] = b;
-                        tail = (tail << 8) | b;
+                    const uint32_t len8 = (len + 7) & ~7u;
+                    if (src + len8 <= opos && opos + len <= out_len) {
+                        // the source lies wholly before the item (and the last load's spare bytes too): eight bytes a load, the loads
+                        // of 32 bytes asked for together before their stores (mem_fast_copy, src/mem.rs:74-92, for a lane); the
+                        // register of the last eight bytes from one more load of the source's end
+                        const uint64_t endw = len >= 8 ? ldu64(out + src + len - 8) : 0;
+                        uint64_t first = 0;
+                        for (uint32_t k0 = 0; k0 < len; k0 += 32) {
+                            uint64_t q[4];
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) q[j] = k0 + 8 * j < len ? ldu64(out + src + k0 + 8 * j) : 0;
+                            if (k0 == 0) first = q[0];
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) {
+                                const uint32_t k = k0 + 8 * j;
+                                if (k + 8 <= len) stu64(out + opos + k, q[j]);
+                                else for (uint32_t t = k; t < len; t++) out[opos + t] = (uint8_t)(q[j] >> (8 * (t - k)));
+                            }
+                        }
+                        if (len >= 8) tail = __builtin_bswap64(endw);
+                        else tail = (tail << (8 * len)) | (__builtin_bswap64(first) >> (64 - 8 * len));
+                    } else {
+                        for (uint32_t k = 0; k < len; k++) {  // overlap-safe forward copy
+                            const uint32_t sp = src + k;
+                            const uint8_t b = sp < out_len ? out[sp] : 0;
+                            if (opos + k < out_len) out[opos + k] = b;
+                            tail = (tail << 8) | b;
+                        }
                     }
                     after_literal = false;
                     match = true;
@@ -299,8 +357,7 @@ struct DecodeMember {
                     const uint32_t h = head[ctx], nh = (h + 1) % kRing;
                     if (match && len >= kMinLen) {
                         const uint32_t ni = (h + kRing - ro) % kRing;
-                        uint8_t& mm = ring_min[(size_t)ctx * kRing + ni];
-                        if (mm <= len) mm = (uint8_t)(len + 1 < 127 ? len + 1 : 127);
+                        if (mn_raw <= len) ring_min[(size_t)ctx * kRing + ni] = (uint8_t)(len + 1 < 127 ? len + 1 : 127);
                     }
                     ring_pos[(size_t)ctx * kRing + nh] = opos + 1;
                     ring_min[(size_t)ctx * kRing + nh] = 0;
@@ -437,7 +494,7 @@ void decode_members_device(BE& be, const uint8_t* src, size_t n, std::vector<uin
         const uint32_t count = M - first < slots ? M - first : slots;
         if (first) be.memset(d_state, 0, (size_t)slots * DecodeLayout::kBytes);  // (alloc zeroes the first round)
         be.timed_begin(2);  // (a slot that is recorded without profile mode)
-        be.launch_waves(count, DecodeMember{DecodeArgs{d_src, d_begin, d_end, d_off, d_len, d_out, d_state, d_status, first, count}}, 0);
+        be.launch_waves(count, DecodeMember{DecodeArgs{d_src, d_begin, d_end, d_off, d_len, d_out, d_state, d_status, first, count}}, DecodeMember::lds_bytes());
         be.timed_end(2);
         stats.launches++;
     }

@@ -45,8 +45,11 @@ constexpr uint32_t kHistSub = (kPre + 1) / kSub;   // unified subtiles of the hi
 constexpr uint32_t kRingMargin = 4;                // item starts the repairs may still add between a source and its reference
 constexpr uint32_t kFastTile = 262144;             // default Gauss-Seidel tile (positions) and rounds per tile.  Measured on a full block,
 constexpr uint32_t kFastRounds = 4;                // emulator, vs the oracle: text -l1 256 K x 3 / x 4: -0.00 / -0.04 %, 512 K x 3: +0.2 %;
-constexpr uint32_t kSettledTile = 262144;          // the schedule of a block that follows a block of settled, text-like statistics
-constexpr uint32_t kSettledRounds = 3;             // (StreamEncoder::fast_parse, round 6): one round less costs text nothing
+constexpr uint32_t kSettledTile = 393216;          // the schedule of a block that follows a block of settled, text-like statistics
+constexpr uint32_t kSettledTileDeep = 262144;      // (StreamEncoder::fast_parse, round 6): three rounds cost text nothing (100 MB, -l1 / -l2:
+constexpr uint32_t kSettledRounds = 3;             // 256 K x 4 -0.029 / +0.159 %, 256 K x 3 -0.028 / +0.150 %, 384 K x 3 +0.074 / +0.230 %, 512 K x 3 +0.154 /
+                                                   // +0.309 %; zeros with noise -l2: +0.36 / +0.44 / +0.78 / +1.37 %); kernel time of a block 31.7 -> 31.0 /
+                                                   // 29.9 / 30.1 ms.  -l2 keeps the 256 K tile (its band is the tighter one).
                                                    // zeros + noise -l2 (one hot context, item starts that depend on each other over long
                                                    // distances): 256 K x 3 / x 4 / x 5: +0.81 / +0.46 / +0.40 %, 512 K x 4: +1.5 %
 
@@ -1402,6 +1405,29 @@ struct FastFlip {
         if (y > hi) return;
         flip_one(y, nullptr);
     }
+    // Which of the eight positions lo + t .. lo + t + 7 (t a multiple of 8, lo - kPre a multiple of 8) have anything to flip: the
+    // tests of flip_one on 8-byte loads of the flag arrays -- most positions of a step have nothing to do, and a thread per
+    // position that finds that out costs a wavefront per 64 of them (FlipPrefixWave).
+    ORZ_D uint32_t flip_mask8(uint32_t t) const {
+        const uint32_t y0 = lo + t, i0 = y0 - kPre;
+        if (y0 > hi) return 0;
+        const uint32_t exit_at = next_entry != ~0u ? a.tentry[next_entry] : a.len;
+        const uint64_t mf8 = *reinterpret_cast<const uint64_t*>(a.mfb + i0), ef8 = *reinterpret_cast<const uint64_t*>(a.efb + i0);
+        const uint64_t pt8 = *reinterpret_cast<const uint64_t*>(a.pt + i0);
+        const uint32_t sb = (uint32_t)((a.sbits[i0 / 64] >> (i0 & 63)) & 0xff);
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t y = y0 + k;
+            if (y > hi) break;
+            const uint32_t mf = (uint32_t)(mf8 >> (8 * k)) & 0xff, ef = (uint32_t)(ef8 >> (8 * k)) & 0xff, ptk = (uint32_t)(pt8 >> (8 * k)) & 0xff;
+            const uint32_t s = (uint32_t)(y == exit_at) | (y < a.len ? (sb >> k) & 1 : 0);
+            const uint32_t sw = y < a.len ? s : mf;
+            const uint32_t ew = y >= kPre + 1 ? (uint32_t)(s && ptk != kTyWord) : ef;
+            if (sw != mf || ew != ef) m |= 1u << k;
+        }
+        return m;
+    }
     // kdirty (repair stage): one bit per hash2 key whose word-update bits changed -- the WORD items of those keys are judged again
     ORZ_D void flip_one(uint32_t y, uint64_t* kdirty) const {
         const uint32_t i = y - kPre;
@@ -1531,17 +1557,36 @@ struct FastPrefixSerial {  // whole block, thread per ctx: sixteen independent l
 // retiring tile.  As branches of the graph on streams of their own these pairs depended on which hardware queues the runtime
 // handed out; as ONE grid whose first blocks do one job and whose last blocks the other they always run side by
 // side: FastFlip beside FastPrefix, then FastRetire beside FastHorizon.  Wave-shaped launches (64 threads a block).
+// Round 6: a wavefront of the flip part takes 512 positions, not 64 -- a lane looks at eight positions with four 8-byte loads
+// (FastFlip::flip_mask8), the positions that do have something to flip are listed in LDS (a prefix sum over the lanes' counts) and
+// the wavefront then takes them a lane each: an eighth of the wavefronts, and no lane walks for eight positions in a row (a thread
+// per eight positions WITHOUT the hand-over measured 45 -> 132 us in round 3).
+constexpr uint32_t kFlipSpan = 512;
+ORZ_HD size_t flip_blocks(uint32_t nflip) { return (nflip + kFlipSpan - 1) / kFlipSpan; }
 struct FlipPrefixWave {
     FastFlip f;
     FastPrefix p;
     uint32_t nflip;  // positions FastFlip visits; its blocks come first
-    static size_t lds_bytes() { return 0; }
+    static size_t lds_bytes() { return kFlipSpan * 2; }
     template <class W>
     ORZ_D void operator()(W& w) const {
-        const uint32_t fb = (nflip + 63) / 64;
+        const uint32_t fb = (uint32_t)flip_blocks(nflip);
         if (w.block() < fb) {
-            const uint32_t t = w.block() * 64 + w.lane();
-            if (t < nflip) f((size_t)t);
+            uint16_t* q = (uint16_t*)w.lds();
+            const uint32_t lane = w.lane(), base = w.block() * kFlipSpan, t0 = base + lane * 8;
+            uint32_t m = t0 < nflip ? f.flip_mask8(t0) : 0;
+            if (t0 + 8 > nflip && t0 < nflip) m &= (1u << (nflip - t0)) - 1;
+            const uint32_t mine = (uint32_t)popc64(m);
+            uint32_t v = mine;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t t = w.shfl(v, lane >= d ? lane - d : lane);
+                if (lane >= d) v += t;
+            }
+            const uint32_t tot = w.bcast(v, 63);
+            uint32_t off = v - mine;
+            while (m) { const uint32_t k = (uint32_t)ctz64(m); m &= m - 1; q[off++] = (uint16_t)(lane * 8 + k); }
+            w.sync();
+            for (uint32_t e = lane; e < tot; e += 64) f((size_t)(base + q[e]));
         } else {
             p.run(w, w.block() - fb);
         }
@@ -1551,6 +1596,9 @@ struct RetireHorizonWave {
     FastRetire r;
     FastHorizon h;
     uint32_t nret;  // positions of the retiring tile (0 = none this step); their blocks come first
+    // (round 6 tried FlipPrefixWave's hand-over here too -- 512 positions a wavefront, the item starts among them a lane each: 2.1 ->
+    // 2.8 ms a block.  A retiring item start is a chain of its own (galloping down the slots, bitmap words, the record), a third of the
+    // positions are item starts, and an eighth of the wavefronts means an eighth of the chains in flight: a thread per position it stays.)
     static size_t lds_bytes() { return 0; }
     template <class W>
     ORZ_D void operator()(W& w) const {

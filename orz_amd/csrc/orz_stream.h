@@ -118,9 +118,11 @@ struct ScatterSlots {  // idx[pos[j]] = j ; run starts
     uint32_t* idx;
     uint32_t* runstart;
     uint32_t* runend;  // optional
+    uint32_t idx_from = 0;  // positions below this one get no idx entry (fast mode: nothing asks for the slot of a history position,
+                            // and a scattered 4-byte store costs a 64-byte line: a quarter of the slots are history on text)
     ORZ_HD void operator()(size_t tid) const {
         if (tid >= n) return;
-        idx[pos[tid]] = (uint32_t)tid;
+        if (pos[tid] >= idx_from) idx[pos[tid]] = (uint32_t)tid;
         if (tid == 0 || keys[tid] != keys[tid - 1]) runstart[keys[tid]] = (uint32_t)tid;
         if (runend && (tid + 1 == n || keys[tid + 1] != keys[tid])) runend[keys[tid]] = (uint32_t)tid + 1;
     }
@@ -411,6 +413,7 @@ class StreamEncoder {
             // fewer in runs of "interior" 4-grams, so the table reaches well beyond 4 x depth
             fK_ = kFastK;  // (deeper runs: the compact lists of final item starts, FastEval / FastRetire)
             sched_auto_ = ftile_ == kFastTile && frounds_ == kFastRounds;
+            if (cfg.depth > 20) sched_tile_ = kSettledTileDeep;
             if (const char* sc = getenv("ORZ_FAST_SCHED")) {
                 unsigned t = 0, r = 0;
                 if (sscanf(sc, "%ux%u", &t, &r) == 2 && t >= kSub && t % kSub == 0 && t <= kNewMax && r >= 1 && r <= 64) { sched_tile_ = t; sched_rounds_ = r; }
@@ -666,7 +669,7 @@ class StreamEncoder {
         uint32_t* kkeysB = keysB + kWLen;
         be_.launch(std::max<size_t>(nent, (size_t)n + 1), BuildKeys{win, hpos_, tailkey_, nhist, n, keysA, valsA, kkeysA, kvalsA});
         be_.sort_pairs_u32(keysA, keysB, valsA, epos_, nent, 21);
-        be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_, nullptr});
+        be_.launch(nent, ScatterSlots{keysB, epos_, nent, idx_, runstart_, nullptr, fast_ ? kPre : 0u});
         be_.sort_pairs_u32(kkeysA, kkeysB, kvalsA, kpos_, (size_t)n + 1, 15);
         if (fast_) {
             // every reset the prep and the post stage need, ONE launch (round 6; before: eight fill dispatches)
@@ -938,8 +941,8 @@ class StreamEncoder {
         // a quarter the size (match-dense, highly repetitive data; never seen on text).
         // Rounds: R per tile -- and, since round 6, a SCHEDULE PER BLOCK.  The default (256 K x 4) is what zeros with noise need (one
         // hot context whose item starts depend on each other over long distances: +0.46 % against +0.81 % at three rounds); text
-        // loses nothing at three rounds (a full block, emulation: +0.045 % at 256 K x 4, +0.041 % at 256 K x 3) and a quarter of
-        // FastEval's work goes.  Which kind a block is, the block BEFORE it says (its statistics came with the parse's read-back:
+        // loses nothing at three rounds (a full block, emulation: +0.045 % at 256 K x 4, +0.041 % at 256 K x 3) and little with
+        // tiles half as large again (kSettledTile, orz_fast.h: the measurements).  Which kind a block is, the block BEFORE it says (its statistics came with the parse's read-back:
         // no extra wait, and the same choice on every run -- reused encoders, the emulation): text-like = at least one item per ten
         // bytes, the busiest ring context under a quarter of the items, under half a per cent of the items repaired.  A stream's
         // first block, short blocks, and a block whose parse turns out unstable under the settled schedule (it is redone) take
@@ -1056,7 +1059,7 @@ class StreamEncoder {
                 const uint32_t rlo = retire ? kPre + (step - R) * T : kPre, rhi = retire ? (uint32_t)std::min<uint64_t>(len, (uint64_t)rlo + T) : kPre;
                 if (fused_steps) {
                     const uint32_t nflip = fhi - lo + 1, nret = rhi - rlo;
-                    be_.launch_waves((size_t)(nflip + 63) / 64 + 256, FlipPrefixWave{ff, fp, nflip}, 0);
+                    be_.launch_waves(flip_blocks(nflip) + 256, FlipPrefixWave{ff, fp, nflip}, FlipPrefixWave::lds_bytes());
                     be_.launch_waves((size_t)(nret + 63) / 64 + (fh.threads() + 63) / 64, RetireHorizonWave{FastRetire{a, rlo, rhi, fcut_}, fh, nret}, 0);
                     // (FastRetireDone: in the next step's FastDecide grid -- every retiring step is followed by one)
                 } else {
@@ -1339,19 +1342,18 @@ class StreamEncoder {
             v.nitems = nitems; v.end = len; v.ML = ML_; v.SRC = SRC_; v.ORD = ORD_; v.sperm = t.sperm; v.rstart = t.rstart;
             v.vrec = vrec_; v.vord = vord_; v.vctx = vctx_; v.vlast = vlast_; v.vwords = vwords_; v.err = verr;
             be_.launch(kVeCount, VerInit{verr});
-            be_.memset(vrec_ + kPre, 0, (size_t)n * 4);
-            be_.launch(nitems, VerItems{v});
-            be_.launch(nitems, VerOrdinals{v});
-            be_.launch(nitems, VerMatches{v});
-            be_.launch(nitems, VerLmKeys{v, entA_});
-            const uint64_t* lmk = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits, kPosBits);  // (the keys come in item order)
-            be_.launch(nitems, VerLenMin{v, lmk});
-            be_.launch(nitems, VerLmCommit{v, lmk});
-            be_.launch(nitems, VerWordEvents{v, entA_});
-            const uint64_t* evs = be_.sort_u64(entA_, entB_, nitems, 2 * kPosBits - 9, kPosBits);  // 15 key bits + the sentinel's bit above 25 position bits that come in order
-            be_.launch(nitems, VerWords{v, evs});
-            be_.launch(nitems, VerWordsCarry{v, evs});
-            be_.launch(256, VerCarry{v});
+            { ZeroRanges z; z.add(vrec_ + kPre, (size_t)n * 4); be_.launch(z.units(), z); }
+            // three launches and the two sorts (round 6; before: nine launches) -- the keys of both sorts are built by the first,
+            // each in its half of the sort buffers (at most 2^24 items: half of a buffer's 2^25 entries)
+            uint64_t* lmA = entA_;
+            uint64_t* lmB = entB_;
+            uint64_t* evA = entA_ + kWLen / 2;
+            uint64_t* evB = entB_ + kWLen / 2;
+            be_.launch(nitems, VerStage1{v, lmA, evA});
+            const uint64_t* lmk = be_.sort_u64(lmA, lmB, nitems, 2 * kPosBits, kPosBits);  // (the keys come in item order)
+            const uint64_t* evs = be_.sort_u64(evA, evB, nitems, 2 * kPosBits - 9, kPosBits);  // 15 key bits + the sentinel's bit above 25 position bits that come in order
+            be_.launch(nitems, VerStage2{v, lmk, evs});
+            { const VerStage3 s3{v, lmk, evs}; be_.launch(s3.threads(), s3); }
         } else {
             be_.launch(kVeCount, VerInit{verr});
         }

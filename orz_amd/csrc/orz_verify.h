@@ -276,6 +276,39 @@ struct VerCarry {  // ring counts and after_literal for the next block
         if (c == 0 && a.nitems) a.vlast[0] = a.vlast[1];
     }
 };
+// The gate in three launches (round 6; before: nine).  What must be ordered stays ordered -- the records and ordinals of ALL items
+// (stage 1) before any match is judged against them (stage 2), every reference judged against the nodes' OLD len_min and the
+// table's OLD entries (stage 2) before the new ones are left behind (stage 3) -- and the kernels between those points, which read
+// the same item arrays over and over, run as one grid each.  A thread is an item (stages 1, 2) / a slot of the sorted lists (stage 3).
+struct VerStage1 {  // records + ordinals + the keys of both sorts
+    VerArgs a;
+    uint64_t *lmkeys, *wev;
+    ORZ_HD void operator()(size_t k) const {
+        VerItems{a}(k);
+        VerOrdinals{a}(k);
+        VerLmKeys{a, lmkeys}(k);
+        VerWordEvents{a, wev}(k);
+    }
+};
+struct VerStage2 {  // sources, ring distances and offset codes; len_min and length codes; excluded symbols and WORD items
+    VerArgs a;
+    const uint64_t *lmk, *evs;  // sorted
+    ORZ_HD void operator()(size_t k) const {
+        VerMatches{a}(k);
+        VerLenMin{a, lmk}(k);
+        VerWords{a, evs}(k);
+    }
+};
+struct VerStage3 {  // the state the next block's gate starts from
+    VerArgs a;
+    const uint64_t *lmk, *evs;
+    ORZ_HD size_t threads() const { return a.nitems > 256 ? a.nitems : 256; }
+    ORZ_HD void operator()(size_t j) const {
+        VerLmCommit{a, lmk}(j);
+        VerWordsCarry{a, evs}(j);
+        VerCarry{a}(j);
+    }
+};
 struct VerReset {  // LZContext::new (src/lz.rs:57-66): empty rings, zero words[], after_literal = true
     uint32_t *vctx, *vlast;
     ORZ_HD void operator()(size_t c) const {

@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 # GPU tier order: the per-row parity tests first, the full-size configurations and the soak last -- the tier runs with -x, and a
 # late failure in the heaviest, newest tests must not blank the per-row evidence ("what's weak" 2)
-_GPU_ORDER = ["test_gpu_parity.py", "test_gpu_fast.py", "test_device_decoder.py", "test_benchmark_tool.py", "test_enwik8.py",
+_GPU_ORDER = ["test_gpu_parity.py", "test_gpu_fast.py", "test_gpu_device_output.py", "test_device_decoder.py", "test_benchmark_tool.py", "test_enwik8.py",
               "test_gpu_verify.py", "test_gpu_arena.py", "test_gpu_configs.py", "test_gpu_soak.py"]
 
 
@@ -94,7 +94,23 @@ def emu():
         lib.emu_free(dst)
         return out
 
+    def encode_fast_device(data, cfg=(15, 9, 6), cap=0):
+        """the fast mode through the device-output path (the stream framed by FrameChunks / FrameAdvance / FrameEof): the stream,
+        or (None, message) when the encode fails"""
+        dst = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        data = bytes(data)
+        lib.emu_last_error.restype = ctypes.c_char_p
+        rc = lib.emu_encode_fast_device(data, ctypes.c_size_t(len(data)), cfg[0], cfg[1], cfg[2], ctypes.c_size_t(cap), ctypes.byref(dst),
+                                        ctypes.byref(n))
+        if rc != 0:
+            return None, lib.emu_last_error().decode()
+        out = ctypes.string_at(dst, n.value)
+        lib.emu_free(dst)
+        return out, None
+
     encode.lib = lib
+    encode.fast_device = encode_fast_device
     encode.fast = encode_fast
     encode.fast_reused = encode_fast_reused
     return encode

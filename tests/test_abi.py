@@ -95,6 +95,23 @@ def test_parse_kernel_keeps_three_waves_per_simd():
     assert int(fields["ScratchSize [bytes/lane]"]) == 0 and int(fields["VGPRs Spill"]) == 0, fields
 
 
+def test_the_hottest_parse_kernel_of_the_fast_mode_does_not_spill():
+    """FastEval is built for an occupancy target (ORZ_EVAL_WAVES, __graft_entry__.build): whatever the target, the shipped build
+    must not spill -- round 5's did (7 registers, 20 B of scratch per lane at six waves) while the build script said it did not"""
+    import __graft_entry__ as ge
+
+    ge.build()
+    path = ge.LIB + ".resources.txt"
+    if not os.path.exists(path):
+        pytest.skip("library was built without the resource remarks")
+    blocks = open(path).read().split("Function Name: ")
+    ev = [b for b in blocks if b.strip() and "orz_thread_kernel_occ" in b.splitlines()[0] and "FastEval" in b.splitlines()[0]]
+    assert ev, "no resource record for FastEval's occupancy-targeted kernel"
+    fields = dict(ln.split(": ", 1) for ln in ev[0].splitlines()[1:] if ": " in ln)
+    assert int(fields["ScratchSize [bytes/lane]"]) == 0 and int(fields["VGPRs Spill"]) == 0 and int(fields["SGPRs Spill"]) == 0, fields
+    assert int(fields["Occupancy [waves/SIMD]"]) >= 5, fields
+
+
 def test_bench_traffic_artefact_is_committed():
     """bench.py reports `roofline.traffic` from the newest committed PMC summary (tools/profile_round.sh) and labels it
     `from_profile: <file>`: the file must exist and hold the per-launch bytes of the kernels the roofline rows are about"""

@@ -44,6 +44,26 @@ def test_tile_and_round_settings(emu, oracle, tile, rounds):
     _roundtrip(emu, oracle, _data.mixed(50_000, seed=3), 1, tile=tile, rounds=rounds)
 
 
+@pytest.mark.parametrize("shape", ["empty", "one", "text", "mixed", "zeros", "random"])
+def test_the_device_framed_stream_is_the_host_framed_stream(emu, oracle, shape):
+    """round 6: FrameChunks / FrameAdvance / FrameEof frame { LEB128(t) chunk[t] }* + the EOF byte on the device
+    (/root/reference/src/lib.rs:79-80,89, src/ioutil.rs:79-88) -- the same bytes the host framing of collect_one writes, into the
+    encoder's own buffer and into a caller's; a caller's buffer that is too small fails the encode"""
+    n = 150_000
+    data = {"empty": lambda: b"", "one": lambda: b"a", "text": lambda: _data.text(n, seed=21), "mixed": lambda: _data.mixed(n, seed=22),
+            "zeros": lambda: _data.zeros_noise(n), "random": lambda: _data.random_bytes(60_000)}[shape]()
+    want, _ = emu.fast(data)
+    own, err = emu.fast_device(data)
+    assert err is None and own == want
+    mine, err = emu.fast_device(data, cap=len(want))  # exactly the stream's size is enough
+    assert err is None and mine == want
+    back, used = oracle.decode(own)
+    assert back == data and used == len(own)
+    if len(want) > 1:
+        none, err = emu.fast_device(data, cap=len(want) - 1)
+        assert none is None and "too small" in err
+
+
 def test_enwik_like_text_is_within_the_band(emu, oracle):
     import corpus
 

@@ -174,7 +174,9 @@ def test_default_settings_size_table(oracle, shape):
            "delta_pct": round(100 * (len(out) - ref) / ref, 4), "delta_bytes": len(out) - ref, "band_pct": 100 * band}
     _record(row)
     assert len(out) - ref <= band * ref + 64, row
-    if shape == "text":
+    # the low side of the band for every shape whose reference stream exceeds 64 KB; the period shapes
+    # compress 6 MB to ~3.2 KB, where twenty bytes are 0.6 %: exempt, named as such in BASELINE.md
+    if ref > 65536:
         assert ref - len(out) <= band * ref, row
 
 
