@@ -64,7 +64,10 @@ struct DecodeLds {  // byte offsets into a member's LDS (DecodeMember::lds_bytes
     static constexpr size_t kWords = 0;                                  // [32768][2] words[]
     static constexpr size_t kPrim = kWords + 65536;                      // [3][4096] u16 first-level lookup: (symbol << 4) | length, kLong = look in the full table
     static constexpr size_t kHead = kPrim + (size_t)3 * 4096 * 2;        // [256] u32 ring heads
-    static constexpr size_t kBytes = kHead + 256 * 4;
+    static constexpr size_t kRecip = kHead + 256 * 4;                    // [64] u32 reciprocals of the steady-state counts 327 + k
+    static constexpr size_t kRankCnt = kRecip + 64 * 4;                  // [512] u32 encoded_cnt of each symbol-ranking context
+    static constexpr size_t kRankSum = kRankCnt + 512 * 4;               // [512] u32 encoded_idx_sum
+    static constexpr size_t kBytes = kRankSum + 512 * 4;
 };
 constexpr uint16_t kDecLong = 0xffff;  // (no real entry: a symbol is below 512 and a length below 16)
 
@@ -80,6 +83,17 @@ struct DecodeArgs {
     uint32_t first, count;     // this launch decodes members first .. first + count - 1, one per block
 };
 
+// four bytes at any address, little-endian (the bit reader runs on the host too: index_members)
+ORZ_HD uint32_t dec_ld32(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ldu32(p);
+#else
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+#endif
+}
+
 struct DecodeMember {
     DecodeArgs a;
 
@@ -91,7 +105,7 @@ struct DecodeMember {
         ORZ_HD void fill() {
             if (have >= 32) return;
             uint32_t w = 0;  // reading past the chunk yields zeros: the encoder padded to 32 bits
-            if (at + 4 <= n) { const uint32_t le = ldu32(p + at); w = (le << 24) | ((le & 0xff00) << 8) | ((le >> 8) & 0xff00) | (le >> 24); }
+            if (at + 4 <= n) { const uint32_t le = dec_ld32(p + at); w = (le << 24) | ((le & 0xff00) << 8) | ((le >> 8) & 0xff00) | (le >> 24); }
             else for (uint32_t i = 0; i < 4; i++) w = (w << 8) | (at + i < n ? p[at + i] : 0);
             at += 4;
             acc = (acc << 32) | w;
@@ -175,6 +189,8 @@ struct DecodeMember {
         uint32_t* l32 = (uint32_t*)w.lds();  // words[] and the ring heads start at zero (LZContext::new, src/lz.rs:57-66): all lanes clear them
         for (uint32_t i = w.lane(); i < DecodeLds::kBytes / 4; i += 64) l32[i] = 0;
         w.sync();
+        l32[DecodeLds::kRecip / 4 + w.lane()] = 0xffffffffu / (327 + w.lane()) + 1;  // floor(n / d) == mulhi(n, floor(2^32 / d) + 1) for n < 2^17
+        w.sync();
         if (w.lane() != 0) return;
         const uint32_t m = a.first + w.block();
         a.status[m] = run(m, a.state + (size_t)w.block() * DecodeLayout::kBytes, w.lds());
@@ -186,10 +202,11 @@ struct DecodeMember {
         uint8_t* ring_exp = st + DecodeLayout::kRingExp;
         uint32_t* head = (uint32_t*)(lds + DecodeLds::kHead);
         uint16_t* prim = (uint16_t*)(lds + DecodeLds::kPrim);
+        const uint32_t* recip = (const uint32_t*)(lds + DecodeLds::kRecip);
         uint16_t* rank_val = (uint16_t*)(st + DecodeLayout::kRankVal);
         uint16_t* rank_idx = (uint16_t*)(st + DecodeLayout::kRankIdx);
-        uint32_t* rank_cnt = (uint32_t*)(st + DecodeLayout::kRankCnt);
-        uint32_t* rank_sum = (uint32_t*)(st + DecodeLayout::kRankSum);
+        uint32_t* rank_cnt = (uint32_t*)(lds + DecodeLds::kRankCnt);  // (LDS since round 6: the move targets are computed before the table's bytes arrive)
+        uint32_t* rank_sum = (uint32_t*)(lds + DecodeLds::kRankSum);
         uint8_t* words = lds + DecodeLds::kWords;
         uint16_t* lut = (uint16_t*)(st + DecodeLayout::kLut);
         uint8_t* lens = st + DecodeLayout::kLens;
@@ -259,33 +276,46 @@ struct DecodeMember {
                 const uint32_t c = ctx | (after_literal ? 256u : 0u);
                 uint16_t* val = rank_val + (size_t)c * kSyms;
                 uint16_t* idx = rank_idx + (size_t)c * kSyms;
-                // (the rank is r or r + 1 -- or the excluded symbol's: both candidates are asked for with index[excluded], one round trip)
+                // The rank is r or r + 1 (or the excluded symbol's), and count and sum live in LDS: the move targets of BOTH candidates
+                // are known before a byte of the table has arrived, so everything the item needs of the table -- index[excluded],
+                // value[r], value[r + 1] and the two values each candidate's move displaces -- is ONE round trip (round 5: three)
+                uint32_t cnt = rank_cnt[c], sum0 = rank_sum[c];
+                if (cnt > kSyms) { cnt = cnt * 9 / 10; sum0 = sum0 * 9 / 10; }
+                cnt += 1;
+                // next_i and the mid point for rank i (src/symrank.rs:67-74)
+                auto targets = [&](uint32_t i, uint32_t& ni, uint32_t& mid) {
+                    const uint32_t n16 = (sum0 + i) >> 4;
+                    // (sum / 16) / cnt: for the steady-state counts 327..390 by a 32-bit reciprocal -- floor(n / d) ==
+                    // mulhi(n, floor(2^32 / d) + 1) for n < 2^17 (the identity orz_symrank_kernel uses; tests/test_abi.py checks it)
+                    const uint32_t quo = (cnt >= 327 && cnt <= 390 && n16 < (1u << 17)) ? (uint32_t)(((uint64_t)n16 * (uint64_t)recip[cnt - 327]) >> 32) : n16 / cnt;
+                    const uint32_t dec = (i / 16 + (uint16_t)quo) & 0xffff;
+                    ni = i > dec ? i - dec : 0;
+                    if (ni < i / 2) ni = i / 2;
+                    mid = ni + (i - ni) / 2;
+                };
+                const uint32_t ra = r < kSyms - 1 ? r : 0, rb = r + 1 < kSyms ? r + 1 : 0;
+                uint32_t nia, mida, nib, midb;
+                targets(ra, nia, mida);
+                targets(rb, nib, midb);
                 const uint32_t iu = idx[w0];
-                const uint16_t va = val[r < kSyms - 1 ? r : 0], vb = val[r + 1 < kSyms ? r + 1 : 0];
-                uint32_t cnt = rank_cnt[c], sum = rank_sum[c];
+                const uint16_t va = val[ra], vb = val[rb], xa = val[mida], ya = val[nia], xb = val[midb], yb = val[nib];
                 const uint32_t i = r == kSyms - 1 ? iu : r + (r >= iu ? 1u : 0u);
                 if (i >= kSyms) return kDecBadData;
-                const uint16_t v = r == kSyms - 1 ? val[i] : (i == r ? va : vb);
-                {
-                    if (cnt > kSyms) { cnt = cnt * 9 / 10; sum = sum * 9 / 10; }
-                    cnt += 1;
-                    sum += i;
-                    rank_cnt[c] = cnt; rank_sum[c] = sum;
-                    const uint32_t dec = (i / 16 + (uint16_t)(sum / 16 / cnt)) & 0xffff;
-                    uint32_t ni = i > dec ? i - dec : 0;
-                    if (ni < i / 2) ni = i / 2;
-                    const uint32_t n = i - ni;
-                    if (n == 1) {
-                        const uint16_t o = val[ni];
-                        val[i] = o; idx[o] = (uint16_t)i;
-                        val[ni] = v; idx[v] = (uint16_t)ni;
-                    } else if (n > 1) {
-                        const uint32_t mid = ni + n / 2;
-                        const uint16_t x = val[mid], y = val[ni];
-                        val[i] = x; idx[x] = (uint16_t)i;
-                        val[mid] = y; idx[y] = (uint16_t)mid;
-                        val[ni] = v; idx[v] = (uint16_t)ni;
-                    }
+                uint16_t v, x, y;
+                uint32_t ni, mid;
+                if (r != kSyms - 1) {
+                    const bool first = i == ra;
+                    v = first ? va : vb; x = first ? xa : xb; y = first ? ya : yb;
+                    ni = first ? nia : nib; mid = first ? mida : midb;
+                } else {  // the excluded symbol itself (rare): its rank came with the loads above
+                    targets(i, ni, mid);
+                    v = val[i]; x = val[mid]; y = val[ni];
+                }
+                rank_cnt[c] = cnt; rank_sum[c] = sum0 + i;
+                if (i != ni) {  // value[i] <- value[mid] <- value[ni] <- v; a move by one has mid == ni: the swap (src/symrank.rs:75-96)
+                    val[i] = x; idx[x] = (uint16_t)i;
+                    if (mid != ni) { val[mid] = y; idx[y] = (uint16_t)mid; }
+                    val[ni] = v; idx[v] = (uint16_t)ni;
                 }
                 // the last item of a stream may run past the announced end (the chunk's end field cuts it back,
                 // src/lz.rs:478): such bytes are decoded but not stored -- the next member's bytes live there
@@ -304,11 +334,13 @@ struct DecodeMember {
                     after_literal = true;
                 } else {
                     const uint32_t roid = (v - 256) / 6, lenid = (v - 256) % 6;
-                    uint32_t base = 0;
-                    for (uint32_t k = 0; k < roid; k++) base += 1u << (k >> 1);
+                    // base(roid) = sum over k < roid of 2^(k / 2) (src/lz.rs:516-530) in closed form: j = roid / 2 full pairs give
+                    // 2 (2^j - 1), an odd roid one more term 2^j
+                    const uint32_t j2 = roid >> 1, base = 2 * ((1u << j2) - 1) + ((roid & 1) << j2);
                     ro = base + br.bits(roid >> 1);
                     if (ro >= kRing) return kDecBadData;
-                    const uint32_t node = (head[ctx] + kRing - ro) % kRing;
+                    const uint32_t hd = head[ctx];
+                    const uint32_t node = hd >= ro ? hd - ro : hd + kRing - ro;  // (head + N - ro) % N without the division: head, ro < N
                     const uint32_t enc = lenid == 5 ? sym(br, lut + 2 * 32768, prim + 2 * 4096, ml[2]) : lenid;
                     // ring nodes hold 1 + the member offset of their item (0 = never written: the reference's pos 0)
                     const uint32_t srec = ring_pos[(size_t)ctx * kRing + node];
@@ -354,9 +386,9 @@ struct DecodeMember {
                 }
                 // Bucket::update, src/matcher.rs:62-80
                 {
-                    const uint32_t h = head[ctx], nh = (h + 1) % kRing;
+                    const uint32_t h = head[ctx], nh = h + 1 == kRing ? 0 : h + 1;
                     if (match && len >= kMinLen) {
-                        const uint32_t ni = (h + kRing - ro) % kRing;
+                        const uint32_t ni = h >= ro ? h - ro : h + kRing - ro;
                         if (mn_raw <= len) ring_min[(size_t)ctx * kRing + ni] = (uint8_t)(len + 1 < 127 ? len + 1 : 127);
                     }
                     ring_pos[(size_t)ctx * kRing + nh] = opos + 1;

@@ -803,8 +803,10 @@ struct FastEval {
         // the round of the position's tile (0: the two positions beyond the range, looked at by the lazy rules)
         const uint32_t t = i / a.tile, rnd = step > t ? step - t : 0;
         bool scan = longrun && (rnd <= 1 || rnd == a.rounds);
-        if (a.dbg & 12) {  // (experiments: 4 = no second scan, 8 = no scans at all, 16 below = the second scan only where the path looks)
-            if ((a.dbg & 8) || ((a.dbg & 4) && rnd > 1)) scan = false;
+        if (a.dbg & (12 | 128 | 256)) {  // (experiments: 4 = no second scan, 8 = no scans at all, 16 below = the second scan only where the path looks,
+            if ((a.dbg & 8) || ((a.dbg & 4) && rnd > 1)) scan = false;  // 128 = no first-round scan, 256 = the first scan in round 2 instead of 1)
+            if ((a.dbg & 128) && rnd <= 1) scan = false;
+            if (a.dbg & 256) scan = longrun && (rnd == 2 || rnd == a.rounds);
         }
         if ((a.dbg & 16) && scan && rnd > 1) {
             // relevant to the current path: an item start, or one of the two positions behind an item start that found a match
@@ -901,6 +903,7 @@ struct FastEval {
         } else if (scan) {
             a.farv[i] = 0;  // (nothing beyond the window counts now; nothing is remembered)
         }
+        if ((a.dbg & (128 | 256)) && first && !scan) a.farv[i] = 0;  // (experiments without a first-round scan: nothing is remembered yet)
         // word predictor (src/lz.rs:132-133): newest update u <= p-2 with hash2(u-1) == hash2(p-1)
         if (rk < 64) kmask = rk ? kmask & (~0ull << (64 - rk)) : 0;
         if (km & 0x80) kmask &= ~(1ull << 63);

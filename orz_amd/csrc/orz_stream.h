@@ -398,7 +398,8 @@ class StreamEncoder {
     static constexpr uint32_t kMaxChunks = 17;
     static constexpr uint32_t kNumKeys = 256 * kHash;
     static constexpr uint32_t kDirtyWords = kNumKeys / 64 + 1;  // one bit per (ctx, hash) run
-    static constexpr int kFirstPasses = 10;                     // repair passes queued before the first read-back (lists form)
+    static constexpr int kFirstPasses = 12;                     // repair passes queued before the first read-back (lists form; text needs 6..7 under the
+                                                                // default schedule, 9..11 under the settled one: round 6 -- a pass behind the one that found nothing is a dozen empty launches)
     static constexpr uint32_t kRepairGrid = 16384;              // threads of the kernels that run over the repair stage's short lists
 
     // `fast`: the GPU-native parse mode (orz_fast.h) instead of the reference-identical one; `fast_tile` positions

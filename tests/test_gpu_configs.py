@@ -10,7 +10,7 @@ encoder (LZEncoder::encode, src/lz.rs:131-346) at the same level ON THE SAME MEM
   size table  the DEFAULT settings on text / mixed / zeros + noise / period 1, 3, 4, 7 at >= 4 MB, a stated band per shape
 
 The oracle's work on 1 GB (15 members, encode + decode) runs on a thread pool: ctypes releases the GIL and the
-members are independent streams.  Results are appended to gpurun_out/r05_configs_parity.jsonl when that directory
+members are independent streams.  Results are appended to gpurun_out/r06_configs_parity.jsonl when that directory
 is writable (the builder copies the file into profiles/)."""
 import json
 import os
@@ -36,7 +36,7 @@ def _record(row):
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "r05_configs_parity.jsonl"), "a") as f:
+        with open(os.path.join(d, "r06_configs_parity.jsonl"), "a") as f:
             f.write(json.dumps(row) + "\n")
     except OSError:
         pass

@@ -168,7 +168,7 @@ def test_soak_rotations_every_member_through_the_oracle(oracle):
            "members": members, "bytes": nbytes, "invalid": 0, "seconds": round(time.time() - t0, 1),
            "encode_MBps_8_encoders_host_buffers": round(nbytes / t_enc / 1e6, 1)}
     try:
-        with open(os.path.join(ROOT, "gpurun_out", "r05_soak.json"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r06_soak.json"), "a") as f:
             f.write(json.dumps(row) + "\n")
     except OSError:
         pass
