@@ -792,8 +792,22 @@ struct FastEval {
         }
         return fv;
     }
+    // Which position a thread takes.  A launch covers the active tiles oldest first, and its wavefronts are dispatched in thread
+    // order: the tile in its FIRST round -- every deep position scans -- came last, so the launch ended on its heaviest wavefronts
+    // with the GPU half empty.  Round 6: the newest tile's threads come first, then the oldest tile's (its last round: the second
+    // scan), then the tiles between (window evaluations only), each tile's positions in order as before (coalescing is per
+    // tile).  The threads are independent: same answers, another order.  (a.dbg & 2048: the old order, for measurements.)
+    ORZ_D uint32_t position_of(size_t tid) const {
+        const uint32_t span = hi - lo, T = a.tile;
+        if ((a.dbg & 2048) || span <= T) return lo + (uint32_t)tid;
+        const uint32_t nch = (span + T - 1) / T, s_last = span - (nch - 1) * T;  // chunks of T positions; the last one is short
+        if (tid < s_last) return lo + (nch - 1) * T + (uint32_t)tid;
+        const uint32_t u = (uint32_t)tid - s_last, k = u / T, off = u - k * T;
+        const uint32_t c = k == 0 ? nch - 2 : k - 1;  // the newest full chunk, then chunks 0, 1, ... in order
+        return lo + c * T + off;
+    }
     ORZ_HD void operator()(size_t tid) const {
-        const uint32_t p = lo + (uint32_t)tid;
+        const uint32_t p = position_of(tid);
         if (p >= hi) return;
         const uint8_t* win = a.win;
         const uint32_t i = p - kPre;
@@ -1049,19 +1063,18 @@ struct FastHorizon {
 // src/lz.rs:139-234 on the snapshot's answers: e = ev of the position, e1 / e2 = ev of the next two (0 past the end);
 // returns type | advance << 8
 ORZ_D uint32_t fast_decide(uint32_t p, uint32_t len, uint32_t e, uint32_t e1, uint32_t e2) {
+    // (selects, no early returns: PathUpWave makes 64 of these decisions a lane and the branchy form was a branch per rule)
     uint32_t L = e & 0xff;
-    if (p + L >= len) L = len - 1 - p;  // an item never reaches the block end (src/matcher.rs:183)
-    if (L < kMinLen) L = 0;
+    L = p + L >= len ? len - 1 - p : L;  // an item never reaches the block end (src/matcher.rs:183)
+    L = L < kMinLen ? 0 : L;
     const uint32_t lwm = (e >> 24) & 1;
-    uint32_t lazy = 0;
-    if (L > 0 && L < kMaxLen / 2) {
-        const uint32_t l1 = L + 1 + ((e >> 25) & 1), l2 = l1 - lwm;
-        if (((e1 >> 8) & 0xff) >= l1) lazy = 1;
-        else if (((e2 >> 16) & 0xff) >= l2) lazy = 2;
-    }
-    if (L > 0 && lazy == 0) return kTyMatch | (L << 8);
-    if (p + 1 < len && lazy != 1 && lwm) return kTyWord | (2u << 8);
-    return kTyLit | (1u << 8);
+    const uint32_t l1 = L + 1 + ((e >> 25) & 1), l2 = l1 - lwm;
+    const bool look = L > 0 && L < kMaxLen / 2;
+    const bool lazy1 = look && ((e1 >> 8) & 0xff) >= l1;
+    const bool lazy2 = look && !lazy1 && ((e2 >> 16) & 0xff) >= l2;
+    const bool match = L > 0 && !lazy1 && !lazy2;
+    const bool word = !match && p + 1 < len && !lazy1 && lwm != 0;
+    return match ? (kTyMatch | (L << 8)) : (word ? (kTyWord | (2u << 8)) : (kTyLit | (1u << 8)));
 }
 struct FastDecide {  // thread per position (measured: inside PathUpWave the four wavefronts of a chunk each pay for it, +20 us a step)
     FastArgs a;
@@ -1145,9 +1158,20 @@ struct PathUpWave {
             uint64_t nlw = 0, tyw = 0;
             if (x < clen) {
                 const uint32_t i0 = (cs - kPre) + x;  // (a multiple of 8: the ten answers the eight decisions look at)
+                // (five 8-byte loads without a branch each -- ev holds 512 entries more than the block, i0 is a multiple of 8 -- and the
+                // answers past the block end zeroed afterwards: ten guarded 4-byte loads were ten branches an iteration)
                 uint32_t e[10];
+                {
+                    const uint64_t* ew = reinterpret_cast<const uint64_t*>(a.ev + i0);
+                    uint64_t w5[5];
 #pragma unroll
-                for (uint32_t q = 0; q < 10; q++) e[q] = cs + x + q < a.len ? a.ev[i0 + q] : 0;
+                    for (uint32_t q = 0; q < 5; q++) w5[q] = ew[q];
+#pragma unroll
+                    for (uint32_t q = 0; q < 10; q++) {
+                        const uint32_t v = (uint32_t)(w5[q >> 1] >> (32 * (q & 1)));
+                        e[q] = cs + x + q < a.len ? v : 0;
+                    }
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < 8; q++) {
                     const uint32_t p = cs + x + q;

@@ -72,6 +72,51 @@ KERNEL(k_writelane_const_ind8, REP8("v_writelane_b32 %[v0], %[s2], 5\n\t"))
 KERNEL(k_writelane_m0_ind8, REP8("v_writelane_b32 %[v0], %[s2], m0\n\t"))
 KERNEL(k_smov_m0_8, REP8("s_mov_b32 m0, %[s1]\n\t"))
 
+
+// ---- round 6: what the lanes formulation of the chain is made of (orz_symrank.h)
+#define KERNEL_X(name, pre, body, post)                                                                     \
+    __global__ __launch_bounds__(64) void name(int* out) {                                                  \
+        __shared__ int lds[1024];                                                                           \
+        lds[threadIdx.x] = threadIdx.x;                                                                     \
+        __syncthreads();                                                                                    \
+        int v0 = threadIdx.x, v1 = threadIdx.x * 3, v2 = 7, v3 = 9;                                         \
+        int va = (int)(uintptr_t)lds + 2 * threadIdx.x;                                                     \
+        int s0 = 1, s1 = 2, s2 = 3, s3 = 5;                                                                 \
+        unsigned it = kIters;                                                                               \
+        asm volatile(pre "1:\n\t" body                                                                      \
+                     "s_sub_u32 %[it], %[it], 1\n\ts_cmp_lg_u32 %[it], 0\n\ts_cbranch_scc1 1b\n\t" post    \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                             \
+                     : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [v3] "+v"(v3), [s0] "+s"(s0), [s1] "+s"(s1), [s2] "+s"(s2), [s3] "+s"(s3), [it] "+s"(it) \
+                     : [va] "v"(va)                                                                         \
+                     : "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "memory");                   \
+        out[threadIdx.x] = v0 + v1 + v2 + v3 + s0 + s1 + s2 + s3 + lds[threadIdx.x];                        \
+    }
+#define EXEC32 "s_mov_b64 s[44:45], exec\n\ts_mov_b32 exec_hi, 0\n\t"
+#define EXEC16 "s_mov_b64 s[44:45], exec\n\ts_mov_b32 exec_hi, 0\n\ts_mov_b32 exec_lo, 0xffff\n\t"
+#define EXECBACK "s_mov_b64 exec, s[44:45]\n\t"
+KERNEL_X(k_valu8_full, "", REP8("v_add_u32 %[v0], %[v0], 1\n\t"), "")
+KERNEL_X(k_valu8_exec32, EXEC32, REP8("v_add_u32 %[v0], %[v0], 1\n\t"), EXECBACK)
+KERNEL_X(k_valu8_exec16, EXEC16, REP8("v_add_u32 %[v0], %[v0], 1\n\t"), EXECBACK)
+KERNEL_X(k_cmpvcc4_exec32, EXEC32, REP4("v_cmp_eq_u32_e32 vcc, %[s0], %[v1]\n\t"), EXECBACK)
+KERNEL_X(k_cndmask8, "", REP8("v_cndmask_b32_e32 %[v0], %[v0], %[v1], vcc\n\t"), "")
+KERNEL_X(k_cndmask8_e64, "", REP8("v_cndmask_b32_e64 %[v0], %[v0], %[v1], s[40:41]\n\t"), "")
+KERNEL_X(k_max3_8, "", REP8("v_max3_i32 %[v0], %[v0], %[v1], 0\n\t"), "")
+KERNEL_X(k_lshladd8, "", REP8("v_lshl_add_u32 %[v0], %[v1], 1, %[s1]\n\t"), "")
+KERNEL_X(k_vmov_s8, "", REP8("v_mov_b32 %[v0], %[s1]\n\t"), "")
+KERNEL_X(k_dswrite8, "", REP8("ds_write_b16 %[va], %[v1]\n\t"), "")
+KERNEL_X(k_dswrite8_off, "", REP4("ds_write_b16 %[va], %[v1] offset:128\n\tds_write_b16 %[va], %[v1] offset:256\n\t"), "")
+KERNEL_X(k_dsread8, "", REP8("ds_read_u16 %[v2], %[va]\n\t"), "")
+KERNEL_X(k_dsread_wait4, "", REP4("ds_read_u16 %[v2], %[va]\n\ts_waitcnt lgkmcnt(0)\n\t"), "")
+KERNEL_X(k_dswrite8_uniform, "v_mov_b32 %[v3], 64\n\t", REP8("ds_write_b16 %[v3], %[v1]\n\t"), "")
+KERNEL_X(k_dsread8_uniform, "v_mov_b32 %[v3], 64\n\t", REP8("ds_read_u16 %[v2], %[v3]\n\t"), "")
+KERNEL_X(k_waitcnt8, "", REP8("s_waitcnt lgkmcnt(1)\n\t"), "")
+KERNEL_X(k_mix_vs8, "", REP4("v_add_u32 %[v0], %[v0], 1\n\ts_add_u32 %[s0], %[s0], 1\n\tv_add_u32 %[v1], %[v1], 1\n\ts_add_u32 %[s1], %[s1], 1\n\t"), "")
+KERNEL_X(k_smax8, "", REP8("s_max_i32 %[s0], %[s0], %[s1]\n\t"), "")
+KERNEL_X(k_slshl1add8, "", REP8("s_lshl1_add_u32 %[s0], %[s0], %[s1]\n\t"), "")
+KERNEL_X(k_readlane_vmov4, "", REP4("v_readlane_b32 s42, %[v0], 6\n\ts_nop 1\n\tv_mov_b32 %[v1], s42\n\t"), "")
+KERNEL_X(k_bpermute4, "", REP4("ds_bpermute_b32 %[v2], %[v3], %[v0]\n\ts_waitcnt lgkmcnt(0)\n\t"), "")
+KERNEL_X(k_dpp_bcast4, "", REP4("v_mov_b32_dpp %[v2], %[v0] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"), "")
+
 struct Test { const char* name; void (*fn)(int*); int n; };
 
 int main(int argc, char** argv) {
@@ -98,6 +143,14 @@ int main(int argc, char** argv) {
         {"8 untaken s_cbranch_scc1", k_untaken_x8, 8}, {"8 v_readlane, lane select in an SGPR", k_readlane_sgprsel_ind8, 8},
         {"8 v_readfirstlane", k_readfirstlane_ind8, 8}, {"8 v_writelane, constant lane", k_writelane_const_ind8, 8},
         {"8 v_writelane, lane in M0", k_writelane_m0_ind8, 8}, {"8 s_mov m0", k_smov_m0_8, 8},
+        {"8 v_add (kernel with LDS)", k_valu8_full, 8}, {"8 v_add, 32 lanes in EXEC", k_valu8_exec32, 8}, {"8 v_add, 16 lanes in EXEC", k_valu8_exec16, 8},
+        {"4 v_cmp to VCC, 32 lanes in EXEC", k_cmpvcc4_exec32, 4}, {"8 v_cndmask by VCC", k_cndmask8, 8}, {"8 v_cndmask by an SGPR pair", k_cndmask8_e64, 8},
+        {"8 v_max3_i32", k_max3_8, 8}, {"8 v_lshl_add_u32 with an SGPR", k_lshladd8, 8}, {"8 v_mov from an SGPR", k_vmov_s8, 8},
+        {"8 ds_write_b16 (lane addresses)", k_dswrite8, 8}, {"8 ds_write_b16 with offsets", k_dswrite8_off, 8}, {"8 ds_read_u16", k_dsread8, 8},
+        {"4 x (ds_read_u16, wait)", k_dsread_wait4, 8}, {"8 ds_write_b16, one address", k_dswrite8_uniform, 8}, {"8 ds_read_u16, one address", k_dsread8_uniform, 8},
+        {"8 s_waitcnt lgkmcnt(1), nothing pending", k_waitcnt8, 8}, {"4 x (v_add, s_add, v_add, s_add)", k_mix_vs8, 16},
+        {"8 s_max_i32", k_smax8, 8}, {"8 s_lshl1_add_u32", k_slshl1add8, 8}, {"4 x (v_readlane, s_nop 1, v_mov from it)", k_readlane_vmov4, 12},
+        {"4 x (ds_bpermute, wait)", k_bpermute4, 8}, {"4 v_mov_dpp row_bcast", k_dpp_bcast4, 4},
     };
     double base = 0;
     for (const Test& t : tests) {
