@@ -80,6 +80,33 @@ constexpr uint32_t kSrLdsBytes = kSrSnapOff + kSrGroup * 128;
     "v_cndmask_b32_e32 %[x], %[x], %[vi], vcc\n\t" /* ni1 -> i (after the first: a swap has ni1 == next_i) */            \
     "v_lshl_add_u32 %[aw], %[rw], 1, %[base]\n\t"                                                                        \
     "v_cndmask_b32_e64 %[x], %[x], %[nx], %[m1]\n\t" /* i -> next_i */
+// The same item without the scalar chain: a group run on the assumption that the quotient stays what it is (it moves once
+// in ~2,000 items of the text workload's hottest context) and checked afterwards from the group's 32 ranks -- see the kernel.
+#define ORZ_SRL_WBS_1 "s_waitcnt lgkmcnt(1)\n\tds_write_b16 %[aw], %[n]\n\t"
+#define ORZ_SRL_WBS_0 "s_nop 1\n\t"
+#define ORZ_SRL_ITEM_S(J2, SNAP, PREV)                                                                                   \
+    "ds_write_b16 %[l2], %[x] offset:" SNAP "\n\t"                                                                       \
+    "v_readlane_b32 %[si], %[x], " J2 "\n\t"                                                                             \
+    ORZ_SRL_WBS_##PREV                                                                                                   \
+    "v_mov_b32 %[vi], %[si]\n\t"                                                                                         \
+    "v_lshrrev_b32 %[t], 4, %[vi]\n\t"                                                                                   \
+    "v_lshrrev_b32 %[h], 1, %[vi]\n\t"                                                                                   \
+    "v_sub_u32 %[t], %[vi], %[t]\n\t"                                                                                    \
+    "v_cmp_eq_u32_e64 %[m1], %[x], %[vi]\n\t"                                                                            \
+    "v_sub_u32_e64 %[t], %[t], %[q]\n\t"                                                                                 \
+    "v_max3_i32 %[nx], %[t], %[h], 0\n\t"                                                                                \
+    "v_add_u32 %[y], %[vi], %[nx]\n\t"                                                                                   \
+    "v_cmp_eq_u32_e64 %[m3], %[x], %[nx]\n\t"                                                                            \
+    "v_lshrrev_b32 %[y], 1, %[y]\n\t"                                                                                    \
+    "v_cndmask_b32_e64 %[rr], %[nx], %[y], %[m01]\n\t"                                                                   \
+    "v_cmp_eq_u32_e32 vcc, %[x], %[y]\n\t"                                                                               \
+    "v_cndmask_b32_e64 %[rw], %[y], %[vi], %[m01]\n\t"                                                                   \
+    "v_lshl_add_u32 %[ar], %[rr], 1, %[base]\n\t"                                                                        \
+    "v_cndmask_b32_e64 %[x], %[x], %[y], %[m3]\n\t"                                                                      \
+    "ds_read_u16 %[n], %[ar]\n\t"                                                                                        \
+    "v_cndmask_b32_e32 %[x], %[x], %[vi], vcc\n\t"                                                                       \
+    "v_lshl_add_u32 %[aw], %[rw], 1, %[base]\n\t"                                                                        \
+    "v_cndmask_b32_e64 %[x], %[x], %[nx], %[m1]\n\t"
 // The rare paths of one item, placed behind the group's straight line
 #define ORZ_SRL_SIDE(P)                                                                                                  \
     P "30:\n\t" /* count and sum scale by 9/10; qa follows */                                                            \
@@ -180,6 +207,40 @@ constexpr uint32_t kSrLdsBytes = kSrSnapOff + kSrGroup * 128;
     ORZ_SRL_SIDE("131") \
     "9:\n\t"
 
+#define ORZ_SRL_GROUP_S \
+    ORZ_SRL_ITEM_S("0", "0", 0) \
+    ORZ_SRL_ITEM_S("2", "128", 1) \
+    ORZ_SRL_ITEM_S("4", "256", 1) \
+    ORZ_SRL_ITEM_S("6", "384", 1) \
+    ORZ_SRL_ITEM_S("8", "512", 1) \
+    ORZ_SRL_ITEM_S("10", "640", 1) \
+    ORZ_SRL_ITEM_S("12", "768", 1) \
+    ORZ_SRL_ITEM_S("14", "896", 1) \
+    ORZ_SRL_ITEM_S("16", "1024", 1) \
+    ORZ_SRL_ITEM_S("18", "1152", 1) \
+    ORZ_SRL_ITEM_S("20", "1280", 1) \
+    ORZ_SRL_ITEM_S("22", "1408", 1) \
+    ORZ_SRL_ITEM_S("24", "1536", 1) \
+    ORZ_SRL_ITEM_S("26", "1664", 1) \
+    ORZ_SRL_ITEM_S("28", "1792", 1) \
+    ORZ_SRL_ITEM_S("30", "1920", 1) \
+    ORZ_SRL_ITEM_S("32", "2048", 1) \
+    ORZ_SRL_ITEM_S("34", "2176", 1) \
+    ORZ_SRL_ITEM_S("36", "2304", 1) \
+    ORZ_SRL_ITEM_S("38", "2432", 1) \
+    ORZ_SRL_ITEM_S("40", "2560", 1) \
+    ORZ_SRL_ITEM_S("42", "2688", 1) \
+    ORZ_SRL_ITEM_S("44", "2816", 1) \
+    ORZ_SRL_ITEM_S("46", "2944", 1) \
+    ORZ_SRL_ITEM_S("48", "3072", 1) \
+    ORZ_SRL_ITEM_S("50", "3200", 1) \
+    ORZ_SRL_ITEM_S("52", "3328", 1) \
+    ORZ_SRL_ITEM_S("54", "3456", 1) \
+    ORZ_SRL_ITEM_S("56", "3584", 1) \
+    ORZ_SRL_ITEM_S("58", "3712", 1) \
+    ORZ_SRL_ITEM_S("60", "3840", 1) \
+    ORZ_SRL_ITEM_S("62", "3968", 1)
+
 // `state_in` / `only_if`: the guarded second run of a block (HipBackend::symrank) -- it starts from the saved tables and
 // does nothing unless the check of the first run's ranks raised *only_if.
 __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, const uint32_t* gsym, uint16_t* grank,
@@ -228,45 +289,85 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
         if (cnt >= 192 && e - j >= kSrGroup) {
             // ---- groups of 32 items while there are 32
             uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)((sum >> 4) / cnt));
-            uint32_t qw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cnt << 4)), qc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q << 4));
-            uint32_t qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sum - q * qw));
             uint32_t pairs = load_pairs(j);
-            uint32_t two = 0;  // the ranks of the group before: read after it, used behind the next group's LDS reads
-            bool have = false;
             do {
-                uint32_t s[7];
+                uint32_t s[7];  // value[] as the group finds it: index[] is rebuilt from it, and a failed speculation restores it
 #pragma unroll
                 for (uint32_t m = 0; m < 7; m++) s[m] = val[lane + 64 * m];
-                if (have && lane < kSrGroup) grank[j - kSrGroup + lane] = out_rank(two & 0xffff, two >> 16);
 #pragma unroll
                 for (uint32_t m = 0; m < 7; m++) at(s[m]) = (uint16_t)(lane + 64 * m);
                 const uint32_t symslot = slot_of((lane & 1) ? pairs >> 16 : pairs & 0xffff);
-                int x = (int)at(symslot);
+                const int x0 = (int)at(symslot);
                 pairs = load_pairs(j + kSrGroup);  // in flight while this group runs
                 q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-                qw = (uint32_t)__builtin_amdgcn_readfirstlane((int)qw);
-                qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)qa);
-                qc = (uint32_t)__builtin_amdgcn_readfirstlane((int)qc);
-                uint32_t si, s0, s1;
+                uint32_t si;
                 uint64_t m1, m3;
-                int vi, t, h, nx, y, rr, rw, ar, aw, n;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                             ORZ_SRL_GROUP
-                             // the last item's displaced values; then every tracked symbol to where it ended up
-                             "s_waitcnt lgkmcnt(0)\n\tds_write_b16 %[aw], %[n]\n\t"
-                             "v_lshl_add_u32 %[ar], %[x], 1, %[base]\n\tds_write_b16 %[ar], %[sym]\n\t"
-                             : [x] "+v"(x), [qw] "+s"(qw), [qa] "+s"(qa), [qc] "+s"(qc), [q] "+s"(q), [si] "=&s"(si), [s0] "=&s"(s0),
-                               [s1] "=&s"(s1), [m1] "=&s"(m1), [m3] "=&s"(m3), [vi] "=&v"(vi), [t] "=&v"(t), [h] "=&v"(h), [nx] "=&v"(nx),
-                               [y] "=&v"(y), [rr] "=&v"(rr), [rw] "=&v"(rw), [ar] "=&v"(ar), [aw] "=&v"(aw), [n] "=&v"(n)
-                             : [l2] "v"(l2), [base] "s"(base), [sym] "v"(symslot), [m01] "s"(m01)
-                             : "scc", "vcc", "memory");
-                two = *snap_pair;
-                have = true;
+                int x, vi, t, h, nx, y, rr, rw, ar, aw, n;
+                // In the steady state (count 352..390, a small quotient) the group runs WITHOUT the scalar chain, on the
+                // assumption that the quotient stays q through its 32 items -- across the one scaling by 9/10 that may fall
+                // into it, whose place is known from the count (src/symrank.rs:63-66) -- and the assumption is checked
+                // afterwards, in every lane for one item: count and sum after each item follow from the 32 ranks by a prefix
+                // sum.  Where it fails (once in ~60 groups on text) value[] is put back and the group runs again, checked.
+                bool done = false;
+                if (cnt >= 327 && q < 32) {
+                    x = x0;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                                 ORZ_SRL_GROUP_S
+                                 "s_waitcnt lgkmcnt(0)\n\tds_write_b16 %[aw], %[n]\n\t"
+                                 "v_lshl_add_u32 %[ar], %[x], 1, %[base]\n\tds_write_b16 %[ar], %[sym]\n\t"
+                                 : [x] "+v"(x), [si] "=&s"(si), [m1] "=&s"(m1), [m3] "=&s"(m3), [vi] "=&v"(vi), [t] "=&v"(t), [h] "=&v"(h),
+                                   [nx] "=&v"(nx), [y] "=&v"(y), [rr] "=&v"(rr), [rw] "=&v"(rw), [ar] "=&v"(ar), [aw] "=&v"(aw), [n] "=&v"(n)
+                                 : [l2] "v"(l2), [base] "s"(base), [sym] "v"(symslot), [m01] "s"(m01), [q] "s"(q)
+                                 : "vcc", "memory");
+                    const uint32_t two = *snap_pair;
+                    // inclusive prefix sum of the items' ranks over lanes 0..31 (two rows of sixteen)
+                    uint32_t ps = lane < kSrGroup ? two & 0xffff : 0;
+                    ps += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ps, 0x111, 0xf, 0xf, true);  // row_shr:1
+                    ps += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ps, 0x112, 0xf, 0xf, true);  // row_shr:2
+                    ps += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ps, 0x114, 0xf, 0xf, true);  // row_shr:4
+                    ps += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ps, 0x118, 0xf, 0xf, true);  // row_shr:8
+                    ps += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ps, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1 and 3
+                    const uint32_t r = kSyms + 1 - cnt;  // the item that starts with count 390 scales first (none: r >= 32)
+                    const uint32_t pr = r > 0 && r < kSrGroup ? (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)((r - 1) & 31)) : 0u;
+                    const uint32_t scaled = (sum + pr) * 9 / 10;
+                    const bool after = lane >= r;
+                    const uint32_t cnt_k = after ? (kSyms + 1) * 9 / 10 + (lane - r) + 1 : cnt + lane + 1;
+                    const uint32_t sum_k = after ? scaled + (ps - pr) : sum + ps;
+                    const uint32_t lo = (q << 4) * cnt_k;
+                    const bool ok = sum_k >= lo && sum_k - lo < (cnt_k << 4);
+                    if (__ballot(lane < kSrGroup && !ok) == 0) {
+                        if (lane < kSrGroup) grank[j + lane] = out_rank(two & 0xffff, two >> 16);
+                        cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_k, 31);
+                        sum = (uint32_t)__builtin_amdgcn_readlane((int)sum_k, 31);
+                        done = true;
+                    } else {
+#pragma unroll
+                        for (uint32_t m = 0; m < 7; m++) val[lane + 64 * m] = (uint16_t)s[m];
+                    }
+                }
+                if (!done) {
+                    uint32_t s0, s1;
+                    uint32_t qw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cnt << 4));
+                    uint32_t qc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q << 4));
+                    uint32_t qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sum - q * qw));
+                    x = x0;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                                 ORZ_SRL_GROUP
+                                 // the last item's displaced values; then every tracked symbol to where it ended up
+                                 "s_waitcnt lgkmcnt(0)\n\tds_write_b16 %[aw], %[n]\n\t"
+                                 "v_lshl_add_u32 %[ar], %[x], 1, %[base]\n\tds_write_b16 %[ar], %[sym]\n\t"
+                                 : [x] "+v"(x), [qw] "+s"(qw), [qa] "+s"(qa), [qc] "+s"(qc), [q] "+s"(q), [si] "=&s"(si), [s0] "=&s"(s0),
+                                   [s1] "=&s"(s1), [m1] "=&s"(m1), [m3] "=&s"(m3), [vi] "=&v"(vi), [t] "=&v"(t), [h] "=&v"(h), [nx] "=&v"(nx),
+                                   [y] "=&v"(y), [rr] "=&v"(rr), [rw] "=&v"(rw), [ar] "=&v"(ar), [aw] "=&v"(aw), [n] "=&v"(n)
+                                 : [l2] "v"(l2), [base] "s"(base), [sym] "v"(symslot), [m01] "s"(m01)
+                                 : "scc", "vcc", "memory");
+                    cnt = qw >> 4;
+                    sum = qa + q * qw;
+                    const uint32_t two = *snap_pair;
+                    if (lane < kSrGroup) grank[j + lane] = out_rank(two & 0xffff, two >> 16);
+                }
                 j += kSrGroup;
             } while (e - j >= kSrGroup);
-            if (lane < kSrGroup) grank[j - kSrGroup + lane] = out_rank(two & 0xffff, two >> 16);
-            cnt = qw >> 4;
-            sum = qa + q * qw;
             idx_ok = false;
             continue;
         }
