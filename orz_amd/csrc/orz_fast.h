@@ -1149,7 +1149,20 @@ struct PathUpWave {
         uint8_t* x0L = nlL + 64 * 68 + 32;
         const uint32_t c = c0 + w.block() / 4, part = w.block() & 3, lane = w.lane();  // four wavefronts per chunk: 60 entries each
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
-        for (uint32_t k = 0; k < 8; k++) {  // 512 words of 8 positions, 8 per lane
+        // (512 words of 8 positions, 8 per lane.  Round 6: the lane's forty loads of ev go out together -- a chunk's wavefront has
+        // its SIMD to itself, nothing else hides a load's latency, and eight trips of load-then-decide were eight round trips.)
+        uint64_t w5[8][5];
+        if (decide) {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t x = (k * 64 + lane) * 8;
+                const uint64_t* ew = reinterpret_cast<const uint64_t*>(a.ev + (cs - kPre) + (x < clen ? x : 0));
+#pragma unroll
+                for (uint32_t q = 0; q < 5; q++) w5[k][q] = ew[q];
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
             const uint32_t x = (k * 64 + lane) * 8;
             if (!decide) {
                 st8_pad68(nlL, x, x < clen ? *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x) : 0);
@@ -1157,20 +1170,12 @@ struct PathUpWave {
             }
             uint64_t nlw = 0, tyw = 0;
             if (x < clen) {
-                const uint32_t i0 = (cs - kPre) + x;  // (a multiple of 8: the ten answers the eight decisions look at)
-                // (five 8-byte loads without a branch each -- ev holds 512 entries more than the block, i0 is a multiple of 8 -- and the
-                // answers past the block end zeroed afterwards: ten guarded 4-byte loads were ten branches an iteration)
-                uint32_t e[10];
-                {
-                    const uint64_t* ew = reinterpret_cast<const uint64_t*>(a.ev + i0);
-                    uint64_t w5[5];
+                const uint32_t i0 = (cs - kPre) + x;  // (a multiple of 8: the ten answers the eight decisions look at; ev holds 512
+                uint32_t e[10];                       // entries more than the block, the answers past the block end are zeroed here)
 #pragma unroll
-                    for (uint32_t q = 0; q < 5; q++) w5[q] = ew[q];
-#pragma unroll
-                    for (uint32_t q = 0; q < 10; q++) {
-                        const uint32_t v = (uint32_t)(w5[q >> 1] >> (32 * (q & 1)));
-                        e[q] = cs + x + q < a.len ? v : 0;
-                    }
+                for (uint32_t q = 0; q < 10; q++) {
+                    const uint32_t v = (uint32_t)(w5[k][q >> 1] >> (32 * (q & 1)));
+                    e[q] = cs + x + q < a.len ? v : 0;
                 }
 #pragma unroll
                 for (uint32_t q = 0; q < 8; q++) {
@@ -1248,16 +1253,25 @@ struct PathMarkWave {  // one wavefront per chunk, lane = segment; also the chun
         const uint32_t c = c0 + w.block(), lane = w.lane();
         const uint32_t cs = kPre + c * kSub, clen = chunk_end(c, a.len) - cs;
         for (uint32_t k = lane; k < 256; k += 64) cnt[k] = 0;
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t x = (k * 64 + lane) * 8;
-            uint64_t v = 0, u = 0, t = 0;
-            if (x < clen) {
-                v = *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x);
-                u = *reinterpret_cast<const uint64_t*>(a.x0 + (cs - kPre) + x);
-                t = *reinterpret_cast<const uint64_t*>(a.ty + (cs - kPre) + x);
+        {   // (the lane's 32 loads in flight together, then the stores: see PathUpWave)
+            uint64_t v[8], u[8], t[8], b[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t x = (k * 64 + lane) * 8;
+                v[k] = u[k] = t[k] = 0;
+                if (x < clen) {
+                    v[k] = *reinterpret_cast<const uint64_t*>(a.nl + (cs - kPre) + x);
+                    u[k] = *reinterpret_cast<const uint64_t*>(a.x0 + (cs - kPre) + x);
+                    t[k] = *reinterpret_cast<const uint64_t*>(a.ty + (cs - kPre) + x);
+                }
+                b[k] = ldu64(a.win + cs - 2 + x);
             }
-            st8_pad68(nlL, x, v); st8_pad68(x0L, x, u); st8_pad68(tyL, x, t);
-            st8_pad68(wL, x, ldu64(a.win + cs - 2 + x));  // wL[pad68(y)] = win[cs - 2 + y]
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t x = (k * 64 + lane) * 8;
+                st8_pad68(nlL, x, v[k]); st8_pad68(x0L, x, u[k]); st8_pad68(tyL, x, t[k]);
+                st8_pad68(wL, x, b[k]);  // wL[pad68(y)] = win[cs - 2 + y]
+            }
         }
         if (lane == 0) st8_pad68(wL, kSub, ldu64(a.win + cs - 2 + kSub));
         w.sync();

@@ -89,11 +89,10 @@ constexpr uint32_t kSrLdsBytes = kSrSnapOff + kSrGroup * 128;
     "v_readlane_b32 %[si], %[x], " J2 "\n\t"                                                                             \
     ORZ_SRL_WBS_##PREV                                                                                                   \
     "v_mov_b32 %[vi], %[si]\n\t"                                                                                         \
-    "v_lshrrev_b32 %[t], 4, %[vi]\n\t"                                                                                   \
+    "v_mad_i32_i24 %[t], %[vi], 15, %[c15]\n\t" /* i - i/16 - q = (15 i + 15 - 16 q) >> 4 (arithmetic): q is the group's */ \
     "v_lshrrev_b32 %[h], 1, %[vi]\n\t"                                                                                   \
-    "v_sub_u32 %[t], %[vi], %[t]\n\t"                                                                                    \
     "v_cmp_eq_u32_e64 %[m1], %[x], %[vi]\n\t"                                                                            \
-    "v_sub_u32_e64 %[t], %[t], %[q]\n\t"                                                                                 \
+    "v_ashrrev_i32 %[t], 4, %[t]\n\t"                                                                                    \
     "v_max3_i32 %[nx], %[t], %[h], 0\n\t"                                                                                \
     "v_add_u32 %[y], %[vi], %[nx]\n\t"                                                                                   \
     "v_cmp_eq_u32_e64 %[m3], %[x], %[nx]\n\t"                                                                            \
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(64) void orz_symrank_kernel(uint16_t* srstate, cons
                                  "v_lshl_add_u32 %[ar], %[x], 1, %[base]\n\tds_write_b16 %[ar], %[sym]\n\t"
                                  : [x] "+v"(x), [si] "=&s"(si), [m1] "=&s"(m1), [m3] "=&s"(m3), [vi] "=&v"(vi), [t] "=&v"(t), [h] "=&v"(h),
                                    [nx] "=&v"(nx), [y] "=&v"(y), [rr] "=&v"(rr), [rw] "=&v"(rw), [ar] "=&v"(ar), [aw] "=&v"(aw), [n] "=&v"(n)
-                                 : [l2] "v"(l2), [base] "s"(base), [sym] "v"(symslot), [m01] "s"(m01), [q] "s"(q)
+                                 : [l2] "v"(l2), [base] "s"(base), [sym] "v"(symslot), [m01] "s"(m01), [c15] "s"(15 - (int)(q << 4))
                                  : "vcc", "memory");
                     const uint32_t two = *snap_pair;
                     // inclusive prefix sum of the items' ranks over lanes 0..31 (two rows of sixteen)
