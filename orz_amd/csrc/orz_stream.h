@@ -954,13 +954,14 @@ class StreamEncoder {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
-            if (n >= cur_unit_) T = ftile_;  // (a full unit is not a short input)
+            if (n >= cur_unit_ / 2) T = ftile_;  // (a full unit is not a short input -- nor is the better part of one: the last block of
+                                                 // the 100 MB workload, 16.1 of 16.8 MB, ran 131 steps of 126 K tiles until round 6)
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it can take larger tiles (ORZ_FAST_LEADMUL) -- half the steps at 2, +0.1 % on that block's
             // output for text but +1 % for zeros with noise, and 2 ms of 330 per 100 MB: off.
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 1;
             if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
-            if (sched_auto_ && settled_next_ && n >= cur_unit_ && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
+            if (sched_auto_ && settled_next_ && n >= cur_unit_ / 2 && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
         }
         for (int attempt = 0;; attempt++) {
             a.tile = T;
