@@ -480,7 +480,9 @@ def main():
             "repairs_per_step": agg["seg_evals"] // args.steps if cfg["mode"] == 1 else None,
             # times the host waited for a stream, per 16 MiB block (orz_encode_stats.host_syncs: one for the block's control block +
             # item count, two when its output is collected two blocks later -- sizes, then bytes --, the closing waits of the call)
-            "host_syncs_per_block": round(agg["host_syncs"] / max(1, agg["blocks"]), 2),
+            "host_syncs_per_block": round(agg["host_syncs"] / max(1, args.steps * -(-len(data) // (1 << 24))), 2),
+            # (a stream of its own parses a block as units -- config.encoder.unit_bytes, orz_stream.h -- and the wait is the unit's)
+            "host_syncs_per_unit": round(agg["host_syncs"] / max(1, args.steps * -(-len(data) // max(1, cfg.get("unit_bytes") or (1 << 24)))), 2),
             "roofline": roofs[0] if roofs else None,
             "roofline_others": roofs[1:],
             # every kernel of one profiled pass over the workload (HIP events around each launch, on the stream it runs on; no graph

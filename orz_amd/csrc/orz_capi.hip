@@ -101,6 +101,7 @@ struct orz_stream {
     bool tracing = false;
     bool fast = false;
     unsigned ftile = orz::kFastTile, frounds = orz::kFastRounds;
+    unsigned unit = 0;  // fast mode: bytes per unit of a block; 0 = the encoder's default (a stream that has the GPU to itself)
     double kernel_ms[4] = {0, 0, 0, 0};
     uint64_t kernel_n[4] = {0, 0, 0, 0};
     std::vector<orz::KernelRow> ktable;  // profile mode: every kernel of the last encode by name (orz_stream_get_kernel_table)
@@ -121,6 +122,7 @@ struct orz_stream {
             be->clear_graphs();
             fresh.reset(new Enc(*be, to_cfg(&cfg), seg, fast ? 64 : window_for(*be, cfg, win), fast, ftile, frounds));
         }
+        if (fast && unit && !getenv("ORZ_FAST_UNIT")) fresh->set_unit(unit);
         be->clear_graphs();  // (captured launches hold the old encoder's buffer addresses)
         enc = std::move(fresh);
         enc->trace = tracing ? &trace : nullptr;
@@ -196,6 +198,7 @@ static orz_stream* stream_new(int device, const orz_lzcfg* cfg, bool lone) {
         s->ftile = env_u("ORZ_FAST_TILE", orz::kFastTile);
         s->frounds = env_u("ORZ_FAST_ROUNDS", orz::kFastRounds);
         s->be->set_graphs(env_u("ORZ_GRAPHS", 1) != 0);
+        if (!lone) s->unit = orz::kNewMax;  // one of several encoders on the device: whole blocks (orz_stream.h, unit_)
         s->rebuild();
         return s.release();
     } catch (const std::exception& e) {

@@ -961,6 +961,8 @@ class StreamEncoder {
             // output for text but +1 % for zeros with noise, and 2 ms of 330 per 100 MB: off.
             static const uint32_t lead_mul = getenv("ORZ_FAST_LEADMUL") ? (uint32_t)atoi(getenv("ORZ_FAST_LEADMUL")) : 1;
             if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
+            // (only whole blocks hand their statistics on: 8 MiB units under the settled schedule measured the same 193 ms per
+            // 100 MB as under the default and 0.13 % more output -- half as many tiles leave the third round half as much to do)
             if (sched_auto_ && settled_next_ && n >= cur_unit_ / 2 && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
         }
         for (int attempt = 0;; attempt++) {
@@ -1645,6 +1647,10 @@ class StreamEncoder {
         unit_base_ = 0;
         cur_unit_ = fast_ ? unit_ : kNewMax;
     }
+    void set_unit(uint32_t bytes) {  // between streams only
+        if (bytes < (1u << 20) || bytes > kNewMax || bytes % kSub) throw std::runtime_error("the unit must be a multiple of 4096 in [1 MiB, 16 MiB]");
+        unit_ = cur_unit_ = bytes;
+    }
     void set_lead_unit(uint32_t bytes) { lead_unit_ = bytes; }  // 0 = the lead block is encoded like the others
     uint32_t lead_unit() const { return lead_unit_; }
 
@@ -1769,10 +1775,16 @@ class StreamEncoder {
     uint32_t last_n_ = kNewMax;  // size of the unit encoded last (what slide() slides by)
     uint32_t hist_hint_ = ~0u;   // history item starts of the next block as the host computes them (~0 = ask the device)
     uint32_t unit_base_ = 0;     // bytes of the current block encoded by earlier units (chunk headers carry decoder positions)
-    // fast mode: bytes per unit of a block (ORZ_FAST_UNIT; a multiple of 4096).  Measured on the 100 MB workload: 8 MiB units
-    // fill the pipeline 18 ms sooner but cost 28 ms of parse (the history is sorted once per unit, the round pipeline and
-    // the repair passes start once per unit): 353 vs 350 ms, 4 MiB units 377 ms -- so a unit is the whole block by default.
-    uint32_t unit_ = kNewMax;
+    // fast mode: bytes per unit of a block (ORZ_FAST_UNIT, set_unit; a multiple of 4096).  A stream of its own is a pipeline of
+    // two stages -- the parse of unit k+1 beside the symbol ranking of unit k -- whose fill and drain are a unit's parse and a
+    // unit's ranking.  While the ranking took 50 ms a block, units did not pay (round 4, the 100 MB workload: 8 MiB units filled
+    // the pipeline 18 ms sooner but cost 28 ms of parse -- the history is sorted once per unit, the round pipeline and the repair
+    // passes start once per unit --: 353 vs 350 ms).  With the ranking at 29 ms a block (round 6) they do: 16 / 10 / 8 / 6 / 4 MiB
+    // units 202 / 197 / 193 / 204 / 219 ms per 100 MB, the stream 0.06 % smaller at 8 MiB.  Eight encoders on one GPU have no
+    // pipeline to fill -- the GPU is busy with the others -- and pay the per-unit work: 733..770 MB/s with whole blocks, 662 with
+    // 8 MiB units.  So: 8 MiB for an encoder that has the GPU to itself, the whole block for the encoders of a members job
+    // (orz_capi.hip decides; the size is part of what makes a stream's bytes, so it never depends on what else is running).
+    uint32_t unit_ = kNewMax / 2;
     uint32_t cur_unit_ = kNewMax;  // unit size in effect for the block being encoded
     uint32_t lead_unit_ = 0;       // unit size of a stream's lead block (0 = off)
     std::vector<int> pend_order_;  // sets whose output is still on the device, oldest first

@@ -4,8 +4,12 @@ product's kernels (tests/emu, fast mode, -l1) on the CPU -- about four minutes p
     python tests/golden/make_emu_soak.py <round> <member> [<member> ...]   -> merges into tests/golden/emu_soak.json
     python tests/golden/make_emu_soak.py <round> <member> --mib N          -> the member's first N MiB only ("..., first N MiB")
 The emulation runs a launch's threads one after another; the GPU tests demand that eight concurrent GPU encoders, fresh and
-reused, write these very bytes (tests/test_gpu_soak.py)."""
+reused, write these very bytes (tests/test_gpu_soak.py).
+The eight encoders of a members job take whole 16 MiB blocks as units; an encoder that has the GPU to itself -- the emulation's
+default too -- takes 8 MiB (orz_stream.h, unit_): the goldens are the members job's, hence the ORZ_FAST_UNIT below."""
 import ctypes, hashlib, json, os, subprocess, sys, time
+
+os.environ["ORZ_FAST_UNIT"] = str(1 << 24)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tools", "dev")); sys.path.insert(0, os.path.join(ROOT, "tests"))
