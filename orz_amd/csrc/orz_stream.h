@@ -954,8 +954,10 @@ class StreamEncoder {
             static const uint32_t tdiv = getenv("ORZ_FAST_TDIV") ? (uint32_t)atoi(getenv("ORZ_FAST_TDIV")) : 128;  // aim at this many tiles per block
             const uint32_t want = ((n / tdiv + kSub - 1) / kSub) * kSub;
             T = std::max<uint32_t>(kSub, std::min<uint32_t>(ftile_, want));
-            if (n >= cur_unit_ / 2) T = ftile_;  // (a full unit is not a short input -- nor is the better part of one: the last block of
-                                                 // the 100 MB workload, 16.1 of 16.8 MB, ran 131 steps of 126 K tiles until round 6)
+            // (a full unit is not a short input -- nor is the better part of one behind other blocks: the last block of the 100 MB
+            // workload, 16.1 of 16.8 MB, ran 131 steps of 126 K tiles until round 6.  A stream's first block keeps the rule it had.)
+            const bool big_part = !stream_start_ && n >= cur_unit_ / 2;
+            if (n >= cur_unit_ || big_part) T = ftile_;
             // The first block of a longer stream has nothing to overlap with (later blocks parse while the previous block's
             // symbols are ranked): it can take larger tiles (ORZ_FAST_LEADMUL) -- half the steps at 2, +0.1 % on that block's
             // output for text but +1 % for zeros with noise, and 2 ms of 330 per 100 MB: off.
@@ -963,7 +965,7 @@ class StreamEncoder {
             if (lead_block_ && T == ftile_ && lead_mul >= 1 && lead_mul <= 8) T = (uint32_t)std::min<uint64_t>((uint64_t)lead_mul * ftile_, kNewMax);
             // (only whole blocks hand their statistics on: 8 MiB units under the settled schedule measured the same 193 ms per
             // 100 MB as under the default and 0.13 % more output -- half as many tiles leave the third round half as much to do)
-            if (sched_auto_ && settled_next_ && n >= cur_unit_ / 2 && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
+            if (sched_auto_ && settled_next_ && (n >= cur_unit_ || big_part) && T == ftile_) { T = sched_tile_; R = sched_rounds_; settled = true; }
         }
         for (int attempt = 0;; attempt++) {
             a.tile = T;
@@ -1275,7 +1277,9 @@ class StreamEncoder {
                 be_.d2h(two, tailkey_ + 3, 8);
             }
             nitems = two[0];
-            hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by)
+            hist_hint_ = n == kNewMax && nitems >= 1 ? nitems - 1 - two[1] : ~0u;  // (valid for a slide by the whole block: slide_by.
+            // Tried in round 6 for the 8 MiB units too -- the unit's items plus the unit's before it, less the two positions that
+            // leave: the arithmetic holds (ORZ_CHECK_HINTS) but the stream came out 1 % slower: the read-back paces the host)
         }
         if (nitems > t.cap) grow_tail_set(t, nitems);  // (the set is idle: its last block was collected above)
         be_.launch(n, CompactPos32{f32_, sc32_, n, kPre, t.ipos});
