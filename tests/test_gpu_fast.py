@@ -244,6 +244,41 @@ def test_units_of_a_block_decode_with_the_reference_loop(oracle, monkeypatch):
     assert abs(len(out) - len(whole)) <= 0.002 * len(whole)
 
 
+def test_the_unit_follows_how_the_encoder_was_made(oracle):
+    """round 6: an encoder that has the device to itself parses a block as two 8 MiB units (the ranking of one beside the parse
+    of the next), the encoders of a members job take whole blocks -- decided by how the encoder was made (orz_capi.hip,
+    stream_new), never by what else is running: a one-job members encoder writes the lone stream's bytes, two jobs write the
+    whole-block stream (another parse of the same input, same size band), and every one of them decodes"""
+    import corpus
+    import orz_amd
+    from orz_amd import dist as od
+
+    data = corpus.enwik_like(20_000_000)
+    enc = orz_amd.StreamEncoder(device=0, level=1, mode="fast")
+    try:
+        assert enc.config()["unit_bytes"] == 1 << 23
+        lone = enc.encode(data)
+    finally:
+        enc.close()
+    outs = {}
+    for jobs in (1, 2):
+        m = orz_amd.MemberEncoder(device=0, level=1, jobs=jobs)
+        try:
+            blob, nm = m.encode(data * jobs, member_bytes=len(data))
+        finally:
+            m.close()
+        pieces = od.split_members(blob)
+        assert nm == jobs == len(pieces) and len(set(pieces)) == 1
+        outs[jobs] = pieces[0]
+    assert outs[1] == lone
+    assert outs[2] != lone
+    ref = len(oracle.encode(data, 1))
+    for out in (lone, outs[2]):
+        back, used = oracle.decode(out)
+        assert used == len(out) and back == data
+        assert abs(len(out) - ref) <= 0.005 * ref
+
+
 def test_members_on_two_devices(oracle):
     """orz_members_new_multi with two HIP devices (one host thread per encoder, hipSetDevice per thread): the members come
     back in order whichever device encoded them and decode with the oracle.  Skipped on a one-GPU box."""
