@@ -48,8 +48,9 @@ def test_encode_to_device_writes_what_encode_writes(oracle, shape, mode):
         assert bytes(dst[cap:].cpu().numpy()) == b"\x5a" * 64
         back, used = oracle.decode(got)
         assert used == len(got) and back == data
-        if len(data) > (1 << 24):  # one wait per block for the parse, one for the stream (+ the pageable upload's none: input in HBM)
-            assert st["host_syncs"] <= st["blocks"] + 2, st
+        if len(data) > (1 << 24):  # two waits per unit for the parse (its read-back; the history count behind a slide by less than a
+            # block: a stream of its own parses 8 MiB units), one for the stream (+ the pageable upload's none: input in HBM)
+            assert st["host_syncs"] <= 2 * st["blocks"] + 2, st
     finally:
         enc.close()
 

@@ -459,9 +459,11 @@ def test_host_waits_per_block_and_the_kernel_table(oracle):
         out, st = enc.encode(data, stats=True)
         units = -(-len(data) // enc.config()["unit_bytes"])
         assert units == 9 and st["blocks"] == units  # (the library counts what it parses as one piece)
-        # round 6: ONE wait per unit (the parse's control block + item count) and two per stream (its length and whatever stopped it;
-        # the one copy of the finished stream to the host) -- the device frames the blocks (orz_stream.h, FrameChunks); round 5: 3 a block
-        assert st["host_syncs"] <= units + 4, st
+        # round 6: TWO waits per unit -- the parse's control block + item count, and the history's item count, which the host knows by
+        # arithmetic only after a slide by a whole block (the encoders of a members job: one wait a block) -- and two per stream
+        # (its length and whatever stopped it; the one copy of the finished stream to the host): the device frames the blocks
+        # (orz_stream.h, FrameChunks); round 5: 3 a block.  (The arithmetic for 8 MiB units was built and made the stream slower: DESIGN 5c.)
+        assert st["host_syncs"] <= 2 * units + 4, st
         enc.set_profile(True)
         out2, st2 = enc.encode(data[:20_000_000], stats=True)
         table = enc.kernel_table()
