@@ -1327,8 +1327,19 @@ struct PathTileDown {
         if (ph == 0) {
             if (!use_lds) return;
             const uint8_t* src = a.x1 + (size_t)c0 * kEntries;  // (c0 * 240 is a multiple of 16)
-            const uint32_t nw = nch * kEntries / 4;
-            for (uint32_t k = tid; k < nw; k += nth) reinterpret_cast<uint32_t*>(lds)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+            // (round 6: sixteen bytes a thread and four of those loads in flight -- ONE workgroup stages up to 90 KB, and a word a
+            // thread a trip was a chain of twenty round trips to memory)
+            struct alignas(16) Q { uint32_t w[4]; };
+            const uint32_t nq = nch * kEntries / 16;
+            const Q* s16 = reinterpret_cast<const Q*>(src);
+            Q* d16 = reinterpret_cast<Q*>(lds);
+            for (uint32_t k0 = tid; k0 < nq; k0 += 4 * nth) {
+                Q v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) if (k0 + u * nth < nq) v[u] = s16[k0 + u * nth];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) if (k0 + u * nth < nq) d16[k0 + u * nth] = v[u];
+            }
         } else if (ph == 1) {
             for (uint32_t k = tid; k < nt * kEntries; k += nth) {
                 const uint32_t t = t0 + k / kEntries, e = k % kEntries;
