@@ -8,18 +8,26 @@
 // v_writelane through M0 and branched on which register held each rank: ~75 ns an item for ranks 0..63, more beyond,
 // 112...117 ns an item in the hottest context of the text workload.
 //
-// Here the wavefront takes 16 items at a time and tracks WHERE THEIR SYMBOLS ARE instead of what sits where: lane 2k holds
-// the current rank of item k's symbol, lane 2k+1 the rank of its excluded symbol (32 lanes: the upper half of EXEC is off
-// while a group runs).  An update of the table is a rotation of three ranks (i -> next_i, next_i -> ni1, ni1 -> i:
-// src/symrank.rs:75-96; a swap or nothing when they coincide), and applying it to the tracked ranks is three compares and
-// three selects whatever the ranks are -- no register choice, no branch.  Item k's rank is then one v_readlane with a
-// constant lane.  value[] lives in LDS and is only needed for the symbols nobody tracks: the two displaced values are read,
-// and written back one item later (the LDS round trip hides behind the next item's instructions); a rank that holds a
-// tracked symbol may be stale in LDS during the group and is rewritten from the lanes when the group ends.  Every item
-// leaves a snapshot of the tracked ranks in LDS (one ds_write); item k's output is read from snapshot k.  31 instructions
-// an item for any rank + the group's start (index[] rebuilt from value[], one lookup a lane) and end.
+// Here the wavefront takes 32 items at a time and tracks WHERE THEIR SYMBOLS ARE instead of what sits where: lane 2k holds
+// the current rank of item k's symbol, lane 2k+1 the rank of its excluded symbol.  An update of the table is a rotation of
+// three ranks (i -> next_i, next_i -> ni1, ni1 -> i: src/symrank.rs:75-96; a swap or nothing when they coincide), and
+// applying it to the 64 tracked ranks is three compares and three selects whatever the ranks are -- no register choice, no
+// branch.  Item k's rank is then one v_readlane with a constant lane (the group's items are unrolled).  value[] lives in LDS
+// and is only needed for the symbols nobody tracks: the two displaced values travel as one read and one write with lane
+// addresses, the write one item late (the LDS round trip hides behind the next item's instructions); a rank that holds a
+// tracked symbol may be stale in LDS during the group and is rewritten from the lanes when the group ends.  Every item leaves
+// a snapshot of the tracked ranks in LDS (one ds_write); item k's output is read from snapshot k.  The group's start rebuilds
+// index[] from value[] (seven reads and seven writes a lane) and looks the next 64 symbols up.
 //
-// The first items of a context's life (count < 192: the quotient moves by more than one an item) and the last < 16 of a
+// Count, sum and the quotient sum / 16 / count are seven scalar instructions and two branches an item -- and the quotient
+// moves once in ~2,000 items.  In the steady state a group therefore runs WITHOUT them (ORZ_SRL_ITEM_S: 22 instructions an
+// item) on the assumption that the quotient stays, and the assumption is checked afterwards from the group's 32 ranks by a
+// prefix sum, one item per lane, the scaling by 9/10 included (its place follows from the count).  A failed check (one
+// group in ~60 on text) puts value[] back and runs the checked group (ORZ_SRL_ITEM: 31 instructions an item).
+// (16 items a group on 32 lanes with the upper half of EXEC off, all compares through VCC, the write-back in mid-item: all
+// measured slower -- DESIGN.md 6a, profiles/r06_symrank_bench.txt.)
+//
+// The first items of a context's life (count < 192: the quotient moves by more than one an item) and the last < 32 of a
 // launch go through a plain loop over index[] / value[] in LDS.
 #pragma once
 #include "orz_kernels.h"
