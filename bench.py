@@ -473,7 +473,8 @@ def main():
                     "36.4 %, bzip2 -9 29.1 % like enwik8), sha256 " + sha[:16],
             "config": {
                 "workload": "BASELINE configs[1]: orz -l1, %d bytes of enwik8-shaped text, single stream per GPU, one 16 MiB block in flight"
-                            % len(data),
+                            % len(data) + ("" if not cfg.get("unit_bytes") or cfg["unit_bytes"] >= (1 << 24) else
+                                           " (parsed in units of %d bytes: the ranking of a unit beside the parse of the next)" % cfg["unit_bytes"]),
                 "mode": "fast" if cfg["mode"] == 1 else "exact",
                 "level": LEVEL,
                 "lzcfg": [int(enc.cfg.match_depth), int(enc.cfg.lazy_match_depth1), int(enc.cfg.lazy_match_depth2)],
